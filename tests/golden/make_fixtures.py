@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json by running the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference, read-only):
+    python3 -B tests/golden/make_fixtures.py
+The reference's verifiable_mpc.ac20.{pivot,compressed_pivot,circuit_sat_r1cs,
+circuit_sat_cb,circuit_builder} are imported unmodified from /root/reference on top
+of the build-written mpyc shim (tests/golden/mpyc_shim), every module-level `prng`
+is replaced by a seeded random.Random, and the inputs/outputs of the hot-path calls
+are recorded.  The fixtures are DATA (inputs, expected outputs, pre-image digests);
+no reference source text is stored.
+
+What these fixtures pin: the reference's protocol logic (hash layout, round structure,
+index conventions, scalar algebra).  What they cannot pin: real MPyC's byte formats,
+because the shim is ours (oracle/ed25519_ref.py header).
+"""
+import hashlib
+import json
+import os
+import random
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(HERE, "mpyc_shim"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+
+# the KoE pivot's BN256 pairing module is out of scope and needs extension fields the
+# shim does not have; a placeholder keeps `import knowledge_of_exponent` working.
+sys.modules["verifiable_mpc.ac20.pairing"] = types.ModuleType("verifiable_mpc.ac20.pairing")
+
+from mpyc.finfields import GF                                   # noqa: E402 (shim)
+from mpyc.fingroups import EllipticCurve                        # noqa: E402 (shim)
+import verifiable_mpc.ac20.pivot as pivot                       # noqa: E402 (reference)
+import verifiable_mpc.ac20.compressed_pivot as compressed_pivot  # noqa: E402
+import verifiable_mpc.ac20.circuit_sat_r1cs as cs_r1cs          # noqa: E402
+from oracle import ed25519_ref as ed                            # noqa: E402
+
+SEED = 20200152
+
+
+def hx(v):
+    return format(int(v), "x")
+
+
+def pt_affine_hex(pt):
+    n = pt.normalize()
+    return [hx(n[0].value), hx(n[1].value)]
+
+
+def pt_proj_hex(pt):
+    return [hx(c.value) for c in pt.value]
+
+
+def typed(v, order):
+    if isinstance(v, int):
+        return "i:" + str(v)
+    return "f:" + hx(int(v) % order)
+
+
+class Recorder:
+    """Wraps pivot.fiat_shamir_hash to record each pre-image's digest and result."""
+
+    def __init__(self, keep_text=False):
+        self.calls = []
+        self.keep_text = keep_text
+        self._orig = pivot.fiat_shamir_hash
+
+    def __enter__(self):
+        def wrapped(input_list, order):
+            text = str(input_list)
+            c = self._orig(input_list, order)
+            rec = {"len": len(text), "sha256": hashlib.sha256(text.encode()).hexdigest(),
+                   "c": hx(c)}
+            if self.keep_text:
+                rec["text"] = text
+            self.calls.append(rec)
+            return c
+        pivot.fiat_shamir_hash = wrapped
+        return self
+
+    def __exit__(self, *a):
+        pivot.fiat_shamir_hash = self._orig
+
+
+def group_and_field():
+    group = EllipticCurve("Ed25519", "projective")   # demos/demo_zkp_ac20.py:46-49
+    group.is_additive = False
+    group.is_multiplicative = True
+    return group, GF(modulus=group.order)
+
+
+def p5_case(n, seed, keep_text=False, keep_proj=False):
+    """Protocol 5 prove+verify on synthetic (L, x) as SURVEY.md section 8d cfg 3."""
+    group, gf = group_and_field()
+    rng = random.Random(seed)
+    # generator exponents: reference draw order r_0..r_{n-1}, then k's (circuit_sat_r1cs.py:64,81)
+    cs_r1cs.prng = random.Random(seed + 1)
+    st = cs_r1cs.prng.getstate()
+    generators = cs_r1cs.create_generators(n, cs_r1cs.PivotChoice.compressed, group)
+    replay = random.Random()
+    replay.setstate(st)
+    exps = [replay.randrange(1, group.order) for _ in range(n)]
+    exp_k = replay.randrange(1, group.order)
+
+    x = [gf(rng.randrange(group.order)) for _ in range(n)]
+    if n >= 7:                     # exercise zero / one / minus-one scalars
+        x[1] = gf(0)
+        x[2] = gf(1)
+        x[3] = gf(-1)
+    gamma = rng.randrange(1, group.order)
+    L = pivot.LinearForm([gf(rng.randrange(group.order)) for _ in range(n)])
+    P = pivot.vector_commitment(x, gamma, generators["g"], generators["h"])
+    y = L(x)
+
+    compressed_pivot.prng = random.Random(seed + 2)
+    st = compressed_pivot.prng.getstate()
+    with Recorder(keep_text) as rec:
+        proof = compressed_pivot.protocol_5_prover(generators, P, L, y, x, gamma, gf)
+        n_prover_hashes = len(rec.calls)
+        ok = compressed_pivot.protocol_5_verifier(generators, P, L, y, proof, gf)
+    replay.setstate(st)
+    r = [replay.randrange(group.order) for _ in range(n)]
+    rho = replay.randrange(group.order)
+    assert ok is True
+    rounds = (n + 1).bit_length() - 2
+    prover_calls = rec.calls[:n_prover_hashes]
+    assert rec.calls[n_prover_hashes:] == prover_calls  # verifier recomputes the same hashes
+    out = {
+        "n": n, "seed": seed, "rounds": rounds,
+        "gen_exponents": [hx(e) for e in exps], "gen_exponent_k": hx(exp_k),
+        "gens_proj_sha256": hashlib.sha256(b"".join(
+            ed.proj_to_bytes(tuple(c.value for c in p.value))
+            for p in generators["g"] + [generators["h"], generators["k"]])).hexdigest(),
+        "x": [hx(v.value) for v in x], "gamma": hx(gamma),
+        "L": [hx(v.value) for v in L.coeffs], "y": hx(y.value),
+        "r": [hx(v) for v in r], "rho": hx(rho),
+        "P": pt_affine_hex(P),
+        "proof": {"t": hx(proof["t"].value), "A": pt_affine_hex(proof["A"]),
+                  "A_i": [pt_affine_hex(proof[f"A{i}"]) for i in range(rounds)],
+                  "B_i": [pt_affine_hex(proof[f"B{i}"]) for i in range(rounds)],
+                  "z_prime": [hx(int(v) % group.order) for v in proof["z_prime"]]},
+        "hashes": prover_calls,      # c0, c1, then one per round
+        "verified": ok,
+    }
+    if keep_proj:
+        out["gens_proj"] = [pt_proj_hex(p) for p in generators["g"]] + \
+            [pt_proj_hex(generators["h"]), pt_proj_hex(generators["k"])]
+    return out
+
+
+def pis_case(n, seed):
+    """Basic pivot Pi_s (pivot.py:156-205)."""
+    group, gf = group_and_field()
+    rng = random.Random(seed)
+    exps = [rng.randrange(1, group.order) for _ in range(n)]
+    g = [group.generator ** e for e in exps]
+    h = group.generator
+    x = [gf(rng.randrange(group.order)) for _ in range(n)]
+    gamma = rng.randrange(1, group.order)
+    L = pivot.LinearForm([gf(rng.randrange(group.order)) for _ in range(n)])
+    P = pivot.vector_commitment(x, gamma, g, h)
+    y = L(x)
+    pivot.prng = random.Random(seed + 2)
+    st = pivot.prng.getstate()
+    with Recorder() as rec:
+        z, phi, c = pivot.prove_linear_form_eval(g, h, P, L, y, x, gamma, gf)
+        ok = pivot.verify_linear_form_proof(g, h, P, L, y, z, phi, c)
+    replay = random.Random()
+    replay.setstate(st)
+    r = [replay.randrange(gf.order) for _ in range(n)]
+    rho = replay.randrange(gf.order)
+    assert ok is True
+    return {"n": n, "seed": seed, "gen_exponents": [hx(e) for e in exps],
+            "x": [hx(v.value) for v in x], "gamma": hx(gamma),
+            "L": [hx(v.value) for v in L.coeffs], "y": hx(y.value),
+            "r": [hx(v) for v in r], "rho": hx(rho), "P": pt_affine_hex(P),
+            "z": [hx(v.value) for v in z], "phi": hx(phi), "c": hx(c),
+            "hashes": rec.calls, "verified": ok}
+
+
+def forms_case():
+    """Known answers of the reference's own LinearForm test (ac20/test/test_pivot.py:84-90)."""
+    lf = pivot.LinearForm([0, 1, 2])
+    return {"expr_27": (lf + lf + 2 * lf + lf.eval([1, 1, 1]) - lf).eval([1, 2, 3]),
+            "expr_8": lf([1, 2, 3])}
+
+
+def demo_case(seed):
+    """BASELINE config 1: demos/demo_zkp_ac20.py --elliptic (n=3), seeded, with the
+    Protocol-5 call (compressed_pivot.py:89) intercepted."""
+    import contextlib
+    import io
+    import verifiable_mpc.ac20.circuit_sat_cb as cs_cb
+    import verifiable_mpc.ac20.circuit_builder as cb
+    sys.path.insert(0, "/root/reference/demos")
+    import demo_zkp_ac20 as demo
+    demo.GROUP = "Elliptic"                    # what the --elliptic flag sets (:107-108)
+    for i, mod in enumerate((cs_r1cs, cs_cb, compressed_pivot, pivot, cb)):
+        mod.prng = random.Random(seed + 10 + i)
+    gen_state = cs_r1cs.prng.getstate()
+    captured = {}
+    orig_p5 = compressed_pivot.protocol_5_prover
+
+    def spy(generators, P, L, y, x, gamma, gf):
+        st = compressed_pivot.prng.getstate()
+        with Recorder() as rec:
+            proof = orig_p5(generators, P, L, y, x, gamma, gf)
+        replay = random.Random()
+        replay.setstate(st)
+        n = len(x)
+        order = gf.order
+        r = [replay.randrange(order) for _ in range(n)]
+        rho = replay.randrange(order)
+        rounds = (n + 1).bit_length() - 2
+        replay.setstate(gen_state)
+        exps = [replay.randrange(1, order) for _ in range(n)]
+        exp_k = replay.randrange(1, order)
+        captured.update({
+            "n": n, "rounds": rounds,
+            "gen_exponents": [hx(e) for e in exps], "gen_exponent_k": hx(exp_k),
+            # Python typing of the scalar inputs matters to the transcript: plain ints stay
+            # unreduced through pivot.py:62-70; "i:<decimal>" = int, "f:<hex residue>" = GF(l)
+            "x_typed": [typed(v, order) for v in x], "gamma": hx(gamma),
+            "L_typed": [typed(v, order) for v in L.coeffs],
+            "L_constant_typed": typed(L.constant, order), "y_typed": typed(y, order),
+            "x": [hx(int(v) % order) for v in x],
+            "L": [hx(int(v) % order) for v in L.coeffs],
+            "L_constant": hx(int(L.constant) % order), "y": hx(int(y) % order),
+            "r": [hx(v) for v in r], "rho": hx(rho), "P": pt_affine_hex(P),
+            "proof": {"t": hx(int(proof["t"]) % order), "A": pt_affine_hex(proof["A"]),
+                      "A_i": [pt_affine_hex(proof[f"A{i}"]) for i in range(rounds)],
+                      "B_i": [pt_affine_hex(proof[f"B{i}"]) for i in range(rounds)],
+                      "z_prime": [hx(int(v) % order) for v in proof["z_prime"]]},
+            "hashes": rec.calls,
+        })
+        return proof
+
+    compressed_pivot.protocol_5_prover = spy
+    try:
+        with contextlib.redirect_stdout(io.StringIO()) as buf:
+            verification = demo.main(cs_cb.PivotChoice.compressed, 3)
+    finally:
+        compressed_pivot.protocol_5_prover = orig_p5
+    captured["verification"] = verification
+    captured["stdout_head"] = [l for l in buf.getvalue().replace("\r", "\n").split("\n")
+                               if l.startswith("Length of")]
+    return captured
+
+
+def main():
+    out = {
+        "forms": forms_case(),
+        "p5": [p5_case(3, SEED, keep_text=True, keep_proj=True),
+               p5_case(7, SEED + 100, keep_proj=True),
+               p5_case(15, SEED + 200),
+               p5_case(127, SEED + 300)],
+        "pis": [pis_case(4, SEED + 400)],
+    }
+    with open(os.path.join(HERE, "ac20_ed25519_small.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    with open(os.path.join(HERE, "ac20_ed25519_n1023.json"), "w") as f:
+        json.dump(p5_case(1023, SEED + 500), f, indent=0, sort_keys=True)
+    try:
+        demo = demo_case(SEED + 600)
+        with open(os.path.join(HERE, "demo_zkp_ac20_elliptic.json"), "w") as f:
+            json.dump(demo, f, indent=0, sort_keys=True)
+        print("demo:", demo["n"], demo["verification"], demo["stdout_head"])
+    except Exception as e:      # the demo needs more of mpyc than the P5 path
+        print("demo fixture not generated:", type(e).__name__, e)
+    print("fixtures written")
+
+
+if __name__ == "__main__":
+    main()
