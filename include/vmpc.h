@@ -1,0 +1,149 @@
+/* vmpc.h - C-ABI of the MI355X-native AC20 hot path (libvmpc_hip.so).
+ *
+ * The reference (toonsegers/verifiable_mpc) is pure Python and has NO FFI of its own:
+ * its seam is the Python functions of verifiable_mpc/ac20/pivot.py and
+ * compressed_pivot.py and the MPyC group-element operators they use.
+ * Each entry point below names the reference call site whose work it takes over; the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md and implemented in
+ * verifiable_mpc_amd/_native.py.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / Python types;
+ *  - scalars: 32 bytes little-endian, canonical residue < l (l = Ed25519 group order);
+ *  - affine points: 64 bytes x||y little-endian, canonical residues < p = 2^255-19;
+ *  - projective points: 96 bytes X||Y||Z (representative preserved, see ge25519.cuh);
+ *  - extended points: 128 bytes X||Y||Z||T;
+ *  - every function returns 0 on success or a negative VMPC_E_* code; the library never
+ *    retains host pointers past a call and never draws randomness (the reference draws
+ *    r, rho and generator exponents in Python: compressed_pivot.py:105-106,
+ *    circuit_sat_r1cs.py:64,81);
+ *  - *_dev functions take DEVICE pointers, enqueue on the context's stream and return
+ *    without synchronising unless stated; buffers may come from vmpc_malloc or from any
+ *    other HIP allocator (e.g. torch tensors' data_ptr()).
+ *  - one context per host thread / GPU; no global mutable state besides the HIP runtime.
+ */
+#ifndef VMPC_H
+#define VMPC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMPC_OK 0
+#define VMPC_E_INVAL (-22)      /* bad length / null pointer / bad flag */
+#define VMPC_E_NONCANON (-34)   /* scalar >= l or coordinate >= p */
+#define VMPC_E_NOTONCURVE (-33) /* affine point does not satisfy the curve equation */
+#define VMPC_E_NOMEM (-12)
+#define VMPC_E_HIP (-5)         /* HIP runtime error, see vmpc_last_error() */
+#define VMPC_E_NODEV (-19)      /* no GPU visible */
+
+#define VMPC_SCALAR_BYTES 32
+#define VMPC_AFFINE_BYTES 64
+#define VMPC_PROJ_BYTES 96
+#define VMPC_EXT_BYTES 128
+
+typedef struct vmpc_ctx vmpc_ctx;
+
+/* ---- runtime ------------------------------------------------------------------- */
+/* number of visible GPUs (or VMPC_E_*); writes "gfx950 MI355X ..." style text */
+int vmpc_backend_info(char *buf, size_t buflen);
+const char *vmpc_last_error(void);
+int vmpc_ctx_create(int device, vmpc_ctx **out);
+int vmpc_ctx_destroy(vmpc_ctx *ctx);
+/* run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int vmpc_ctx_set_stream(vmpc_ctx *ctx, void *hip_stream);
+int vmpc_ctx_sync(vmpc_ctx *ctx);
+int vmpc_malloc(vmpc_ctx *ctx, size_t bytes, void **dptr);
+int vmpc_free(vmpc_ctx *ctx, void *dptr);
+int vmpc_memcpy_h2d(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronous */
+int vmpc_memcpy_d2h(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronous */
+int vmpc_memcpy_d2d(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes); /* async */
+/* per-stage HIP-event timing of the MSM pipeline (bench.py roofline leg) */
+int vmpc_ctx_profile(vmpc_ctx *ctx, int enable);
+/* sums since the last reset; names is a ';'-separated list matching ms[] */
+int vmpc_ctx_profile_read(vmpc_ctx *ctx, char *names, size_t names_len, double *ms,
+                          uint64_t *launches, int max_stages, int reset);
+/* Pippenger window width override (0 = automatic); for tuning / tests */
+int vmpc_ctx_set_window(vmpc_ctx *ctx, int c_bits);
+
+/* ---- host-buffer one-shots (SURVEY.md 8b proposal) -------------------------------- */
+/* h^gamma-less MSM: out = sum scalars[i] * points[i].
+ * Replaces the list comprehension + reduce of pivot.vector_commitment,
+ * verifiable_mpc/ac20/pivot.py:143-144 (called from circuit_sat_cb.py:103 and
+ * compressed_pivot.py:41,42,110,193). */
+int vmpc_ed25519_msm(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out[64]);
+/* out[i] = c * pts_l[i] + pts_r[i]: the generator fold of
+ * verifiable_mpc/ac20/compressed_pivot.py:64 (prover) and :178 (verifier). */
+int vmpc_ed25519_fold(const uint8_t *pts_l, const uint8_t *pts_r, const uint8_t c[32],
+                      size_t half, uint8_t *out);
+/* out[i] = scalars[i] * base: generator setup g_i = h ** r_i,
+ * verifiable_mpc/ac20/circuit_sat_r1cs.py:64-70,81. */
+int vmpc_ed25519_fixed_base_batch(const uint8_t base[64], const uint8_t *scalars, size_t n,
+                                  uint8_t *out);
+/* out[i] = c * x[i] + y[i] mod l: z' = z_l + c z_r and L' = c L_l + L_r,
+ * verifiable_mpc/ac20/compressed_pivot.py:70-76; z = c0 x + r, :134. */
+int vmpc_fr_axpy(const uint8_t c[32], const uint8_t *x, const uint8_t *y, size_t n, uint8_t *out);
+/* out = sum a[i] * b[i] mod l: LinearForm evaluation, verifiable_mpc/ac20/pivot.py:84-92. */
+int vmpc_fr_dot(const uint8_t *a, const uint8_t *b, size_t n, uint8_t out[32]);
+
+/* ---- device-resident entry points ---------------------------------------------------- */
+/* canonical-encoding + on-curve check of n affine points; *n_bad = number of offenders (sync) */
+int vmpc_points_validate_dev(vmpc_ctx *ctx, const void *affine, size_t n, uint64_t *n_bad);
+
+/* Pedersen vector commitment as one MSM over n + n_extra terms
+ * (pivot.py:139-145: the extra term is h ** gamma).  Any of out_ext / out_affine may be
+ * NULL.  Scalars must be canonical (checked on device, reported at the next sync point
+ * through vmpc_ctx_sync -> VMPC_E_NONCANON). */
+int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affine_points, size_t n,
+                 const void *extra_scalars, const void *extra_affine_points, size_t n_extra,
+                 void *out_ext, void *out_affine);
+
+/* sum of m extended points in index order, normalised (multi-GPU combine of the per-rank
+ * partial commitments; also A * Q^c * B^(c^2) style products once the powers are points) */
+int vmpc_points_sum_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, void *out_ext,
+                        void *out_affine);
+
+/* element-wise `base_i ** n_i` replaying the reference's operation sequence (ge25519.cuh):
+ * bases are projective (96 B) or, with bases_affine != 0, affine (64 B, Z = 1); a single
+ * base is broadcast when n_bases == 1.  signed_scalars != 0 applies the reference's
+ * pivot._int convention (pivot.py:119-128): residues above l/2 act as negative exponents.
+ * Outputs: projective representatives (may be NULL) and/or affine (may be NULL). */
+int vmpc_repeat_dev(vmpc_ctx *ctx, const void *bases, size_t n_bases, int bases_affine,
+                    const void *scalars, size_t n, int signed_scalars, void *out_proj,
+                    void *out_affine);
+
+/* g'_i = (g_l[i] ** c) * g_r[i], compressed_pivot.py:64/:178, replayed exactly.
+ * in_affine != 0: inputs are 64-byte affine points (Z = 1), else 96-byte projective. */
+int vmpc_fold_dev(vmpc_ctx *ctx, const void *g_l, const void *g_r, int in_affine,
+                  const uint8_t c[32], size_t half, void *out_proj, void *out_affine);
+
+/* pivot.list_mul (pivot.py:26-28): balanced pairwise product tree of n projective points
+ * in the reference's order, optional identity appended at the end; `points` is clobbered. */
+int vmpc_tree_reduce_dev(vmpc_ctx *ctx, void *proj_points, size_t n, int append_identity,
+                         void *out_proj);
+
+/* .normalize() for a whole vector (compressed_pivot.py:52,118): projective -> affine */
+int vmpc_normalize_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *out_affine);
+/* affine (x, y) -> projective (x, y, 1) */
+int vmpc_affine_to_proj_dev(vmpc_ctx *ctx, const void *affine, size_t n, void *out_proj);
+
+int vmpc_fr_axpy_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *x, const void *y, size_t n,
+                     void *out);
+int vmpc_fr_scale_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *x, size_t n, void *out);
+/* synchronous: result copied to host */
+int vmpc_fr_dot_dev(vmpc_ctx *ctx, const void *a, const void *b, size_t n, uint8_t out[32]);
+
+/* Text of the Fiat-Shamir pre-image (pivot.py:134 str(input_list)) produced on device:
+ * "item0, item1, ..., item{n-1}, " (every item followed by ", ").  Synchronous; *len gets
+ * the number of bytes written, VMPC_E_NOMEM if cap is too small. */
+int vmpc_format_points_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *out_text, size_t cap,
+                           uint64_t *len);
+int vmpc_format_scalars_dev(vmpc_ctx *ctx, const void *scalars, size_t n, int is_signed,
+                            void *out_text, size_t cap, uint64_t *len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,293 @@
+"""GPU parity tests of the C-ABI kernels against the oracle (bit-exact, integer work).
+
+Every call goes through libvmpc_hip.so via ctypes (verifiable_mpc_amd/_native.py).
+Sizes are kept where the pure-Python oracle finishes in seconds; larger sizes are covered
+by size-independent properties in tests/test_gpu_msm_large.py.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import ac20_ref as ac
+from oracle import ed25519_ref as ed
+
+pytestmark = pytest.mark.gpu
+
+ELL, P = ed.ELL, ed.P
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from verifiable_mpc_amd import _native
+    n, info = _native.backend_info()
+    assert n >= 1, info
+    return _native
+
+
+@pytest.fixture(scope="module")
+def ctx(nat):
+    c = nat.Context(0)
+    yield c
+    c.close()
+
+
+def aff_bytes(pts):
+    return np.frombuffer(b"".join(ed.affine_to_bytes(p) for p in pts), dtype=np.uint8).reshape(-1, 64)
+
+
+def proj_bytes(pts):
+    return np.frombuffer(b"".join(ed.proj_to_bytes(p) for p in pts), dtype=np.uint8).reshape(-1, 96)
+
+
+def sc_bytes(nat, vals):
+    return nat.ints_to_array([v % ELL for v in vals], 32)
+
+
+def make_points(rng, n):
+    exps = [rng.randrange(1, ELL) for _ in range(n)]
+    return exps, [ed.pt_repeat(ed.BASE, e) for e in exps]
+
+
+def dl_aff(ctx, ptr, n=1):
+    raw = ctx.download(ptr, 64 * n).tobytes()
+    return [ed.affine_from_bytes(raw[64 * i:64 * i + 64]) for i in range(n)]
+
+
+def dl_proj(ctx, ptr, n=1):
+    raw = ctx.download(ptr, 96 * n).tobytes()
+    return [ed.proj_from_bytes(raw[96 * i:96 * i + 96]) for i in range(n)]
+
+
+def test_backend_info(nat):
+    n, info = nat.backend_info()
+    assert "gfx950" in info, info
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 300])
+def test_msm_matches_oracle_vector_commitment(nat, ctx, n):
+    """vmpc_msm_dev == pivot.vector_commitment restated (pivot.py:139-145), incl. the
+    h**gamma term passed as the extra segment."""
+    rng = random.Random(100 + n)
+    _, g = make_points(rng, n + 1)
+    h, g = g[-1], g[:-1]
+    x = [rng.randrange(ELL) for _ in range(n)]
+    for i, v in enumerate([0, 1, ELL - 1, 2, ELL // 2, ELL // 2 + 1]):
+        if i < n:
+            x[i] = v
+    gamma = rng.randrange(ELL)
+    want = ed.pt_affine(ac.vector_commitment(x, gamma, g, h))
+    ds, dp = ctx.upload(sc_bytes(nat, x)), ctx.upload(aff_bytes(g))
+    dg, dh = ctx.upload(sc_bytes(nat, [gamma])), ctx.upload(aff_bytes([h]))
+    out_ext, out_aff = ctx.alloc(128), ctx.alloc(64)
+    ctx.msm(ds.ptr, dp.ptr, n, dg.ptr, dh.ptr, 1, out_ext.ptr, out_aff.ptr)
+    ctx.sync()
+    got = dl_aff(ctx, out_aff.ptr)[0]
+    assert got[:2] == want
+    # the extended output is the same group element
+    raw = ctx.download(out_ext.ptr, 128).tobytes()
+    X, Y, Z, T = (int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(4))
+    assert ed.pt_affine((X, Y, Z)) == want and (X * Y - T * Z) % P == 0
+
+
+@pytest.mark.parametrize("c_bits", [4, 5, 8, 11, 13, 16])
+def test_msm_every_window_width(nat, ctx, c_bits):
+    """the result must not depend on the Pippenger window; exercises carries in the signed
+    recoding and the chunked bucket reduction at each width."""
+    rng = random.Random(7)
+    n = 200
+    exps, g = make_points(rng, n)
+    x = [rng.randrange(ELL) for _ in range(n)]
+    x[0], x[1], x[2] = ELL - 1, 2**252, (1 << 252) - 1
+    want = ed.pt_affine(ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(x, exps)) % ELL))
+    ds, dp = ctx.upload(sc_bytes(nat, x)), ctx.upload(aff_bytes(g))
+    out = ctx.alloc(64)
+    ctx.set_window(c_bits)
+    try:
+        ctx.msm(ds.ptr, dp.ptr, n, None, None, 0, None, out.ptr)
+        ctx.sync()
+    finally:
+        ctx.set_window(0)
+    assert dl_aff(ctx, out.ptr)[0][:2] == want
+
+
+def test_msm_edge_cases(nat, ctx):
+    rng = random.Random(9)
+    exps, g = make_points(rng, 8)
+    out = ctx.alloc(64)
+    dp = ctx.upload(aff_bytes(g))
+    # empty product = identity (pivot.list_mul's initial value)
+    ctx.msm(None, None, 0, None, None, 0, None, out.ptr)
+    ctx.sync()
+    assert dl_aff(ctx, out.ptr)[0][:2] == (0, 1)
+    # all-zero scalars = identity
+    ds = ctx.upload(sc_bytes(nat, [0] * 8))
+    ctx.msm(ds.ptr, dp.ptr, 8, None, None, 0, None, out.ptr)
+    ctx.sync()
+    assert dl_aff(ctx, out.ptr)[0][:2] == (0, 1)
+    # P + (-P): scalars 1 and l-1 on the same point
+    dp2 = ctx.upload(aff_bytes([g[0], g[0]]))
+    ds2 = ctx.upload(sc_bytes(nat, [1, ELL - 1]))
+    ctx.msm(ds2.ptr, dp2.ptr, 2, None, None, 0, None, out.ptr)
+    ctx.sync()
+    assert dl_aff(ctx, out.ptr)[0][:2] == (0, 1)
+    # identity point among the generators
+    dp3 = ctx.upload(aff_bytes([ed.IDENTITY, g[1]]))
+    ds3 = ctx.upload(sc_bytes(nat, [5, 7]))
+    ctx.msm(ds3.ptr, dp3.ptr, 2, None, None, 0, None, out.ptr)
+    ctx.sync()
+    assert dl_aff(ctx, out.ptr)[0][:2] == ed.pt_affine(ed.pt_repeat(g[1], 7))
+    # non-canonical scalar is reported at the sync point
+    bad = np.frombuffer(ELL.to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32)
+    dsb = ctx.upload(bad)
+    ctx.msm(dsb.ptr, dp.ptr, 1, None, None, 0, None, out.ptr)
+    with pytest.raises(nat.VmpcError) as ei:
+        ctx.sync()
+    assert ei.value.code == nat.E_NONCANON
+    ctx.sync()  # status word was cleared
+
+
+def test_repeat_replays_reference_sequence(nat, ctx):
+    """`g ** n` gives the oracle's exact projective representative (Z included)."""
+    rng = random.Random(11)
+    _, pts = make_points(rng, 6)
+    bases = [ed.BASE, ed.IDENTITY] + pts + [ed.pt_add(pts[0], pts[1]), ed.pt_dbl(pts[2])]
+    scal = [0, 1, 2, 3, ELL - 1, ELL // 2, ELL // 2 + 1, 2**252, 2**64, rng.randrange(ELL)]
+    scal = (scal * 2)[:len(bases)]
+    db, ds = ctx.upload(proj_bytes(bases)), ctx.upload(sc_bytes(nat, scal))
+    n = len(bases)
+    op, oa = ctx.alloc(96 * n), ctx.alloc(64 * n)
+    for signed in (False, True):
+        ctx.repeat(db.ptr, n, False, ds.ptr, n, signed, op.ptr, oa.ptr)
+        ctx.sync()
+        want = [ed.pt_repeat(b, ed.scalar_int(s) if signed else s) for b, s in zip(bases, scal)]
+        assert dl_proj(ctx, op.ptr, n) == want
+        assert [a[:2] for a in dl_aff(ctx, oa.ptr, n)] == [ed.pt_affine(w) for w in want]
+    # broadcast of one affine base: create_generators (circuit_sat_r1cs.py:64-70)
+    exps = [rng.randrange(1, ELL) for _ in range(40)]
+    dbase, dexp = ctx.upload(aff_bytes([ed.BASE])), ctx.upload(sc_bytes(nat, exps))
+    op2 = ctx.alloc(96 * 40)
+    ctx.repeat(dbase.ptr, 1, True, dexp.ptr, 40, False, op2.ptr, None)
+    ctx.sync()
+    assert dl_proj(ctx, op2.ptr, 40) == ac.create_generators(exps)["g"]
+
+
+def test_fold_replays_reference_sequence(nat, ctx):
+    """g' = (g_l ** c) * g_r, compressed_pivot.py:64: exact (X, Y, Z) and affine."""
+    rng = random.Random(12)
+    half = 37
+    gl = ac.create_generators([rng.randrange(1, ELL) for _ in range(half)])["g"]   # Z != 1
+    gr = ac.create_generators([rng.randrange(1, ELL) for _ in range(half)])["g"]
+    for c in (rng.randrange(ELL), 1, 0, ELL - 1):
+        want = ac.fold_generators(gl, gr, c)
+        dl_, dr_ = ctx.upload(proj_bytes(gl)), ctx.upload(proj_bytes(gr))
+        op, oa = ctx.alloc(96 * half), ctx.alloc(64 * half)
+        ctx.fold(dl_.ptr, dr_.ptr, False, c, half, op.ptr, oa.ptr)
+        ctx.sync()
+        assert dl_proj(ctx, op.ptr, half) == want
+        assert [a[:2] for a in dl_aff(ctx, oa.ptr, half)] == [ed.pt_affine(w) for w in want]
+    # affine inputs (Z = 1)
+    gla, gra = [ed.pt_normalize(p) for p in gl], [ed.pt_normalize(p) for p in gr]
+    c = rng.randrange(ELL)
+    da, dbb = ctx.upload(aff_bytes(gla)), ctx.upload(aff_bytes(gra))
+    op = ctx.alloc(96 * half)
+    ctx.fold(da.ptr, dbb.ptr, True, c, half, op.ptr, None)
+    ctx.sync()
+    assert dl_proj(ctx, op.ptr, half) == ac.fold_generators(gla, gra, c)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 13, 64, 65])
+def test_tree_reduce_order(nat, ctx, n):
+    """pivot.list_mul (pivot.py:26-28): same tree shape => same projective representative."""
+    rng = random.Random(13 + n)
+    pts = ac.create_generators([rng.randrange(1, ELL) for _ in range(n)])["g"]
+    for append in (True, False):
+        d = ctx.upload(proj_bytes(pts))
+        out = ctx.alloc(96)
+        ctx.tree_reduce(d.ptr, n, append, out.ptr)
+        ctx.sync()
+        want = ed.tree_reduce(ed.pt_add, pts, ed.IDENTITY if append else None)
+        assert dl_proj(ctx, out.ptr)[0] == want
+
+
+def test_normalize_and_lift(nat, ctx):
+    rng = random.Random(14)
+    pts = ac.create_generators([rng.randrange(1, ELL) for _ in range(20)])["g"] + [ed.IDENTITY]
+    n = len(pts)
+    d = ctx.upload(proj_bytes(pts))
+    oa, op = ctx.alloc(64 * n), ctx.alloc(96 * n)
+    ctx.normalize(d.ptr, n, oa.ptr)
+    ctx.affine_to_proj(oa.ptr, n, op.ptr)
+    ctx.sync()
+    assert [a[:2] for a in dl_aff(ctx, oa.ptr, n)] == [ed.pt_affine(p) for p in pts]
+    assert dl_proj(ctx, op.ptr, n) == [ed.pt_normalize(p) for p in pts]
+    assert ctx.validate_points(oa.ptr, n) == 0
+    # off-curve and non-canonical encodings are counted
+    bad = aff_bytes(pts[:3]).copy()
+    bad[0, 0] ^= 1
+    bad[1, 32:64] = np.frombuffer((P + 1).to_bytes(32, "little"), dtype=np.uint8)
+    assert ctx.validate_points(ctx.upload(bad).ptr, 3) == 2
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 5000])
+def test_fr_vector_ops(nat, ctx, n):
+    rng = random.Random(15 + n)
+    x = [rng.randrange(ELL) for _ in range(n)]
+    y = [rng.randrange(ELL) for _ in range(n)]
+    x[0], y[0] = ELL - 1, ELL - 1
+    c = rng.randrange(ELL)
+    dx, dy = ctx.upload(sc_bytes(nat, x)), ctx.upload(sc_bytes(nat, y))
+    out = ctx.alloc(32 * n)
+    ctx.fr_axpy(c, dx.ptr, dy.ptr, n, out.ptr)
+    assert nat.array_to_ints(ctx.download(out.ptr, 32 * n, (n, 32))) == [(c * a + b) % ELL for a, b in zip(x, y)]
+    ctx.fr_scale(c, dx.ptr, n, out.ptr)
+    assert nat.array_to_ints(ctx.download(out.ptr, 32 * n, (n, 32))) == [(c * a) % ELL for a in x]
+    assert ctx.fr_dot(dx.ptr, dy.ptr, n) == sum(a * b for a, b in zip(x, y)) % ELL
+    # in-place axpy (z' overwrites z_l)
+    ctx.fr_axpy(c, dy.ptr, dx.ptr, n, dx.ptr)
+    assert nat.array_to_ints(ctx.download(dx.ptr, 32 * n, (n, 32))) == [(c * b + a) % ELL for a, b in zip(x, y)]
+
+
+def test_transcript_text(nat, ctx):
+    """device-formatted text == the oracle's str() restatement (pivot.py:134)."""
+    rng = random.Random(16)
+    pts = ac.create_generators([rng.randrange(1, ELL) for _ in range(300)])["g"]
+    pts += [ed.IDENTITY, ed.BASE, (0, 5, 7), (10**76, 1, 10**9)]
+    txt = ctx.format_points(ctx.upload(proj_bytes(pts)).ptr, len(pts)).tobytes().decode()
+    assert txt == "".join(ed.pt_repr(p) + ", " for p in pts)
+    sc = [rng.randrange(ELL) for _ in range(2500)] + [0, 1, ELL - 1, ELL // 2, ELL // 2 + 1, 10**9, 10**9 - 1]
+    d = ctx.upload(sc_bytes(nat, sc))
+    txt = ctx.format_scalars(d.ptr, len(sc), True).tobytes().decode()
+    assert txt == "".join(ed.scalar_repr(v) + ", " for v in sc)
+    txt = ctx.format_scalars(d.ptr, len(sc), False).tobytes().decode()
+    assert txt == "".join(str(v) + ", " for v in sc)
+
+
+def test_host_one_shots(nat):
+    rng = random.Random(17)
+    exps, g = make_points(rng, 24)
+    x = [rng.randrange(ELL) for _ in range(24)]
+    out = nat.ed25519_msm(sc_bytes(nat, x), aff_bytes(g))
+    want = ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(x, exps)) % ELL)
+    assert ed.affine_from_bytes(out.tobytes())[:2] == ed.pt_affine(want)
+    c = rng.randrange(ELL)
+    got = nat.ed25519_fold(aff_bytes(g[:12]), aff_bytes(g[12:]), c)
+    want = [ed.pt_affine(p) for p in ac.fold_generators(g[:12], g[12:], c)]
+    assert [ed.affine_from_bytes(got[i].tobytes())[:2] for i in range(12)] == want
+    got = nat.ed25519_fixed_base_batch(aff_bytes([ed.BASE]), sc_bytes(nat, exps))
+    assert [ed.affine_from_bytes(got[i].tobytes())[:2] for i in range(24)] == [ed.pt_affine(p) for p in g]
+    y = [rng.randrange(ELL) for _ in range(24)]
+    assert nat.array_to_ints(nat.fr_axpy(c, sc_bytes(nat, x), sc_bytes(nat, y))) == \
+        [(c * a + b) % ELL for a, b in zip(x, y)]
+    assert nat.fr_dot(sc_bytes(nat, x), sc_bytes(nat, y)) == sum(a * b for a, b in zip(x, y)) % ELL
+    # error conventions of the boundary
+    offcurve = aff_bytes(g).copy()
+    offcurve[3, 5] ^= 0x40
+    with pytest.raises(nat.VmpcError) as ei:
+        nat.ed25519_msm(sc_bytes(nat, x), offcurve)
+    assert ei.value.code == nat.E_NOTONCURVE
+    bad_sc = sc_bytes(nat, x).copy()
+    bad_sc[0] = np.frombuffer((ELL + 5).to_bytes(32, "little"), dtype=np.uint8)
+    with pytest.raises(nat.VmpcError) as ei:
+        nat.ed25519_msm(bad_sc, aff_bytes(g))
+    assert ei.value.code == nat.E_NONCANON

@@ -1,0 +1,136 @@
+"""CPU check of the device math headers (fe25519/ge25519/fr/fmt .cuh).
+
+The headers are `__host__ __device__`; this test builds them with g++ into a small
+harness (tests/native/host_math_test.cpp) and compares every operation with the
+Python oracle on random and edge-case operands.  It does not replace the `-m gpu`
+parity tests (which call the kernels through the C-ABI); it catches arithmetic bugs
+before GPU time is spent.
+"""
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import ed25519_ref as ed
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "host_math_test.cpp")
+P, ELL = ed.P, ed.ELL
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("native") / "host_math_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, SRC])
+
+    def run(lines):
+        out = subprocess.run([exe], input="\n".join(lines) + "\nquit\n", text=True,
+                             capture_output=True, check=True).stdout.strip().split("\n")
+        assert len(out) == len(lines), (len(out), len(lines))
+        return out
+    return run
+
+
+def hx(v):
+    return format(v, "x")
+
+
+EDGE = [0, 1, 2, 19, 38, P - 1, P, P + 1, 2 * P, 2 * P + 37, 2**255, 2**256 - 1, 2**256 - 38,
+        2**255 - 20, 2**32 - 1, 2**224 - 1, (2**256 - 1) ^ (2**128)]
+
+
+def test_field_ops(harness):
+    rng = random.Random(1)
+    vals = EDGE + [rng.getrandbits(256) for _ in range(60)]
+    pairs = [(a, b) for a in EDGE for b in EDGE] + \
+            [(rng.choice(vals), rng.choice(vals)) for _ in range(300)]
+    lines, want = [], []
+    for a, b in pairs:
+        lines += [f"femul {hx(a)} {hx(b)}", f"feadd {hx(a)} {hx(b)}", f"fesub {hx(a)} {hx(b)}"]
+        want += [hx(a * b % P), hx((a + b) % P), hx((a - b) % P)]
+    for a in vals:
+        lines += [f"fesqr {hx(a)}", f"fecanon {hx(a)}", f"femulu32 {hx(a)} {hx(rng.getrandbits(32))}"]
+        s = int(lines[-1].split()[-1], 16)
+        want += [hx(a * a % P), f"{hx(a % P)} {1 if a < P else 0}", hx(a * s % P)]
+        if a % P:
+            lines.append(f"feinv {hx(a)}")
+            want.append(hx(pow(a, P - 2, P)))
+    lines.append("consts")
+    want.append(f"{hx(ed.D)} {hx(ed.D2)}")
+    assert harness(lines) == want
+
+
+def test_scalar_field_ops(harness):
+    rng = random.Random(2)
+    vals = [0, 1, 2, ELL - 1, ELL - 2, ELL // 2, ELL // 2 + 1, 2**252, 2**252 - 1] + \
+           [rng.randrange(ELL) for _ in range(100)]
+    lines, want = [], []
+    for _ in range(400):
+        a, b = rng.choice(vals), rng.choice(vals)
+        lines += [f"fradd {hx(a)} {hx(b)}", f"frsub {hx(a)} {hx(b)}", f"frmul {hx(a)} {hx(b)}"]
+        want += [hx((a + b) % ELL), hx((a - b) % ELL), hx(a * b % ELL)]
+    for x in [0, 1, ELL, ELL - 1, 2**512 - 1, 2**511, ELL * ELL, (ELL - 1) ** 2, 2**256 - 1, 2**256] + \
+            [rng.getrandbits(512) for _ in range(100)]:
+        lines.append(f"frred {hx(x)}")
+        want.append(hx(x % ELL))
+    for a in vals:
+        for sg in (0, 1):
+            lines.append(f"frrepr {hx(a)} {sg}")
+            s = str(a - ELL) if (sg and a > ELL // 2) else str(a)
+            want.append(f"{s} {len(s)}")
+    assert harness(lines) == want
+
+
+def test_decimal(harness):
+    rng = random.Random(3)
+    vals = [0, 1, 9, 10, 10**9 - 1, 10**9, 10**18, 10**77, 10**77 - 1, 2**256 - 1, P - 1] + \
+           [rng.getrandbits(rng.randrange(1, 257)) for _ in range(200)]
+    out = harness([f"dec {hx(v)}" for v in vals])
+    assert out == [f"{v} {len(str(v))}" for v in vals]
+
+
+def rand_point(rng):
+    return ed.pt_repeat(ed.BASE, rng.randrange(1, ELL))
+
+
+def test_projective_replay(harness):
+    """add-2008-bbjlp / dbl-2008-bbjlp / right-to-left repeat give the oracle's exact
+    (X, Y, Z) representatives, not merely the same group element."""
+    rng = random.Random(4)
+    lines, want = [], []
+    pts = [ed.IDENTITY, ed.BASE] + [rand_point(rng) for _ in range(6)]
+    pts += [ed.pt_add(pts[2], pts[3]), ed.pt_dbl(pts[4])]          # Z != 1
+    f3 = lambda t: " ".join(hx(c) for c in t)
+    for p in pts:
+        for q in pts[:5]:
+            lines.append(f"padd {f3(p)} {f3(q)}")
+            want.append(f3(ed.pt_add(p, q)))
+        lines.append(f"pdbl {f3(p)}")
+        want.append(f3(ed.pt_dbl(p)))
+        lines.append(f"prepr {f3(p)}")
+        want.append(ed.pt_repr(p) + "|" + str(len(ed.pt_repr(p))))
+        for n in [0, 1, 2, 3, 2**32 - 1, 2**32, 2**33 + 1, ELL - 1, ELL, 2**253 - 1,
+                  rng.randrange(ELL), rng.randrange(ELL) ** 2 % 2**256, rng.getrandbits(64)]:
+            lines.append(f"prepeat {f3(p)} {hx(n)}")
+            want.append(f3(ed.pt_repeat(p, n)))
+    assert harness(lines) == want
+
+
+def test_extended_formulas(harness):
+    rng = random.Random(5)
+    lines, want = [], []
+    f2 = lambda t: " ".join(hx(c) for c in ed.pt_affine(t))
+    pts = [rand_point(rng) for _ in range(8)]
+    for p in pts:
+        lines.append(f"edbl {f2(p)}")
+        want.append(f2(ed.pt_repeat(p, 4)) + " 1")
+        for q in pts[:4] + [p, ed.pt_repeat(p, 3), ed.pt_neg(ed.pt_repeat(p, 3)), ed.IDENTITY]:
+            p3 = ed.pt_repeat(p, 3)
+            lines.append(f"eadd {f2(p)} {f2(q)}")
+            want.append(f2(ed.pt_add(p3, q)) + " 1")
+            lines.append(f"emadd {f2(p)} {f2(q)}")
+            want.append(f2(ed.pt_add(p3, q)) + " 1")
+            lines.append(f"emaddneg {f2(p)} {f2(q)}")
+            want.append(f2(ed.pt_add(p3, ed.pt_neg(q))) + " 1")
+    assert harness(lines) == want

@@ -1,0 +1,374 @@
+"""ctypes binding of libvmpc_hip.so (include/vmpc.h).
+
+There is deliberately NO CPU fallback: if the HIP library is missing or no GPU is
+visible, every entry point raises.  The Python modules above this file (pivot.py,
+compressed_pivot.py, ...) mirror the reference's call signatures and send all O(N)
+group / vector work through here.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvmpc_hip.so")
+
+OK = 0
+E_INVAL, E_NONCANON, E_NOTONCURVE, E_NOMEM, E_HIP, E_NODEV = -22, -34, -33, -12, -5, -19
+_ERR_NAMES = {E_INVAL: "VMPC_E_INVAL", E_NONCANON: "VMPC_E_NONCANON",
+              E_NOTONCURVE: "VMPC_E_NOTONCURVE", E_NOMEM: "VMPC_E_NOMEM", E_HIP: "VMPC_E_HIP",
+              E_NODEV: "VMPC_E_NODEV"}
+
+SCALAR_BYTES, AFFINE_BYTES, PROJ_BYTES, EXT_BYTES = 32, 64, 96, 128
+
+# every symbol include/vmpc.h declares (tests/test_cabi_symbols.py checks the list
+# against the header and against the built library)
+SYMBOLS = [
+    "vmpc_backend_info", "vmpc_last_error", "vmpc_ctx_create", "vmpc_ctx_destroy",
+    "vmpc_ctx_set_stream", "vmpc_ctx_sync", "vmpc_malloc", "vmpc_free", "vmpc_memcpy_h2d",
+    "vmpc_memcpy_d2h", "vmpc_memcpy_d2d", "vmpc_ctx_profile", "vmpc_ctx_profile_read",
+    "vmpc_ctx_set_window", "vmpc_ed25519_msm", "vmpc_ed25519_fold",
+    "vmpc_ed25519_fixed_base_batch", "vmpc_fr_axpy", "vmpc_fr_dot", "vmpc_points_validate_dev",
+    "vmpc_msm_dev", "vmpc_points_sum_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
+    "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
+    "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
+]
+
+
+class VmpcError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: {_ERR_NAMES.get(code, code)} {detail}".strip())
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m verifiable_mpc_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback for the AC20 hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, i32, u64p = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)
+    cp = ctypes.c_char_p
+    sig = {
+        "vmpc_backend_info": (i32, [cp, sz]),
+        "vmpc_last_error": (cp, []),
+        "vmpc_ctx_create": (i32, [i32, ctypes.POINTER(vp)]),
+        "vmpc_ctx_destroy": (i32, [vp]),
+        "vmpc_ctx_set_stream": (i32, [vp, vp]),
+        "vmpc_ctx_sync": (i32, [vp]),
+        "vmpc_malloc": (i32, [vp, sz, ctypes.POINTER(vp)]),
+        "vmpc_free": (i32, [vp, vp]),
+        "vmpc_memcpy_h2d": (i32, [vp, vp, vp, sz]),
+        "vmpc_memcpy_d2h": (i32, [vp, vp, vp, sz]),
+        "vmpc_memcpy_d2d": (i32, [vp, vp, vp, sz]),
+        "vmpc_ctx_profile": (i32, [vp, i32]),
+        "vmpc_ctx_profile_read": (i32, [vp, cp, sz, ctypes.POINTER(ctypes.c_double), u64p, i32, i32]),
+        "vmpc_ctx_set_window": (i32, [vp, i32]),
+        "vmpc_ed25519_msm": (i32, [vp, vp, sz, vp]),
+        "vmpc_ed25519_fold": (i32, [vp, vp, vp, sz, vp]),
+        "vmpc_ed25519_fixed_base_batch": (i32, [vp, vp, sz, vp]),
+        "vmpc_fr_axpy": (i32, [vp, vp, vp, sz, vp]),
+        "vmpc_fr_dot": (i32, [vp, vp, sz, vp]),
+        "vmpc_points_validate_dev": (i32, [vp, vp, sz, u64p]),
+        "vmpc_msm_dev": (i32, [vp, vp, vp, sz, vp, vp, sz, vp, vp]),
+        "vmpc_points_sum_dev": (i32, [vp, vp, sz, vp, vp]),
+        "vmpc_repeat_dev": (i32, [vp, vp, sz, i32, vp, sz, i32, vp, vp]),
+        "vmpc_fold_dev": (i32, [vp, vp, vp, i32, vp, sz, vp, vp]),
+        "vmpc_tree_reduce_dev": (i32, [vp, vp, sz, i32, vp]),
+        "vmpc_normalize_dev": (i32, [vp, vp, sz, vp]),
+        "vmpc_affine_to_proj_dev": (i32, [vp, vp, sz, vp]),
+        "vmpc_fr_axpy_dev": (i32, [vp, vp, vp, vp, sz, vp]),
+        "vmpc_fr_scale_dev": (i32, [vp, vp, vp, sz, vp]),
+        "vmpc_fr_dot_dev": (i32, [vp, vp, vp, sz, vp]),
+        "vmpc_format_points_dev": (i32, [vp, vp, sz, vp, sz, u64p]),
+        "vmpc_format_scalars_dev": (i32, [vp, vp, sz, i32, vp, sz, u64p]),
+    }
+    for name in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype, fn.argtypes = sig[name]
+    _lib = lib
+    return lib
+
+
+def _check(rc, where):
+    if rc != OK:
+        detail = load_library().vmpc_last_error().decode(errors="replace") if rc == E_HIP or rc == E_NONCANON or rc == E_NOMEM or rc == E_NODEV else ""
+        raise VmpcError(rc, where, detail)
+
+
+def backend_info():
+    lib = load_library()
+    buf = ctypes.create_string_buffer(256)
+    n = lib.vmpc_backend_info(buf, 256)
+    return n, buf.value.decode()
+
+
+def _np_ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def as_bytes_array(a, width):
+    """C-contiguous uint8 array of shape (n, width)."""
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim == 1:
+        a = a.reshape(-1, width)
+    assert a.ndim == 2 and a.shape[1] == width, (a.shape, width)
+    return a
+
+
+def scalar_to_bytes(v):
+    return int(v).to_bytes(32, "little")
+
+
+def ints_to_array(vals, width=32):
+    """list of non-negative ints -> (n, width) uint8 little-endian."""
+    return np.frombuffer(b"".join(int(v).to_bytes(width, "little") for v in vals),
+                         dtype=np.uint8).reshape(-1, width).copy() if len(vals) else \
+        np.zeros((0, width), dtype=np.uint8)
+
+
+def array_to_ints(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    w = a.shape[-1]
+    raw = a.tobytes()
+    return [int.from_bytes(raw[i:i + w], "little") for i in range(0, len(raw), w)]
+
+
+class DeviceBuffer:
+    """Owned device allocation (vmpc_malloc) - freed with the object."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        _check(ctx.lib.vmpc_malloc(ctx.handle, self.nbytes, ctypes.byref(p)), "vmpc_malloc")
+        self.ptr = p.value
+
+    def at(self, byte_offset):
+        return ctypes.c_void_p(self.ptr + int(byte_offset))
+
+    def free(self):
+        if self.ptr and self.ctx.handle:
+            self.ctx.lib.vmpc_free(self.ctx.handle, ctypes.c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU, one stream (vmpc_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self.lib.vmpc_ctx_create(device, ctypes.byref(h)), "vmpc_ctx_create")
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            self.lib.vmpc_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- memory -------------------------------------------------------------------------
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = DeviceBuffer(self, max(arr.nbytes, 1))
+        if arr.nbytes:
+            _check(self.lib.vmpc_memcpy_h2d(self.handle, ctypes.c_void_p(buf.ptr), _np_ptr(arr),
+                                            arr.nbytes), "vmpc_memcpy_h2d")
+        return buf
+
+    def upload_into(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes:
+            _check(self.lib.vmpc_memcpy_h2d(self.handle, ctypes.c_void_p(ptr), _np_ptr(arr),
+                                            arr.nbytes), "vmpc_memcpy_h2d")
+
+    def download(self, ptr, nbytes, shape=None):
+        out = np.empty(int(nbytes), dtype=np.uint8)
+        if nbytes:
+            _check(self.lib.vmpc_memcpy_d2h(self.handle, _np_ptr(out), ctypes.c_void_p(ptr),
+                                            int(nbytes)), "vmpc_memcpy_d2h")
+        return out.reshape(shape) if shape is not None else out
+
+    def copy(self, dst_ptr, src_ptr, nbytes):
+        _check(self.lib.vmpc_memcpy_d2d(self.handle, ctypes.c_void_p(dst_ptr),
+                                        ctypes.c_void_p(src_ptr), int(nbytes)), "vmpc_memcpy_d2d")
+
+    def sync(self):
+        _check(self.lib.vmpc_ctx_sync(self.handle), "vmpc_ctx_sync")
+
+    def set_stream(self, stream_ptr):
+        _check(self.lib.vmpc_ctx_set_stream(self.handle, ctypes.c_void_p(stream_ptr)),
+               "vmpc_ctx_set_stream")
+
+    def set_window(self, c_bits):
+        _check(self.lib.vmpc_ctx_set_window(self.handle, int(c_bits)), "vmpc_ctx_set_window")
+
+    def profile(self, enable=True):
+        _check(self.lib.vmpc_ctx_profile(self.handle, 1 if enable else 0), "vmpc_ctx_profile")
+
+    def profile_read(self, reset=True):
+        names = ctypes.create_string_buffer(2048)
+        ms = (ctypes.c_double * 64)()
+        cnt = (ctypes.c_uint64 * 64)()
+        k = self.lib.vmpc_ctx_profile_read(self.handle, names, 2048, ms, cnt, 64, 1 if reset else 0)
+        if k < 0:
+            _check(k, "vmpc_ctx_profile_read")
+        nm = names.value.decode().split(";") if k else []
+        return {nm[i]: (ms[i], int(cnt[i])) for i in range(k)}
+
+    # ---- device entry points (pointers are ints / c_void_p) --------------------------------
+    def validate_points(self, affine_ptr, n):
+        bad = ctypes.c_uint64()
+        _check(self.lib.vmpc_points_validate_dev(self.handle, ctypes.c_void_p(affine_ptr), n,
+                                                 ctypes.byref(bad)), "vmpc_points_validate_dev")
+        return bad.value
+
+    def msm(self, scalars_ptr, points_ptr, n, extra_scalars_ptr=None, extra_points_ptr=None,
+            n_extra=0, out_ext_ptr=None, out_affine_ptr=None):
+        _check(self.lib.vmpc_msm_dev(self.handle, ctypes.c_void_p(scalars_ptr),
+                                     ctypes.c_void_p(points_ptr), n,
+                                     ctypes.c_void_p(extra_scalars_ptr),
+                                     ctypes.c_void_p(extra_points_ptr), n_extra,
+                                     ctypes.c_void_p(out_ext_ptr), ctypes.c_void_p(out_affine_ptr)),
+               "vmpc_msm_dev")
+
+    def points_sum(self, ext_ptr, m, out_ext_ptr=None, out_affine_ptr=None):
+        _check(self.lib.vmpc_points_sum_dev(self.handle, ctypes.c_void_p(ext_ptr), m,
+                                            ctypes.c_void_p(out_ext_ptr),
+                                            ctypes.c_void_p(out_affine_ptr)), "vmpc_points_sum_dev")
+
+    def repeat(self, bases_ptr, n_bases, bases_affine, scalars_ptr, n, signed_scalars,
+               out_proj_ptr=None, out_affine_ptr=None):
+        _check(self.lib.vmpc_repeat_dev(self.handle, ctypes.c_void_p(bases_ptr), n_bases,
+                                        1 if bases_affine else 0, ctypes.c_void_p(scalars_ptr), n,
+                                        1 if signed_scalars else 0, ctypes.c_void_p(out_proj_ptr),
+                                        ctypes.c_void_p(out_affine_ptr)), "vmpc_repeat_dev")
+
+    def fold(self, gl_ptr, gr_ptr, in_affine, c, half, out_proj_ptr=None, out_affine_ptr=None):
+        cb = ctypes.create_string_buffer(scalar_to_bytes(c), 32)
+        _check(self.lib.vmpc_fold_dev(self.handle, ctypes.c_void_p(gl_ptr), ctypes.c_void_p(gr_ptr),
+                                      1 if in_affine else 0, cb, half, ctypes.c_void_p(out_proj_ptr),
+                                      ctypes.c_void_p(out_affine_ptr)), "vmpc_fold_dev")
+
+    def tree_reduce(self, proj_ptr, n, append_identity, out_proj_ptr):
+        _check(self.lib.vmpc_tree_reduce_dev(self.handle, ctypes.c_void_p(proj_ptr), n,
+                                             1 if append_identity else 0,
+                                             ctypes.c_void_p(out_proj_ptr)), "vmpc_tree_reduce_dev")
+
+    def normalize(self, proj_ptr, n, out_affine_ptr):
+        _check(self.lib.vmpc_normalize_dev(self.handle, ctypes.c_void_p(proj_ptr), n,
+                                           ctypes.c_void_p(out_affine_ptr)), "vmpc_normalize_dev")
+
+    def affine_to_proj(self, affine_ptr, n, out_proj_ptr):
+        _check(self.lib.vmpc_affine_to_proj_dev(self.handle, ctypes.c_void_p(affine_ptr), n,
+                                                ctypes.c_void_p(out_proj_ptr)),
+               "vmpc_affine_to_proj_dev")
+
+    def fr_axpy(self, c, x_ptr, y_ptr, n, out_ptr):
+        cb = ctypes.create_string_buffer(scalar_to_bytes(c), 32)
+        _check(self.lib.vmpc_fr_axpy_dev(self.handle, cb, ctypes.c_void_p(x_ptr),
+                                         ctypes.c_void_p(y_ptr), n, ctypes.c_void_p(out_ptr)),
+               "vmpc_fr_axpy_dev")
+
+    def fr_scale(self, c, x_ptr, n, out_ptr):
+        cb = ctypes.create_string_buffer(scalar_to_bytes(c), 32)
+        _check(self.lib.vmpc_fr_scale_dev(self.handle, cb, ctypes.c_void_p(x_ptr), n,
+                                          ctypes.c_void_p(out_ptr)), "vmpc_fr_scale_dev")
+
+    def fr_dot(self, a_ptr, b_ptr, n):
+        out = ctypes.create_string_buffer(32)
+        _check(self.lib.vmpc_fr_dot_dev(self.handle, ctypes.c_void_p(a_ptr), ctypes.c_void_p(b_ptr),
+                                        n, out), "vmpc_fr_dot_dev")
+        return int.from_bytes(out.raw, "little")
+
+    def _format(self, fn, name, src_ptr, n, per_item_cap, *extra):
+        cap = n * per_item_cap + 16
+        buf = DeviceBuffer(self, cap)
+        ln = ctypes.c_uint64()
+        _check(fn(self.handle, ctypes.c_void_p(src_ptr), n, *extra, ctypes.c_void_p(buf.ptr), cap,
+                  ctypes.byref(ln)), name)
+        out = self.download(buf.ptr, ln.value)
+        buf.free()
+        return out
+
+    def format_points(self, proj_ptr, n):
+        """uint8 array 'item0, item1, ..., ' for n projective points."""
+        return self._format(self.lib.vmpc_format_points_dev, "vmpc_format_points_dev", proj_ptr, n,
+                            3 * 78 + 8)
+
+    def format_scalars(self, sc_ptr, n, is_signed=True):
+        return self._format(self.lib.vmpc_format_scalars_dev, "vmpc_format_scalars_dev", sc_ptr, n,
+                            78 + 3, 1 if is_signed else 0)
+
+
+# ---- host-buffer one-shots ------------------------------------------------------------------
+def ed25519_msm(scalars, points):
+    lib = load_library()
+    s = as_bytes_array(scalars, 32)
+    p = as_bytes_array(points, 64)
+    assert len(s) == len(p)
+    out = np.zeros(64, dtype=np.uint8)
+    _check(lib.vmpc_ed25519_msm(_np_ptr(s), _np_ptr(p), len(s), _np_ptr(out)), "vmpc_ed25519_msm")
+    return out
+
+
+def ed25519_fold(pts_l, pts_r, c):
+    lib = load_library()
+    l = as_bytes_array(pts_l, 64)
+    r = as_bytes_array(pts_r, 64)
+    assert len(l) == len(r)
+    out = np.zeros((len(l), 64), dtype=np.uint8)
+    cb = ctypes.create_string_buffer(scalar_to_bytes(c), 32)
+    _check(lib.vmpc_ed25519_fold(_np_ptr(l), _np_ptr(r), cb, len(l), _np_ptr(out)),
+           "vmpc_ed25519_fold")
+    return out
+
+
+def ed25519_fixed_base_batch(base, scalars):
+    lib = load_library()
+    b = as_bytes_array(base, 64)
+    s = as_bytes_array(scalars, 32)
+    out = np.zeros((len(s), 64), dtype=np.uint8)
+    _check(lib.vmpc_ed25519_fixed_base_batch(_np_ptr(b), _np_ptr(s), len(s), _np_ptr(out)),
+           "vmpc_ed25519_fixed_base_batch")
+    return out
+
+
+def fr_axpy(c, x, y):
+    lib = load_library()
+    xa, ya = as_bytes_array(x, 32), as_bytes_array(y, 32)
+    out = np.zeros_like(xa)
+    cb = ctypes.create_string_buffer(scalar_to_bytes(c), 32)
+    _check(lib.vmpc_fr_axpy(cb, _np_ptr(xa), _np_ptr(ya), len(xa), _np_ptr(out)), "vmpc_fr_axpy")
+    return out
+
+
+def fr_dot(a, b):
+    lib = load_library()
+    aa, ba = as_bytes_array(a, 32), as_bytes_array(b, 32)
+    out = ctypes.create_string_buffer(32)
+    _check(lib.vmpc_fr_dot(_np_ptr(aa), _np_ptr(ba), len(aa), out), "vmpc_fr_dot")
+    return int.from_bytes(out.raw, "little")

@@ -1,0 +1,356 @@
+// C-ABI runtime of libvmpc_hip: contexts, memory helpers, profiling, and the host-buffer
+// one-shot entry points of include/vmpc.h.
+#include <stdlib.h>
+
+#include "common.cuh"
+
+thread_local char vmpc_err_buf[512] = {0};
+
+int vmpc_fr_check_dev(vmpc_ctx *ctx, const void *v, size_t n);  // frvec.hip
+
+extern "C" const char *vmpc_last_error(void) { return vmpc_err_buf; }
+
+extern "C" int vmpc_backend_info(char *buf, size_t buflen) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        if (buf && buflen) snprintf(buf, buflen, "no HIP device (%s)", hipGetErrorString(e));
+        return VMPC_E_NODEV;
+    }
+    if (buf && buflen) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, 0) == hipSuccess)
+            snprintf(buf, buflen, "%s %s cus=%d lds=%zu hbm=%.0fGiB devices=%d", p.gcnArchName, p.name,
+                     p.multiProcessorCount, (size_t)p.sharedMemPerBlock,
+                     (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), n);
+        else
+            snprintf(buf, buflen, "devices=%d", n);
+    }
+    return n;
+}
+
+extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
+    if (!out) return VMPC_E_INVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "no HIP device visible");
+        return VMPC_E_NODEV;
+    }
+    if (device < 0 || device >= n) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(device));
+    vmpc_ctx *c = new vmpc_ctx();
+    c->device = device;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess) c->cu_count = p.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "hipStreamCreate: %s", hipGetErrorString(e));
+        return VMPC_E_HIP;
+    }
+    c->own_stream = true;
+    e = hipMalloc((void **)&c->d_status, VMPC_ST_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_status, 0, VMPC_ST_WORDS * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        hipStreamDestroy(c->stream);
+        delete c;
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "hipMalloc(status): %s", hipGetErrorString(e));
+        return VMPC_E_HIP;
+    }
+    const char *w = getenv("VMPC_MSM_WINDOW");
+    if (w) c->window_override = atoi(w);
+    *out = c;
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_ctx_destroy(vmpc_ctx *ctx) {
+    if (!ctx) return VMPC_E_INVAL;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->stages)
+        for (auto &pr : s.pending) {
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->d_status) hipFree(ctx->d_status);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_ctx_set_stream(vmpc_ctx *ctx, void *hip_stream) {
+    if (!ctx) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) {
+        hipStreamDestroy(ctx->stream);
+        ctx->own_stream = false;
+    }
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        VMPC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_ctx_sync(vmpc_ctx *ctx) {
+    if (!ctx) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    uint32_t st[VMPC_ST_WORDS];
+    VMPC_HIP_CHECK(hipMemcpyAsync(st, ctx->d_status, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (st[VMPC_ST_NONCANON]) {
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "%u non-canonical scalar(s) (>= l) seen on device",
+                 st[VMPC_ST_NONCANON]);
+        VMPC_HIP_CHECK(hipMemsetAsync(ctx->d_status, 0, sizeof st, ctx->stream));
+        VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return VMPC_E_NONCANON;
+    }
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_ctx_set_window(vmpc_ctx *ctx, int c_bits) {
+    if (!ctx || (c_bits != 0 && (c_bits < 4 || c_bits > 16))) return VMPC_E_INVAL;
+    ctx->window_override = c_bits;
+    return VMPC_OK;
+}
+
+int vmpc_ws_reserve(vmpc_ctx *ctx, size_t total_bytes) {
+    ctx->ws_used = 0;
+    if (total_bytes <= ctx->ws_bytes) return VMPC_OK;
+    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) {
+        VMPC_HIP_CHECK(hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    size_t want = total_bytes + total_bytes / 8 + (1 << 20);
+    hipError_t e = hipMalloc(&ctx->ws, want);
+    if (e != hipSuccess) {
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "workspace hipMalloc(%zu): %s", want,
+                 hipGetErrorString(e));
+        return VMPC_E_NOMEM;
+    }
+    ctx->ws_bytes = want;
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_malloc(vmpc_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        return VMPC_E_NOMEM;
+    }
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_free(vmpc_ctx *ctx, void *dptr) {
+    if (!ctx) return VMPC_E_INVAL;
+    if (!dptr) return VMPC_OK;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    VMPC_HIP_CHECK(hipFree(dptr));
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_memcpy_h2d(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return VMPC_E_INVAL;
+    if (!bytes) return VMPC_OK;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    VMPC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_memcpy_d2h(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return VMPC_E_INVAL;
+    if (!bytes) return VMPC_OK;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    VMPC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_memcpy_d2d(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return VMPC_E_INVAL;
+    if (!bytes) return VMPC_OK;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    VMPC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return VMPC_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------
+extern "C" int vmpc_ctx_profile(vmpc_ctx *ctx, int enable) {
+    if (!ctx) return VMPC_E_INVAL;
+    ctx->profile = enable != 0;
+    return VMPC_OK;
+}
+
+static hipEvent_t take_event(vmpc_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+int vmpc_stage_begin(vmpc_ctx *ctx, const char *name) {
+    if (!ctx->profile) return -1;
+    int idx = -1;
+    for (size_t i = 0; i < ctx->stages.size(); i++)
+        if (strcmp(ctx->stages[i].name, name) == 0) idx = (int)i;
+    if (idx < 0) {
+        vmpc_stage s;
+        s.name = name;
+        ctx->stages.push_back(s);
+        idx = (int)ctx->stages.size() - 1;
+    }
+    hipEvent_t a = take_event(ctx), b = take_event(ctx);
+    hipEventRecord(a, ctx->stream);
+    ctx->stages[idx].pending.push_back({a, b});
+    return idx;
+}
+
+void vmpc_stage_end(vmpc_ctx *ctx, int handle) {
+    if (handle < 0) return;
+    hipEventRecord(ctx->stages[handle].pending.back().second, ctx->stream);
+}
+
+extern "C" int vmpc_ctx_profile_read(vmpc_ctx *ctx, char *names, size_t names_len, double *ms,
+                                     uint64_t *launches, int max_stages, int reset) {
+    if (!ctx) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::string all;
+    int k = 0;
+    for (auto &s : ctx->stages) {
+        for (auto &pr : s.pending) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) {
+                s.ms += t;
+                s.launches++;
+            }
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        s.pending.clear();
+        if (k < max_stages) {
+            if (ms) ms[k] = s.ms;
+            if (launches) launches[k] = s.launches;
+            if (k) all += ";";
+            all += s.name;
+            k++;
+        }
+        if (reset) {
+            s.ms = 0;
+            s.launches = 0;
+        }
+    }
+    if (names && names_len) snprintf(names, names_len, "%s", all.c_str());
+    return k;
+}
+
+// ---- host-buffer one-shots ------------------------------------------------------------------------
+namespace {
+struct host_call {
+    vmpc_ctx *ctx = nullptr;
+    std::vector<void *> bufs;
+    int rc = VMPC_OK;
+    host_call() { rc = vmpc_ctx_create(0, &ctx); }
+    ~host_call() {
+        if (ctx) {
+            for (void *b : bufs) vmpc_free(ctx, b);
+            vmpc_ctx_destroy(ctx);
+        }
+    }
+    void *up(const void *src, size_t bytes) {
+        if (rc) return nullptr;
+        void *d = nullptr;
+        rc = vmpc_malloc(ctx, bytes, &d);
+        if (rc) return nullptr;
+        bufs.push_back(d);
+        if (src) rc = vmpc_memcpy_h2d(ctx, d, src, bytes);
+        return d;
+    }
+};
+}  // namespace
+
+extern "C" int vmpc_ed25519_msm(const uint8_t *scalars, const uint8_t *points, size_t n,
+                                uint8_t out[64]) {
+    if (!out || (n && (!scalars || !points))) return VMPC_E_INVAL;
+    host_call h;
+    void *ds = h.up(scalars, n * 32), *dp = h.up(points, n * 64), *dout = h.up(nullptr, 64);
+    if (h.rc) return h.rc;
+    uint64_t bad = 0;
+    VMPC_CHECK(vmpc_points_validate_dev(h.ctx, dp, n, &bad));
+    if (bad) return VMPC_E_NOTONCURVE;
+    VMPC_CHECK(vmpc_msm_dev(h.ctx, ds, dp, n, nullptr, nullptr, 0, nullptr, dout));
+    VMPC_CHECK(vmpc_ctx_sync(h.ctx));
+    return vmpc_memcpy_d2h(h.ctx, out, dout, 64);
+}
+
+extern "C" int vmpc_ed25519_fold(const uint8_t *pts_l, const uint8_t *pts_r, const uint8_t c[32],
+                                 size_t half, uint8_t *out) {
+    if (!c || (half && (!pts_l || !pts_r || !out))) return VMPC_E_INVAL;
+    if (!half) return VMPC_OK;
+    host_call h;
+    void *dl = h.up(pts_l, half * 64), *dr = h.up(pts_r, half * 64), *dout = h.up(nullptr, half * 64);
+    if (h.rc) return h.rc;
+    uint64_t bad = 0, bad2 = 0;
+    VMPC_CHECK(vmpc_points_validate_dev(h.ctx, dl, half, &bad));
+    VMPC_CHECK(vmpc_points_validate_dev(h.ctx, dr, half, &bad2));
+    if (bad || bad2) return VMPC_E_NOTONCURVE;
+    VMPC_CHECK(vmpc_fold_dev(h.ctx, dl, dr, 1, c, half, nullptr, dout));
+    VMPC_CHECK(vmpc_ctx_sync(h.ctx));
+    return vmpc_memcpy_d2h(h.ctx, out, dout, half * 64);
+}
+
+extern "C" int vmpc_ed25519_fixed_base_batch(const uint8_t base[64], const uint8_t *scalars, size_t n,
+                                             uint8_t *out) {
+    if (!base || (n && (!scalars || !out))) return VMPC_E_INVAL;
+    if (!n) return VMPC_OK;
+    host_call h;
+    void *db = h.up(base, 64), *ds = h.up(scalars, n * 32), *dout = h.up(nullptr, n * 64);
+    if (h.rc) return h.rc;
+    uint64_t bad = 0;
+    VMPC_CHECK(vmpc_points_validate_dev(h.ctx, db, 1, &bad));
+    if (bad) return VMPC_E_NOTONCURVE;
+    VMPC_CHECK(vmpc_fr_check_dev(h.ctx, ds, n));
+    VMPC_CHECK(vmpc_repeat_dev(h.ctx, db, 1, 1, ds, n, 0, nullptr, dout));
+    VMPC_CHECK(vmpc_ctx_sync(h.ctx));
+    return vmpc_memcpy_d2h(h.ctx, out, dout, n * 64);
+}
+
+extern "C" int vmpc_fr_axpy(const uint8_t c[32], const uint8_t *x, const uint8_t *y, size_t n,
+                            uint8_t *out) {
+    if (!c || (n && (!x || !y || !out))) return VMPC_E_INVAL;
+    if (!n) return VMPC_OK;
+    host_call h;
+    void *dx = h.up(x, n * 32), *dy = h.up(y, n * 32), *dout = h.up(nullptr, n * 32);
+    if (h.rc) return h.rc;
+    VMPC_CHECK(vmpc_fr_check_dev(h.ctx, dx, n));
+    VMPC_CHECK(vmpc_fr_check_dev(h.ctx, dy, n));
+    VMPC_CHECK(vmpc_fr_axpy_dev(h.ctx, c, dx, dy, n, dout));
+    VMPC_CHECK(vmpc_ctx_sync(h.ctx));
+    return vmpc_memcpy_d2h(h.ctx, out, dout, n * 32);
+}
+
+extern "C" int vmpc_fr_dot(const uint8_t *a, const uint8_t *b, size_t n, uint8_t out[32]) {
+    if (!out || (n && (!a || !b))) return VMPC_E_INVAL;
+    host_call h;
+    void *da = h.up(a, n * 32), *db = h.up(b, n * 32);
+    if (h.rc) return h.rc;
+    VMPC_CHECK(vmpc_fr_check_dev(h.ctx, da, n));
+    VMPC_CHECK(vmpc_fr_check_dev(h.ctx, db, n));
+    VMPC_CHECK(vmpc_fr_dot_dev(h.ctx, da, db, n, out));
+    return vmpc_ctx_sync(h.ctx);
+}

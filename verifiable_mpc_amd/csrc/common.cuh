@@ -1,0 +1,81 @@
+// Shared host-side plumbing of libvmpc_hip: context, workspace arena, error handling,
+// per-stage HIP-event profiling.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/vmpc.h"
+
+extern thread_local char vmpc_err_buf[512];
+
+#define VMPC_HIP_CHECK(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "%s:%d: %s -> %s", __FILE__, __LINE__, \
+                     #expr, hipGetErrorString(_e));                                           \
+            return VMPC_E_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+#define VMPC_CHECK(expr)              \
+    do {                              \
+        int _r = (expr);              \
+        if (_r != VMPC_OK) return _r; \
+    } while (0)
+
+// device-side status word layout (ctx->d_status, 4 x u32)
+#define VMPC_ST_NONCANON 0  // count of non-canonical scalars seen by recode kernels
+#define VMPC_ST_WORDS 4
+
+struct vmpc_stage {
+    const char *name;
+    double ms = 0;
+    uint64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct vmpc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // growable scratch arena (never shrinks; reused by every call on this context)
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    size_t ws_used = 0;
+    uint32_t *d_status = nullptr;
+    int window_override = 0;
+    int cu_count = 256;
+    // profiling
+    bool profile = false;
+    std::vector<vmpc_stage> stages;
+    std::vector<hipEvent_t> event_pool;
+};
+
+// Reserve `bytes` from the context arena (256-byte aligned).  The arena is reset at the
+// start of each public call; if it is too small the call grows it (stream-synchronising).
+int vmpc_ws_reserve(vmpc_ctx *ctx, size_t total_bytes);
+inline void *vmpc_ws_take(vmpc_ctx *ctx, size_t bytes) {
+    size_t off = (ctx->ws_used + 255) & ~(size_t)255;
+    ctx->ws_used = off + bytes;
+    return (char *)ctx->ws + off;
+}
+inline size_t vmpc_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// profiling helpers: bracket a kernel launch with events when ctx->profile is on
+int vmpc_stage_begin(vmpc_ctx *ctx, const char *name);
+void vmpc_stage_end(vmpc_ctx *ctx, int handle);
+
+struct vmpc_stage_scope {
+    vmpc_ctx *ctx;
+    int h;
+    vmpc_stage_scope(vmpc_ctx *c, const char *name) : ctx(c), h(vmpc_stage_begin(c, name)) {}
+    ~vmpc_stage_scope() { vmpc_stage_end(ctx, h); }
+};
+
+#define VMPC_KERNEL_CHECK() VMPC_HIP_CHECK(hipGetLastError())

@@ -1,0 +1,231 @@
+// Element-wise kernels that REPLAY the reference's group-operation sequences
+// (projective add-2008-bbjlp / dbl-2008-bbjlp, right-to-left `repeat`) so that the
+// un-normalised coordinates entering the reference's Fiat-Shamir pre-image are
+// reproduced bit for bit (see ge25519.cuh):
+//   vmpc_fold_dev         g'_i = (g_l[i] ** c) * g_r[i]     compressed_pivot.py:64 / :178
+//   vmpc_repeat_dev       base ** r_i, g[i] ** x_i          circuit_sat_r1cs.py:64-70,81; pivot.py:143
+//   vmpc_tree_reduce_dev  pivot.list_mul                    pivot.py:26-28
+//   vmpc_normalize_dev    .normalize() over a vector        compressed_pivot.py:52,118
+// One lane per element; 96-B / 64-B elements are moved with 16-B accesses.  The fold has a
+// wave-uniform scalar (no divergence); repeat predicates per lane.
+#include "common.cuh"
+#include "fe25519.cuh"
+#include "fr.cuh"
+#include "ge25519.cuh"
+
+#define EX_BLOCK 256
+
+__device__ __forceinline__ fe ex_fe_ld(const uint32_t *src) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(src);
+    uint4 a = p[0], b = p[1];
+    fe r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void ex_fe_st(uint32_t *dst, const fe &a) {
+    uint4 *p = reinterpret_cast<uint4 *>(dst);
+    p[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    p[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+__device__ __forceinline__ ge_proj ex_load_point(const uint32_t *base, size_t i, bool affine) {
+    ge_proj p;
+    if (affine) {
+        p.X = ex_fe_ld(base + 16 * i);
+        p.Y = ex_fe_ld(base + 16 * i + 8);
+        p.Z = fe_one();
+    } else {
+        p.X = ex_fe_ld(base + 24 * i);
+        p.Y = ex_fe_ld(base + 24 * i + 8);
+        p.Z = ex_fe_ld(base + 24 * i + 16);
+    }
+    return p;
+}
+__device__ __forceinline__ void ex_store_point(const ge_proj &r, size_t i, uint32_t *out_proj,
+                                               uint32_t *out_aff) {
+    if (out_proj) {
+        ge_proj c = ge_proj_canon(r);
+        ex_fe_st(out_proj + 24 * i, c.X);
+        ex_fe_st(out_proj + 24 * i + 8, c.Y);
+        ex_fe_st(out_proj + 24 * i + 16, c.Z);
+    }
+    if (out_aff) {
+        ge_aff a = ge_proj_to_affine(r);
+        ex_fe_st(out_aff + 16 * i, a.x);
+        ex_fe_st(out_aff + 16 * i + 8, a.y);
+    }
+}
+
+struct u256_arg {
+    uint32_t v[8];
+};
+
+// ---- fold ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EX_BLOCK)
+k_fold(const uint32_t *__restrict__ gl, const uint32_t *__restrict__ gr, int in_affine, u256_arg c,
+       size_t half, uint32_t *__restrict__ out_proj, uint32_t *__restrict__ out_aff) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    ge_proj a = ex_load_point(gl, i, in_affine != 0);
+    ge_proj b = ex_load_point(gr, i, in_affine != 0);
+    ge_proj r = ge_proj_add(ge_proj_repeat(a, c.v), b);  // (g_l ** c) * g_r
+    ex_store_point(r, i, out_proj, out_aff);
+}
+
+// ---- repeat -------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EX_BLOCK)
+k_repeat(const uint32_t *__restrict__ bases, size_t n_bases, int bases_affine,
+         const uint32_t *__restrict__ scalars, size_t n, int signed_scalars,
+         uint32_t *__restrict__ out_proj, uint32_t *__restrict__ out_aff) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ge_proj a = ex_load_point(bases, n_bases == 1 ? 0 : i, bases_affine != 0);
+    fr s;
+    {
+        const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * i);
+        uint4 x = p[0], y = p[1];
+        s.v[0] = x.x; s.v[1] = x.y; s.v[2] = x.z; s.v[3] = x.w;
+        s.v[4] = y.x; s.v[5] = y.y; s.v[6] = y.z; s.v[7] = y.w;
+    }
+    if (signed_scalars) {
+        // pivot._int on a signed field element: residues above l/2 are negative ints, and
+        // `a ** n` with n < 0 inverts the base first (oracle pt_repeat)
+        fr mag;
+        bool neg = fr_signed_abs(s, mag);
+        if (neg) a = ge_proj_neg(a);
+        s = mag;
+    }
+    ge_proj r = ge_proj_repeat(a, s.v);
+    ex_store_point(r, i, out_proj, out_aff);
+}
+
+// ---- tree reduce (one level) ------------------------------------------------------------------
+// xs[odd:] = [f(xs[i], xs[i+1]) for i in range(odd, len, 2)] with odd = len % 2
+__global__ void __launch_bounds__(EX_BLOCK)
+k_tree_level(const uint32_t *__restrict__ in, size_t len, uint32_t *__restrict__ out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t odd = len & 1;
+    size_t out_len = odd + (len - odd) / 2;
+    if (t >= out_len) return;
+    ge_proj r;
+    if (odd && t == 0) {
+        r = ex_load_point(in, 0, false);
+        ex_fe_st(out, r.X);
+        ex_fe_st(out + 8, r.Y);
+        ex_fe_st(out + 16, r.Z);
+        return;
+    }
+    size_t i = odd + 2 * (t - odd);
+    r = ge_proj_add(ex_load_point(in, i, false), ex_load_point(in, i + 1, false));
+    r = ge_proj_canon(r);
+    ex_fe_st(out + 24 * t, r.X);
+    ex_fe_st(out + 24 * t + 8, r.Y);
+    ex_fe_st(out + 24 * t + 16, r.Z);
+}
+
+// ---- normalize / lift -------------------------------------------------------------------------
+__global__ void __launch_bounds__(EX_BLOCK)
+k_normalize(const uint32_t *__restrict__ proj, size_t n, uint32_t *__restrict__ out_aff) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ge_aff a = ge_proj_to_affine(ex_load_point(proj, i, false));
+    ex_fe_st(out_aff + 16 * i, a.x);
+    ex_fe_st(out_aff + 16 * i + 8, a.y);
+}
+
+__global__ void __launch_bounds__(EX_BLOCK)
+k_affine_to_proj(const uint32_t *__restrict__ aff, size_t n, uint32_t *__restrict__ out_proj) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ge_proj p = ex_load_point(aff, i, true);
+    ex_fe_st(out_proj + 24 * i, p.X);
+    ex_fe_st(out_proj + 24 * i + 8, p.Y);
+    ex_fe_st(out_proj + 24 * i + 16, p.Z);
+}
+
+static inline unsigned ex_grid(size_t n) { return (unsigned)((n + EX_BLOCK - 1) / EX_BLOCK); }
+
+extern "C" int vmpc_fold_dev(vmpc_ctx *ctx, const void *g_l, const void *g_r, int in_affine,
+                             const uint8_t c[32], size_t half, void *out_proj, void *out_affine) {
+    if (!ctx || !c || (half && (!g_l || !g_r)) || (!out_proj && !out_affine)) return VMPC_E_INVAL;
+    if (half == 0) return VMPC_OK;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    u256_arg ca;
+    memcpy(ca.v, c, 32);
+    if (fr_geq_l(ca.v)) return VMPC_E_NONCANON;
+    vmpc_stage_scope s(ctx, "fold");
+    k_fold<<<ex_grid(half), EX_BLOCK, 0, ctx->stream>>>((const uint32_t *)g_l, (const uint32_t *)g_r,
+                                                        in_affine, ca, half, (uint32_t *)out_proj,
+                                                        (uint32_t *)out_affine);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_repeat_dev(vmpc_ctx *ctx, const void *bases, size_t n_bases, int bases_affine,
+                               const void *scalars, size_t n, int signed_scalars, void *out_proj,
+                               void *out_affine) {
+    if (!ctx || (n && (!bases || !scalars)) || (!out_proj && !out_affine)) return VMPC_E_INVAL;
+    if (n_bases != 1 && n_bases != n) return VMPC_E_INVAL;
+    if (n == 0) return VMPC_OK;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    vmpc_stage_scope s(ctx, "repeat");
+    k_repeat<<<ex_grid(n), EX_BLOCK, 0, ctx->stream>>>((const uint32_t *)bases, n_bases, bases_affine,
+                                                       (const uint32_t *)scalars, n, signed_scalars,
+                                                       (uint32_t *)out_proj, (uint32_t *)out_affine);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_tree_reduce_dev(vmpc_ctx *ctx, void *proj_points, size_t n, int append_identity,
+                                    void *out_proj) {
+    if (!ctx || !out_proj || (n && !proj_points)) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    size_t len = n + (append_identity ? 1 : 0);
+    if (len == 0) return VMPC_E_INVAL;  // reduce() of empty sequence with no initial value
+    VMPC_CHECK(vmpc_ws_reserve(ctx, 2 * vmpc_align(len * 96)));
+    uint32_t *a = (uint32_t *)vmpc_ws_take(ctx, len * 96);
+    uint32_t *b = (uint32_t *)vmpc_ws_take(ctx, len * 96);
+    if (n) VMPC_HIP_CHECK(hipMemcpyAsync(a, proj_points, n * 96, hipMemcpyDeviceToDevice, st));
+    if (append_identity) {
+        uint32_t id[24] = {0};
+        id[8] = 1;
+        id[16] = 1;
+        VMPC_HIP_CHECK(hipMemcpyAsync(a + 24 * n, id, 96, hipMemcpyHostToDevice, st));
+        VMPC_HIP_CHECK(hipStreamSynchronize(st));  // `id` is a stack buffer
+    }
+    vmpc_stage_scope s(ctx, "tree_reduce");
+    while (len > 1) {
+        size_t odd = len & 1;
+        size_t out_len = odd + (len - odd) / 2;
+        k_tree_level<<<ex_grid(out_len), EX_BLOCK, 0, st>>>(a, len, b);
+        VMPC_KERNEL_CHECK();
+        uint32_t *t = a;
+        a = b;
+        b = t;
+        len = out_len;
+    }
+    VMPC_HIP_CHECK(hipMemcpyAsync(out_proj, a, 96, hipMemcpyDeviceToDevice, st));
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_normalize_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *out_affine) {
+    if (!ctx || (n && (!proj || !out_affine))) return VMPC_E_INVAL;
+    if (n == 0) return VMPC_OK;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    vmpc_stage_scope s(ctx, "normalize");
+    k_normalize<<<ex_grid(n), EX_BLOCK, 0, ctx->stream>>>((const uint32_t *)proj, n,
+                                                          (uint32_t *)out_affine);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_affine_to_proj_dev(vmpc_ctx *ctx, const void *affine, size_t n, void *out_proj) {
+    if (!ctx || (n && (!affine || !out_proj))) return VMPC_E_INVAL;
+    if (n == 0) return VMPC_OK;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    k_affine_to_proj<<<ex_grid(n), EX_BLOCK, 0, ctx->stream>>>((const uint32_t *)affine, n,
+                                                               (uint32_t *)out_proj);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}

@@ -1,0 +1,149 @@
+// Scalar-field (mod l) vector kernels of Protocol 4/5's scalar side:
+//   vmpc_fr_axpy_dev   out = c*x + y      z' = z_l + c*z_r, L' = c*L_l + L_r (compressed_pivot.py:70-76),
+//                                         z = c0*x + r (:134)
+//   vmpc_fr_scale_dev  out = c*x          L~ = (L||0)*c1 (:141)
+//   vmpc_fr_dot_dev    sum a_i*b_i        LinearForm evaluation (pivot.py:84-92), L~(0||z_l), L~(z_r||0)
+// HBM-bound streaming kernels: 32-B elements, two 16-B accesses per lane, grid capped at
+// 2048 workgroups with a grid-stride loop.
+#include "common.cuh"
+#include "fr.cuh"
+
+#define FR_BLOCK 256
+#define FR_MAX_GRID 2048
+
+struct fr_arg {
+    uint32_t v[8];
+};
+
+__device__ __forceinline__ fr frv_ld(const uint32_t *src) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(src);
+    uint4 a = p[0], b = p[1];
+    fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void frv_st(uint32_t *dst, const fr &a) {
+    uint4 *p = reinterpret_cast<uint4 *>(dst);
+    p[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    p[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+__global__ void __launch_bounds__(FR_BLOCK)
+k_fr_axpy(fr_arg c, const uint32_t *__restrict__ x, const uint32_t *__restrict__ y, size_t n,
+          uint32_t *__restrict__ out) {
+    fr cc;
+#pragma unroll
+    for (int i = 0; i < 8; i++) cc.v[i] = c.v[i];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        fr r = fr_mul(cc, frv_ld(x + 8 * i));
+        if (y) r = fr_add(r, frv_ld(y + 8 * i));
+        frv_st(out + 8 * i, r);
+    }
+}
+
+__global__ void __launch_bounds__(FR_BLOCK)
+k_fr_dot(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t n,
+         uint32_t *__restrict__ partials) {
+    __shared__ uint32_t lds[FR_BLOCK * 8];
+    fr acc = fr_zero();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        acc = fr_add(acc, fr_mul(frv_ld(a + 8 * i), frv_ld(b + 8 * i)));
+    frv_st(lds + 8 * threadIdx.x, acc);
+    __syncthreads();
+    for (int stride = FR_BLOCK / 2; stride >= 1; stride >>= 1) {
+        if ((int)threadIdx.x < stride)
+            frv_st(lds + 8 * threadIdx.x,
+                   fr_add(frv_ld(lds + 8 * threadIdx.x), frv_ld(lds + 8 * (threadIdx.x + stride))));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) frv_st(partials + 8 * blockIdx.x, frv_ld(lds));
+}
+
+__global__ void __launch_bounds__(FR_BLOCK)
+k_fr_sum(const uint32_t *__restrict__ v, size_t n, uint32_t *__restrict__ out) {
+    __shared__ uint32_t lds[FR_BLOCK * 8];
+    fr acc = fr_zero();
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) acc = fr_add(acc, frv_ld(v + 8 * i));
+    frv_st(lds + 8 * threadIdx.x, acc);
+    __syncthreads();
+    for (int stride = FR_BLOCK / 2; stride >= 1; stride >>= 1) {
+        if ((int)threadIdx.x < stride)
+            frv_st(lds + 8 * threadIdx.x,
+                   fr_add(frv_ld(lds + 8 * threadIdx.x), frv_ld(lds + 8 * (threadIdx.x + stride))));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) frv_st(out, frv_ld(lds));
+}
+
+__global__ void __launch_bounds__(FR_BLOCK)
+k_fr_check(const uint32_t *__restrict__ v, size_t n, uint32_t *__restrict__ status) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        fr a = frv_ld(v + 8 * i);
+        if (fr_geq_l(a.v)) atomicAdd(&status[VMPC_ST_NONCANON], 1u);
+    }
+}
+
+static inline unsigned fr_grid(size_t n) {
+    size_t g = (n + FR_BLOCK - 1) / FR_BLOCK;
+    return (unsigned)(g > FR_MAX_GRID ? FR_MAX_GRID : (g ? g : 1));
+}
+
+static int fr_arg_from(const uint8_t c[32], fr_arg &a) {
+    memcpy(a.v, c, 32);
+    return fr_geq_l(a.v) ? VMPC_E_NONCANON : VMPC_OK;
+}
+
+extern "C" int vmpc_fr_axpy_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *x, const void *y,
+                                size_t n, void *out) {
+    if (!ctx || !c || (n && (!x || !out))) return VMPC_E_INVAL;
+    if (n == 0) return VMPC_OK;
+    fr_arg ca;
+    VMPC_CHECK(fr_arg_from(c, ca));
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    vmpc_stage_scope s(ctx, "fr_axpy");
+    k_fr_axpy<<<fr_grid(n), FR_BLOCK, 0, ctx->stream>>>(ca, (const uint32_t *)x, (const uint32_t *)y, n,
+                                                        (uint32_t *)out);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_fr_scale_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *x, size_t n,
+                                 void *out) {
+    return vmpc_fr_axpy_dev(ctx, c, x, nullptr, n, out);
+}
+
+extern "C" int vmpc_fr_dot_dev(vmpc_ctx *ctx, const void *a, const void *b, size_t n,
+                               uint8_t out[32]) {
+    if (!ctx || !out || (n && (!a || !b))) return VMPC_E_INVAL;
+    if (n == 0) {
+        memset(out, 0, 32);
+        return VMPC_OK;
+    }
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    unsigned g = fr_grid(n);
+    VMPC_CHECK(vmpc_ws_reserve(ctx, vmpc_align((size_t)g * 32) + 256));
+    uint32_t *partials = (uint32_t *)vmpc_ws_take(ctx, (size_t)g * 32);
+    uint32_t *res = (uint32_t *)vmpc_ws_take(ctx, 32);
+    {
+        vmpc_stage_scope s(ctx, "fr_dot");
+        k_fr_dot<<<g, FR_BLOCK, 0, ctx->stream>>>((const uint32_t *)a, (const uint32_t *)b, n, partials);
+        VMPC_KERNEL_CHECK();
+        k_fr_sum<<<1, FR_BLOCK, 0, ctx->stream>>>(partials, g, res);
+        VMPC_KERNEL_CHECK();
+    }
+    VMPC_HIP_CHECK(hipMemcpyAsync(out, res, 32, hipMemcpyDeviceToHost, ctx->stream));
+    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VMPC_OK;
+}
+
+// canonical-residue check of a scalar vector (C-ABI boundary hygiene, SURVEY.md hard part 5)
+int vmpc_fr_check_dev(vmpc_ctx *ctx, const void *v, size_t n) {
+    if (n == 0) return VMPC_OK;
+    k_fr_check<<<fr_grid(n), FR_BLOCK, 0, ctx->stream>>>((const uint32_t *)v, n, ctx->d_status);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}

@@ -1,0 +1,505 @@
+// Pippenger multi-scalar multiplication over Ed25519 for gfx950.
+//
+// Replaces the hot loop of the reference's Pedersen vector commitment,
+//     prod = list_mul([g[i] ** _int(x_i) for i, x_i in enumerate(x)])
+//     verifiable_mpc/ac20/pivot.py:143-144
+// (n independent 253-bit double-and-add ladders followed by a product tree) by a
+// windowed bucket method.  The group element produced is the same; only its affine
+// normal form is defined as output.
+//
+// Pipeline (all on one stream, no host round trip):
+//   prep     affine (x,y) -> niels (y-x, y+x, 2dxy), 96 B/point, coalesced 16-B accesses
+//   recode   32-B scalars -> W signed c-bit digits (int16, window-major)
+//   hist     per (window, slice) workgroup: digit histogram in LDS (up to 128 KiB)
+//   counts   per-bucket totals + per-slice exclusive offsets
+//   scan     exclusive scan of bucket totals -> bucket start offsets
+//   scatter  per (window, slice) workgroup: LDS cursors -> bucket-sorted point indices
+//   bucket   one lane per bucket: mixed additions (7M) over its sorted run
+//   reduce   per window: chunked running sums + LDS tree -> sum_b b*B_b partials
+//   final    window sums, Horner over windows (c doublings each), one inversion -> affine
+//
+// HBM traffic is dominated by the 96-B niels gathers (W per term) and the 4-B sorted
+// indices; the algorithmic bytes of SURVEY.md 8d are 96 B per term (32 B scalar + 64 B
+// point).  Arithmetic is 32x32->64 integer multiply-add; no MFMA.
+#include "common.cuh"
+#include "fe25519.cuh"
+#include "fr.cuh"
+#include "ge25519.cuh"
+#include "scan.cuh"
+
+#define MSM_MAX_C 16
+#define MSM_BLOCK 256
+#define MSM_SORT_BLOCK 1024
+
+struct msm_plan {
+    size_t n_main, n_extra, n_total;
+    int c, W, nb, nb1;  // nb = 2^(c-1) buckets per window, nb1 = nb + 1 (bucket 0 unused)
+    int S;              // slices per window in the sort kernels
+    size_t slice_len;
+    int chunks;         // chunk-threads per window in the reduce kernel
+    int chunk_len;      // buckets per chunk (power of two)
+    int red_blocks;     // blocks per window in the reduce kernel
+};
+
+__device__ __forceinline__ void load_u32x8(uint32_t dst[8], const uint32_t *src) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(src);
+    uint4 a = p[0], b = p[1];
+    dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+    dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+}
+__device__ __forceinline__ void store_u32x8(uint32_t *dst, const uint32_t src[8]) {
+    uint4 *p = reinterpret_cast<uint4 *>(dst);
+    p[0] = make_uint4(src[0], src[1], src[2], src[3]);
+    p[1] = make_uint4(src[4], src[5], src[6], src[7]);
+}
+__device__ __forceinline__ fe fe_ld(const uint32_t *src) {
+    fe r;
+    load_u32x8(r.v, src);
+    return r;
+}
+__device__ __forceinline__ void fe_st(uint32_t *dst, const fe &a) { store_u32x8(dst, a.v); }
+
+__device__ __forceinline__ ge_ext ext_ld(const uint32_t *p) {
+    ge_ext r;
+    r.X = fe_ld(p);
+    r.Y = fe_ld(p + 8);
+    r.Z = fe_ld(p + 16);
+    r.T = fe_ld(p + 24);
+    return r;
+}
+__device__ __forceinline__ void ext_st(uint32_t *p, const ge_ext &a) {
+    fe_st(p, a.X);
+    fe_st(p + 8, a.Y);
+    fe_st(p + 16, a.Z);
+    fe_st(p + 24, a.T);
+}
+
+// ---- prep: affine -> niels ------------------------------------------------------------
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_prep(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__restrict__ aff_extra,
+           size_t n_total, uint32_t *__restrict__ niels) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    const uint32_t *src = (i < n_main) ? aff + 16 * i : aff_extra + 16 * (i - n_main);
+    ge_aff a;
+    a.x = fe_ld(src);
+    a.y = fe_ld(src + 8);
+    ge_niels q = ge_niels_from_affine(a);
+    uint32_t *dst = niels + 24 * i;
+    fe_st(dst, q.ymx);
+    fe_st(dst + 8, q.ypx);
+    fe_st(dst + 16, q.t2d);
+}
+
+// ---- recode: scalar -> signed digits ----------------------------------------------------
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__restrict__ sc_extra,
+             size_t n_total, int16_t *__restrict__ digits, int c, int W,
+             uint32_t *__restrict__ status) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    const uint32_t *src = (i < n_main) ? sc + 8 * i : sc_extra + 8 * (i - n_main);
+    uint32_t s[8];
+    load_u32x8(s, src);
+    if (fr_geq_l(s)) {
+        atomicAdd(&status[VMPC_ST_NONCANON], 1u);
+        // keep going with the value reduced once (still < 2^256 - l): result is defined,
+        // but the caller is told at the next sync point
+    }
+    const uint32_t mask = (1u << c) - 1u;
+    const uint32_t half = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        uint32_t raw = (s[0] & mask) + carry;
+        int32_t d;
+        if (raw >= half) {
+            d = (int32_t)raw - (int32_t)(1u << c);
+            carry = 1;
+        } else {
+            d = (int32_t)raw;
+            carry = 0;
+        }
+        digits[(size_t)w * n_total + i] = (int16_t)d;
+        // s >>= c  (c < 32; static limb indices keep s[] in registers)
+#pragma unroll
+        for (int k = 0; k < 7; k++) s[k] = (s[k] >> c) | (s[k + 1] << (32 - c));
+        s[7] >>= c;
+    }
+}
+
+// ---- hist: per (slice, window) digit histogram in LDS ----------------------------------
+__global__ void __launch_bounds__(MSM_SORT_BLOCK)
+k_msm_hist(const int16_t *__restrict__ digits, size_t n_total, size_t slice_len, int nb1, int S,
+           uint32_t *__restrict__ hist) {
+    extern __shared__ uint32_t lds[];
+    const int s = blockIdx.x, w = blockIdx.y;
+    for (int b = threadIdx.x; b < nb1; b += blockDim.x) lds[b] = 0;
+    __syncthreads();
+    size_t lo = (size_t)s * slice_len;
+    size_t hi = lo + slice_len;
+    if (hi > n_total) hi = n_total;
+    const int16_t *dw = digits + (size_t)w * n_total;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        int d = dw[i];
+        if (d != 0) atomicAdd(&lds[d < 0 ? -d : d], 1u);
+    }
+    __syncthreads();
+    uint32_t *out = hist + ((size_t)w * S + s) * nb1;
+    for (int b = threadIdx.x; b < nb1; b += blockDim.x) out[b] = lds[b];
+}
+
+// ---- counts: per-bucket totals; hist[w][s][b] becomes the exclusive offset of slice s ---
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_counts(uint32_t *__restrict__ hist, int W, int S, int nb1, uint32_t *__restrict__ counts) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)W * nb1) return;
+    int w = (int)(t / nb1), b = (int)(t % nb1);
+    uint32_t run = 0;
+    for (int s = 0; s < S; s++) {
+        size_t idx = ((size_t)w * S + s) * nb1 + b;
+        uint32_t v = hist[idx];
+        hist[idx] = run;
+        run += v;
+    }
+    counts[t] = run;
+}
+
+// ---- scatter: bucket-sorted point indices -------------------------------------------------
+__global__ void __launch_bounds__(MSM_SORT_BLOCK)
+k_msm_scatter(const int16_t *__restrict__ digits, size_t n_total, size_t slice_len, int nb1, int S,
+              const uint32_t *__restrict__ hist, const uint32_t *__restrict__ starts,
+              uint32_t *__restrict__ sorted) {
+    extern __shared__ uint32_t lds[];
+    const int s = blockIdx.x, w = blockIdx.y;
+    const uint32_t *off = hist + ((size_t)w * S + s) * nb1;
+    const uint32_t *st = starts + (size_t)w * nb1;
+    for (int b = threadIdx.x; b < nb1; b += blockDim.x) lds[b] = st[b] + off[b];
+    __syncthreads();
+    size_t lo = (size_t)s * slice_len;
+    size_t hi = lo + slice_len;
+    if (hi > n_total) hi = n_total;
+    const int16_t *dw = digits + (size_t)w * n_total;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        int d = dw[i];
+        if (d != 0) {
+            uint32_t pos = atomicAdd(&lds[d < 0 ? -d : d], 1u);
+            sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+
+// ---- bucket accumulation: one lane per (window, bucket) --------------------------------
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ sorted,
+             const uint32_t *__restrict__ starts, const uint32_t *__restrict__ counts, int W, int nb,
+             uint32_t *__restrict__ buckets) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)W * nb) return;
+    int w = (int)(t / nb), b = (int)(t % nb) + 1;
+    size_t ci = (size_t)w * (nb + 1) + b;
+    uint32_t start = starts[ci], cnt = counts[ci];
+    ge_ext acc = ge_ext_identity();
+    for (uint32_t j = 0; j < cnt; j++) {
+        uint32_t e = sorted[start + j];
+        const uint32_t *src = niels + 24 * (size_t)(e & 0x7fffffffu);
+        ge_niels q;
+        q.ymx = fe_ld(src);
+        q.ypx = fe_ld(src + 8);
+        q.t2d = fe_ld(src + 16);
+        q = ge_niels_select_neg(q, (e >> 31) != 0);
+        acc = ge_madd(acc, q);
+    }
+    ext_st(buckets + 32 * t, acc);
+}
+
+// ---- reduce: sum_b b * B_b per window ---------------------------------------------------
+// thread = one chunk of `chunk_len` consecutive buckets; running sums inside the chunk,
+// chunk offset by a short double-and-add, then an LDS tree over the workgroup.
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_reduce(const uint32_t *__restrict__ buckets, int nb, int chunks, int chunk_len,
+             int log2_chunk_len, int red_blocks, uint32_t *__restrict__ partials) {
+    __shared__ uint32_t lds[MSM_BLOCK * 32];
+    const int w = blockIdx.y;
+    const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
+    ge_ext contrib = ge_ext_identity();
+    if (chunk < chunks) {
+        const int lo = chunk * chunk_len;  // 0-based bucket index; bucket value = index + 1
+        const uint32_t *bw = buckets + 32 * ((size_t)w * nb + lo);
+        ge_ext acc = ge_ext_identity(), sum = ge_ext_identity();
+        for (int j = chunk_len - 1; j >= 0; j--) {
+            acc = ge_add(acc, ext_ld(bw + 32 * j));
+            sum = ge_add(sum, acc);
+        }
+        // sum = sum_j (j+1) B_{lo+j}; add lo * acc where lo = chunk * 2^log2_chunk_len
+        if (chunk != 0) {
+            ge_ext base = acc;
+            for (int k = 0; k < log2_chunk_len; k++) base = ge_dbl(base);
+            ge_ext r = ge_ext_identity();
+            int top = 31 - __clz(chunk);
+            for (int k = top; k >= 0; k--) {
+                r = ge_dbl(r);
+                if ((chunk >> k) & 1) r = ge_add(r, base);
+            }
+            sum = ge_add(sum, r);
+        }
+        contrib = sum;
+    }
+    ext_st(lds + 32 * threadIdx.x, contrib);
+    __syncthreads();
+    for (int stride = MSM_BLOCK / 2; stride >= 1; stride >>= 1) {
+        if ((int)threadIdx.x < stride) {
+            ge_ext a = ext_ld(lds + 32 * threadIdx.x);
+            ge_ext b = ext_ld(lds + 32 * (threadIdx.x + stride));
+            ext_st(lds + 32 * threadIdx.x, ge_add(a, b));
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        ext_st(partials + 32 * ((size_t)w * red_blocks + blockIdx.x), ext_ld(lds));
+}
+
+// ---- final: window sums, Horner, normalise -----------------------------------------------
+__global__ void __launch_bounds__(64)
+k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
+            uint32_t *__restrict__ out_ext, uint32_t *__restrict__ out_aff) {
+    __shared__ uint32_t lds[64 * 32];
+    const int w = threadIdx.x;
+    if (w < W) {
+        ge_ext r = ext_ld(partials + 32 * ((size_t)w * red_blocks));
+        for (int j = 1; j < red_blocks; j++)
+            r = ge_add(r, ext_ld(partials + 32 * ((size_t)w * red_blocks + j)));
+        ext_st(lds + 32 * w, r);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ge_ext acc = ext_ld(lds + 32 * (W - 1));
+        for (int k = W - 2; k >= 0; k--) {
+            for (int j = 0; j < c; j++) acc = ge_dbl(acc);
+            acc = ge_add(acc, ext_ld(lds + 32 * k));
+        }
+        if (out_ext) ext_st(out_ext, acc);
+        if (out_aff) {
+            ge_aff a = ge_ext_to_affine(acc);
+            fe_st(out_aff, a.x);
+            fe_st(out_aff + 8, a.y);
+        }
+    }
+}
+
+// ---- sum of m extended points in order (multi-GPU combine) --------------------------------
+__global__ void __launch_bounds__(64)
+k_points_sum(const uint32_t *__restrict__ pts, size_t m, uint32_t *__restrict__ out_ext,
+             uint32_t *__restrict__ out_aff) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ge_ext acc = ge_ext_identity();
+    for (size_t i = 0; i < m; i++) acc = ge_add(acc, ext_ld(pts + 32 * i));
+    if (out_ext) ext_st(out_ext, acc);
+    if (out_aff) {
+        ge_aff a = ge_ext_to_affine(acc);
+        fe_st(out_aff, a.x);
+        fe_st(out_aff + 8, a.y);
+    }
+}
+
+// ---- validation ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_points_validate(const uint32_t *__restrict__ aff, size_t n, unsigned long long *__restrict__ bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ge_aff a;
+    a.x = fe_ld(aff + 16 * i);
+    a.y = fe_ld(aff + 16 * i + 8);
+    bool ok = fe_is_canonical(a.x) && fe_is_canonical(a.y) && ge_aff_on_curve(a);
+    if (!ok) atomicAdd(bad, 1ull);
+}
+
+// ---- host side ---------------------------------------------------------------------------
+static int msm_pick_window(size_t n) {
+    double best = 1e300;
+    int best_c = 4;
+    for (int c = 4; c <= MSM_MAX_C; c++) {
+        int W = (255 + c - 1) / c;
+        double cost = (double)W * ((double)n + 2.5 * (double)(1u << (c - 1)));
+        if (cost < best) {
+            best = cost;
+            best_c = c;
+        }
+    }
+    return best_c;
+}
+
+static void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, msm_plan &p) {
+    p.n_main = n_main;
+    p.n_extra = n_extra;
+    p.n_total = n_main + n_extra;
+    p.c = ctx->window_override ? ctx->window_override : msm_pick_window(p.n_total);
+    if (p.c < 2) p.c = 2;
+    if (p.c > MSM_MAX_C) p.c = MSM_MAX_C;
+    p.W = (255 + p.c - 1) / p.c;
+    p.nb = 1 << (p.c - 1);
+    p.nb1 = p.nb + 1;
+    // enough (window, slice) workgroups to cover the chip twice, slices of >= 4096 terms
+    int S = (2 * ctx->cu_count + p.W - 1) / p.W;
+    size_t max_s = (p.n_total + 4095) / 4096;
+    if ((size_t)S > max_s) S = (int)max_s;
+    if (S < 1) S = 1;
+    p.S = S;
+    p.slice_len = (p.n_total + S - 1) / S;
+    // reduce: up to 2048 chunk-threads per window, chunk length a power of two
+    int chunks = p.nb < 2048 ? p.nb : 2048;
+    p.chunks = chunks;
+    p.chunk_len = p.nb / chunks;
+    p.red_blocks = (chunks + MSM_BLOCK - 1) / MSM_BLOCK;
+}
+
+struct msm_ws {
+    uint32_t *niels, *hist, *counts, *starts, *sorted, *buckets, *partials;
+    int16_t *digits;
+    void *scan_ws;
+    size_t total;
+};
+
+static void msm_layout(const msm_plan &p, msm_ws &w, char *base) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += vmpc_align(bytes);
+        return base ? (void *)(base + o) : (void *)nullptr;
+    };
+    size_t nbk = (size_t)p.W * p.nb1;
+    w.niels = (uint32_t *)take(p.n_total * 96);
+    w.digits = (int16_t *)take((size_t)p.W * p.n_total * 2);
+    w.hist = (uint32_t *)take((size_t)p.W * p.S * p.nb1 * 4);
+    w.counts = (uint32_t *)take(nbk * 4);
+    w.starts = (uint32_t *)take(nbk * 4);
+    w.sorted = (uint32_t *)take((size_t)p.W * p.n_total * 4);
+    w.buckets = (uint32_t *)take((size_t)p.W * p.nb * 128);
+    w.partials = (uint32_t *)take((size_t)p.W * p.red_blocks * 128);
+    w.scan_ws = take(vmpc_scan_ws_bytes(nbk, 4));
+    w.total = off;
+}
+
+static int ilog2(int v) {
+    int r = 0;
+    while ((1 << r) < v) r++;
+    return r;
+}
+
+extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affine_points, size_t n,
+                            const void *extra_scalars, const void *extra_affine_points,
+                            size_t n_extra, void *out_ext, void *out_affine) {
+    if (!ctx || (n && (!scalars || !affine_points)) || (n_extra && (!extra_scalars || !extra_affine_points)))
+        return VMPC_E_INVAL;
+    if (!out_ext && !out_affine) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    size_t n_total = n + n_extra;
+    if (n_total == 0) {
+        // empty product = identity (pivot.list_mul's `initial`, pivot.py:28)
+        uint32_t id_ext[32] = {0}, id_aff[16] = {0};
+        id_ext[8] = 1; id_ext[16] = 1; id_aff[8] = 1;
+        if (out_ext) VMPC_HIP_CHECK(hipMemcpyAsync(out_ext, id_ext, 128, hipMemcpyHostToDevice, st));
+        if (out_affine) VMPC_HIP_CHECK(hipMemcpyAsync(out_affine, id_aff, 64, hipMemcpyHostToDevice, st));
+        VMPC_HIP_CHECK(hipStreamSynchronize(st));
+        return VMPC_OK;
+    }
+    if (n_total >= (1ull << 31) / 16) return VMPC_E_INVAL;  // index / offset width
+    msm_plan p;
+    msm_make_plan(ctx, n, n_extra, p);
+    msm_ws w;
+    msm_layout(p, w, nullptr);
+    VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
+    msm_layout(p, w, (char *)ctx->ws);
+
+    const unsigned gb = (unsigned)((n_total + MSM_BLOCK - 1) / MSM_BLOCK);
+    const size_t lds_bytes = (size_t)p.nb1 * 4;
+    if (lds_bytes > 48 * 1024) {
+        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_hist,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_scatter,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_prep");
+        k_msm_prep<<<gb, MSM_BLOCK, 0, st>>>((const uint32_t *)affine_points, n,
+                                            (const uint32_t *)extra_affine_points, n_total, w.niels);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_recode");
+        k_msm_recode<<<gb, MSM_BLOCK, 0, st>>>((const uint32_t *)scalars, n,
+                                              (const uint32_t *)extra_scalars, n_total, w.digits, p.c,
+                                              p.W, ctx->d_status);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_hist");
+        k_msm_hist<<<dim3(p.S, p.W), MSM_SORT_BLOCK, lds_bytes, st>>>(w.digits, n_total, p.slice_len,
+                                                                     p.nb1, p.S, w.hist);
+        VMPC_KERNEL_CHECK();
+    }
+    size_t nbk = (size_t)p.W * p.nb1;
+    {
+        vmpc_stage_scope s(ctx, "msm_counts_scan");
+        k_msm_counts<<<(unsigned)((nbk + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
+            w.hist, p.W, p.S, p.nb1, w.counts);
+        VMPC_KERNEL_CHECK();
+        VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint32_t>(st, w.counts, w.starts, nbk, w.scan_ws,
+                                                            (uint32_t *)nullptr)));
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_scatter");
+        k_msm_scatter<<<dim3(p.S, p.W), MSM_SORT_BLOCK, lds_bytes, st>>>(
+            w.digits, n_total, p.slice_len, p.nb1, p.S, w.hist, w.starts, w.sorted);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_bucket");
+        size_t nt = (size_t)p.W * p.nb;
+        k_msm_bucket<<<(unsigned)((nt + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
+            w.niels, w.sorted, w.starts, w.counts, p.W, p.nb, w.buckets);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_reduce");
+        k_msm_reduce<<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, st>>>(
+            w.buckets, p.nb, p.chunks, p.chunk_len, ilog2(p.chunk_len), p.red_blocks, w.partials);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_final");
+        k_msm_final<<<1, 64, 0, st>>>(w.partials, p.W, p.red_blocks, p.c, (uint32_t *)out_ext,
+                                      (uint32_t *)out_affine);
+        VMPC_KERNEL_CHECK();
+    }
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_points_sum_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, void *out_ext,
+                                   void *out_affine) {
+    if (!ctx || (m && !ext_points) || (!out_ext && !out_affine)) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    vmpc_stage_scope s(ctx, "points_sum");
+    k_points_sum<<<1, 64, 0, ctx->stream>>>((const uint32_t *)ext_points, m, (uint32_t *)out_ext,
+                                           (uint32_t *)out_affine);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_points_validate_dev(vmpc_ctx *ctx, const void *affine, size_t n, uint64_t *n_bad) {
+    if (!ctx || !n_bad || (n && !affine)) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    VMPC_CHECK(vmpc_ws_reserve(ctx, 256));
+    unsigned long long *d_bad = (unsigned long long *)vmpc_ws_take(ctx, 8);
+    VMPC_HIP_CHECK(hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+    if (n) {
+        k_points_validate<<<(unsigned)((n + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
+            (const uint32_t *)affine, n, d_bad);
+        VMPC_KERNEL_CHECK();
+    }
+    unsigned long long h = 0;
+    VMPC_HIP_CHECK(hipMemcpyAsync(&h, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *n_bad = h;
+    return VMPC_OK;
+}
