@@ -1,0 +1,268 @@
+"""GPU parity of the drop-in Protocol 4/5 (verifiable_mpc_amd.compressed_pivot) against
+ (1) the golden fixtures captured from the reference's own modules
+     (tests/golden/make_fixtures.py), and
+ (2) the oracle restatement run on the same seeded inputs.
+Bit-exact: commitments, every A_i/B_i (affine), t, z', and every Fiat-Shamir challenge
+(i.e. the pre-image text itself, including the un-normalised folded generators).
+"""
+import hashlib
+import random
+
+import pytest
+
+from oracle import ac20_ref as ac
+from oracle import ed25519_ref as ed
+
+pytestmark = pytest.mark.gpu
+
+ELL = ed.ELL
+hx = lambda v: format(int(v), "x")
+h2i = lambda s: int(s, 16)
+
+
+@pytest.fixture(scope="module")
+def vm():
+    import verifiable_mpc_amd as v
+    v.get_context()
+    return v
+
+
+@pytest.fixture()
+def record_hashes(vm, monkeypatch):
+    calls = []
+    orig = vm.pivot.fiat_shamir_hash
+
+    def wrapped(input_list, order):
+        c = orig(input_list, order)
+        calls.append(c)
+        return c
+    monkeypatch.setattr(vm.pivot, "fiat_shamir_hash", wrapped)
+    return calls
+
+
+def aff_hex(pt):
+    n = pt.normalize()
+    return [hx(n.coords[0]), hx(n.coords[1])]
+
+
+def build_generators(vm, case, monkeypatch, seed):
+    """create_generators with the reference's draw order replayed from the fixture seed."""
+    group = vm.EllipticCurve("Ed25519", "projective")
+    monkeypatch.setattr(vm.circuit_sat, "prng", random.Random(seed))
+    gens = vm.create_generators(case["n"], vm.PivotChoice.compressed, group)
+    return group, gens
+
+
+def check_proof(case, proof, hashes):
+    pr = case["proof"]
+    assert hx(int(proof["t"]) % ELL) == pr["t"]
+    assert aff_hex(proof["A"]) == pr["A"]
+    for i in range(case["rounds"]):
+        assert aff_hex(proof[f"A{i}"]) == pr["A_i"][i], f"A{i}"
+        assert aff_hex(proof[f"B{i}"]) == pr["B_i"][i], f"B{i}"
+    assert [hx(int(v) % ELL) for v in proof["z_prime"]] == pr["z_prime"]
+    assert [hx(c) for c in hashes] == [h["c"] for h in case["hashes"]]
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+@pytest.mark.parametrize("device_mode", [False, True])
+def test_protocol5_matches_reference_fixture(vm, golden_small, monkeypatch, record_hashes, idx,
+                                             device_mode):
+    case = golden_small["p5"][idx]
+    n = case["n"]
+    group, gens = build_generators(vm, case, monkeypatch, case["seed"] + 1)
+    gf = vm.GF(group.order)
+    # generator representatives are the reference's (projective, un-normalised)
+    pts = gens["g"].to_points() + [gens["h"], gens["k"]]
+    raw = b"".join(p.to_proj_bytes() for p in pts)
+    assert hashlib.sha256(raw).hexdigest() == case["gens_proj_sha256"]
+    if "gens_proj" in case:
+        assert [[hx(c) for c in p.coords] for p in pts] == case["gens_proj"]
+
+    x = [gf(h2i(v)) for v in case["x"]]
+    coeffs = [gf(h2i(v)) for v in case["L"]]
+    gamma, y = h2i(case["gamma"]), gf(h2i(case["y"]))
+    if device_mode:
+        x = vm.ScalarVector.from_ints(x)
+        L = vm.pivot.LinearForm(vm.ScalarVector.from_ints(coeffs))
+    else:
+        L = vm.pivot.LinearForm(coeffs)
+    P = vm.pivot.vector_commitment(x, gamma, gens["g"], gens["h"])
+    assert aff_hex(P) == case["P"]
+
+    monkeypatch.setattr(vm.compressed_pivot, "prng", random.Random(case["seed"] + 2))
+    proof = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, gamma, gf)
+    prover_hashes = list(record_hashes)
+    check_proof(case, proof, prover_hashes)
+
+    assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, proof, gf) is True
+    assert record_hashes[len(prover_hashes):] == prover_hashes
+    bad = dict(proof)
+    bad["z_prime"] = [proof["z_prime"][0] + 1, proof["z_prime"][1]]
+    assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, bad, gf) is False
+    bad = dict(proof)
+    bad["A0"] = proof["B0"]
+    assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, bad, gf) is False
+
+
+def test_protocol5_first_preimage_text(vm, golden_small, monkeypatch):
+    """the streamed pre-image equals the reference's str(input_list) byte for byte (N = 4)."""
+    case = golden_small["p5"][0]
+    group, gens = build_generators(vm, case, monkeypatch, case["seed"] + 1)
+    gf = vm.GF(group.order)
+    texts = []
+
+    class Spy:
+        def __init__(self):
+            self.h = hashlib.sha256()
+            self.buf = bytearray()
+
+        def update(self, b):
+            self.buf += bytes(b)
+            self.h.update(b)
+
+        def digest(self):
+            texts.append(bytes(self.buf).decode())
+            return self.h.digest()
+    import types
+    monkeypatch.setattr(vm.pivot, "hashlib", types.SimpleNamespace(sha256=lambda: Spy()))
+    x = [gf(h2i(v)) for v in case["x"]]
+    L = vm.pivot.LinearForm([gf(h2i(v)) for v in case["L"]])
+    P = vm.Ed25519Point((h2i(case["P"][0]), h2i(case["P"][1]), 1))
+    monkeypatch.setattr(vm.compressed_pivot, "prng", random.Random(case["seed"] + 2))
+    vm.compressed_pivot.protocol_5_prover(gens, P, L, gf(h2i(case["y"])), x, h2i(case["gamma"]), gf)
+    assert texts == [h["text"] for h in case["hashes"]]
+
+
+def test_protocol5_n1023_device_mode(vm, golden_n1023, monkeypatch, record_hashes):
+    case = golden_n1023
+    group, gens = build_generators(vm, case, monkeypatch, case["seed"] + 1)
+    gf = vm.GF(group.order)
+    x = vm.ScalarVector.from_ints([h2i(v) for v in case["x"]])
+    L = vm.pivot.LinearForm(vm.ScalarVector.from_ints([h2i(v) for v in case["L"]]))
+    gamma, y = h2i(case["gamma"]), gf(h2i(case["y"]))
+    P = vm.pivot.vector_commitment(x, gamma, gens["g"], gens["h"])
+    assert aff_hex(P) == case["P"]
+    monkeypatch.setattr(vm.compressed_pivot, "prng", random.Random(case["seed"] + 2))
+    proof = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, gamma, gf)
+    hashes = list(record_hashes)
+    check_proof(case, proof, hashes)
+    assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, proof, gf) is True
+
+
+def typed_value(gf, s):
+    kind, v = s.split(":")
+    return int(v) if kind == "i" else gf(int(v, 16))
+
+
+def test_demo_zkp_ac20_elliptic_protocol5_call(vm, golden_demo, monkeypatch, record_hashes):
+    """BASELINE config 1: the Protocol-5 call made by demos/demo_zkp_ac20.py --elliptic
+    (N = 128), with the demo's exact Python typing of x and L (plain ints stay unreduced in
+    the pre-image, pivot.py:62-70)."""
+    case = golden_demo
+    group, gens = build_generators(vm, case, monkeypatch, 20200152 + 600 + 10)
+    gf = vm.GF(group.order)
+    x = [typed_value(gf, s) for s in case["x_typed"]]
+    L = vm.pivot.AffineForm([typed_value(gf, s) for s in case["L_typed"]],
+                            typed_value(gf, case["L_constant_typed"]))
+    y = typed_value(gf, case["y_typed"])
+    gamma = h2i(case["gamma"])
+    P = vm.pivot.vector_commitment(x, gamma, gens["g"], gens["h"])
+    assert aff_hex(P) == case["P"]
+    monkeypatch.setattr(vm.compressed_pivot, "prng", random.Random(20200152 + 600 + 12))
+    proof = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, gamma, gf)
+    check_proof(case, proof, list(record_hashes))
+    # the demo's verifier call passes y = 0 and the un-shifted form (circuit_sat_cb.py:297-299)
+    assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, 0, proof, gf) is True
+
+
+@pytest.mark.parametrize("n", [3, 31])
+def test_compact_transcript_matches_oracle(vm, monkeypatch, n):
+    rng = random.Random(500 + n)
+    exps = [rng.randrange(1, ELL) for _ in range(n)]
+    ek = rng.randrange(1, ELL)
+    ogens = ac.create_generators(exps, ek)
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    gens = {"g": vm.PointVector.fixed_base(group.generator, exps, keep_proj=False),
+            "h": group.generator, "k": vm.Ed25519Point.repeat(group.generator, ek)}
+    x = [rng.randrange(ELL) for _ in range(n)]
+    coeffs = [rng.randrange(ELL) for _ in range(n)]
+    gamma = rng.randrange(1, ELL)
+    r = [rng.randrange(ELL) for _ in range(n)]
+    rho = rng.randrange(ELL)
+    oP = ac.vector_commitment(x, gamma, ogens["g"], ogens["h"])
+    oy = ac.form_eval(coeffs, 0, x)
+    want = ac.protocol_5_prover(ogens, oP, coeffs, 0, oy, x, gamma, r, rho, "compact")
+    xs, Lf = vm.ScalarVector.from_ints(x), vm.pivot.LinearForm(vm.ScalarVector.from_ints(coeffs))
+    P = vm.pivot.vector_commitment(xs, gamma, gens["g"], gens["h"])
+    proof = vm.compressed_pivot.protocol_5_prover(gens, P, Lf, gf(oy), xs, gamma, gf,
+                                                  transcript="compact", r=r, rho=rho)
+    rounds = (n + 1).bit_length() - 2
+    assert int(proof["t"]) % ELL == want["t"]
+    for key in ["A"] + [f"A{i}" for i in range(rounds)] + [f"B{i}" for i in range(rounds)]:
+        assert tuple(proof[key].normalize().coords[:2]) == ed.pt_affine(want[key]), key
+    assert [int(v) % ELL for v in proof["z_prime"]] == want["z_prime"]
+    assert vm.compressed_pivot.protocol_5_verifier(gens, P, Lf, gf(oy), proof, gf,
+                                                   transcript="compact") is True
+    assert vm.compressed_pivot.protocol_5_verifier(gens, P, Lf, gf(oy + 1), proof, gf,
+                                                   transcript="compact") is False
+
+
+def test_basic_pivot_fixture(vm, golden_small, monkeypatch, record_hashes):
+    """Pi_s (pivot.py:156-205)."""
+    case = golden_small["pis"][0]
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    h = group.generator
+    g = vm.PointVector.fixed_base(h, [h2i(e) for e in case["gen_exponents"]])
+    x = [gf(h2i(v)) for v in case["x"]]
+    L = vm.pivot.LinearForm([gf(h2i(v)) for v in case["L"]])
+    gamma, y = h2i(case["gamma"]), gf(h2i(case["y"]))
+    P = vm.pivot.vector_commitment(x, gamma, g, h)
+    assert aff_hex(P) == case["P"]
+    monkeypatch.setattr(vm.pivot, "prng", random.Random(case["seed"] + 2))
+    monkeypatch.setattr(vm.Ed25519Point, "is_multiplicative", True)
+    monkeypatch.setattr(vm.Ed25519Point, "is_additive", False)
+    z, phi, c = vm.pivot.prove_linear_form_eval(g, h, P, L, y, x, gamma, gf)
+    assert [hx(v.value) for v in z] == case["z"] and hx(phi) == case["phi"] and hx(c) == case["c"]
+    assert vm.pivot.verify_linear_form_proof(g, h, P, L, y, z, phi, c) is True
+    assert [hx(v) for v in record_hashes] == [hh["c"] for hh in case["hashes"]]
+    assert vm.pivot.verify_linear_form_proof(g, h, P, L, y, z, phi + 1, c) is False
+
+
+def test_vector_commitment_exact_representative(vm):
+    """exact_representative=True replays pivot.py:143-144 + list_mul: same (X:Y:Z)."""
+    rng = random.Random(77)
+    n = 21
+    exps = [rng.randrange(1, ELL) for _ in range(n)]
+    ogens = ac.create_generators(exps)
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    g = vm.PointVector.fixed_base(group.generator, exps)
+    x = [rng.randrange(ELL) for _ in range(n)]
+    gamma = rng.randrange(ELL)
+    want = ac.vector_commitment(x, gamma, ogens["g"], ogens["h"])       # signed exponents
+    got = vm.pivot.vector_commitment([gf(v) for v in x], gamma, g, group.generator,
+                                     exact_representative=True)
+    assert got.coords == want
+    want_u = ac.vector_commitment(x, gamma, ogens["g"], ogens["h"], signed_exponents=False)
+    got_u = vm.pivot.vector_commitment(x, gamma, g, group.generator, exact_representative=True)
+    assert got_u.coords == want_u
+    assert vm.pivot.list_mul(g).coords == ed.tree_reduce(ed.pt_add, ogens["g"], ed.IDENTITY)
+
+
+def test_reference_error_conventions(vm):
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    g = vm.PointVector.fixed_base(group.generator, [3, 5])
+    with pytest.raises(AssertionError, match="Not enough generators."):
+        vm.pivot.vector_commitment([1, 2, 3], 1, g, group.generator)
+    gens = {"g": g, "h": group.generator, "k": group.generator}
+    with pytest.raises(AssertionError, match="power of 2"):
+        vm.compressed_pivot.protocol_5_prover(gens, group.generator, vm.pivot.LinearForm([1, 2]),
+                                              0, [1, 2], 1, gf)
+    with pytest.raises(NotImplementedError):
+        vm.create_generators(3, vm.PivotChoice.koe, group)
+    with pytest.raises(NotImplementedError):
+        vm.EllipticCurve("BN256")

@@ -1,0 +1,343 @@
+"""Drop-in counterpart of verifiable_mpc/ac20/compressed_pivot.py (AC20 Protocols 4 and 5)
+with the O(N) work on MI355X.
+
+    protocol_4_prover    compressed_pivot.py:29-86
+    protocol_5_prover    compressed_pivot.py:89-145
+    protocol_4_verifier  compressed_pivot.py:148-202
+    protocol_5_verifier  compressed_pivot.py:205-239
+
+Per halving round the GPU runs two Pippenger MSMs (A_i, B_i: csrc/msm.hip), the generator
+fold g' (csrc/exact.hip), the scalar folds z', L' and the two inner products (csrc/frvec.hip)
+and formats the Fiat-Shamir pre-image (csrc/format.hip); the host hashes it and does the
+O(1) algebra on Q.
+
+Two scalar-side modes, chosen by the argument types:
+  * Python lists (the reference's calling convention): scalars stay Python objects with the
+    reference's typing semantics (ints are never reduced, field elements are), so the
+    pre-image text is what the reference would hash; only reduced copies go to the GPU;
+  * device vectors (verifiable_mpc_amd.device.ScalarVector / PointVector): everything stays
+    in HBM; this is the mode for N = 2^20.
+Transcripts: "reference" = str(input_list) as in the reference (default);
+"compact" = the build's O(1)-per-round byte transcript.
+"""
+import hashlib
+import logging
+from random import SystemRandom
+
+from . import pivot
+from .device import PointVector, ScalarVector, reduce_scalar
+from .groups import EllipticCurvePoint as EllipticCurveElement
+from .groups import Ed25519Point
+
+prng = SystemRandom()
+
+logger_cp = logging.getLogger("compressed_pivot")
+logger_cp.setLevel(logging.INFO)
+logger_cp_hin = logging.getLogger("compressed_pivot_hash_inputs")
+logger_cp_hin.setLevel(logging.INFO)
+logger_cp_hout = logging.getLogger("compressed_pivot_hash_outputs")
+logger_cp_hout.setLevel(logging.INFO)
+
+TRANSCRIPT = "reference"
+CHUNK = 4096
+
+
+# ---- group glue on single elements (independent of the is_additive/is_multiplicative flags) ----
+
+def _pt(obj):
+    """Accept our points or any 3-coordinate projective element (e.g. an MPyC point)."""
+    if isinstance(obj, Ed25519Point):
+        return obj
+    return Ed25519Point((int(obj[0]), int(obj[1]), int(obj[2])))
+
+
+def _gmul(a, b):
+    return Ed25519Point.operation(a, b)
+
+
+def _gpow(a, n):
+    return Ed25519Point.repeat(a, int(n))
+
+
+def _same_residue(a, b, order):
+    return (pivot._residue(a) - pivot._residue(b)) % order == 0
+
+
+# ---- scalar-side strategies --------------------------------------------------------------------
+
+def _on_device(*vs):
+    return any(isinstance(v, ScalarVector) for v in vs)
+
+
+def _coeffs_dev(form):
+    return pivot._as_device(form.coeffs)
+
+
+def _commit(z_part, gamma, g_part, k):
+    return pivot.vector_commitment(z_part, gamma, g_part, k)
+
+
+# ---- compact transcript ---------------------------------------------------------------------------
+
+def _chunked_digest(tag, data):
+    mv = memoryview(data)
+    leaves = b"".join(hashlib.sha256(mv[o:o + CHUNK]).digest() for o in range(0, len(mv), CHUNK))
+    return hashlib.sha256(tag + len(mv).to_bytes(8, "little") + leaves).digest()
+
+
+def _sc_bytes(v):
+    return reduce_scalar(v).to_bytes(32, "little")
+
+
+def generators_digest(generators):
+    """Digest of the CRS for the compact transcript; cached on the device vector."""
+    g = generators["g"]
+    if isinstance(g, PointVector) and g._digest is not None:
+        return g._digest
+    gv = pivot._points_on_device(g)
+    data = gv.affine_array().tobytes() + _pt(generators["h"]).to_affine_bytes() + \
+        _pt(generators["k"]).to_affine_bytes()
+    d = _chunked_digest(b"vmpc-ac20/gens/v1", data)
+    if isinstance(g, PointVector):
+        g._digest = d
+    return d
+
+
+def _form_digest(L):
+    c = L.coeffs
+    if isinstance(c, ScalarVector):
+        data = c.ctx.download(c.ptr, 32 * len(c)).tobytes()
+    else:
+        data = b"".join(_sc_bytes(pivot._residue(v)) for v in c)
+    return _chunked_digest(b"vmpc-ac20/form/v1", data)
+
+
+def _compact_seed(generators, P, L, y, t, A):
+    return hashlib.sha256(b"vmpc-ac20/p5/v1" + generators_digest(generators) + _form_digest(L)
+                          + P.to_affine_bytes() + _sc_bytes(pivot._residue(y))
+                          + _sc_bytes(pivot._residue(t)) + A.to_affine_bytes()).digest()
+
+
+def _challenge(digest, order):
+    return int.from_bytes(digest, "little") % order
+
+
+class _Transcript:
+    """Challenge source for Protocol 4: reference text hashing or the compact chain."""
+
+    def __init__(self, mode, order, state=None):
+        if mode not in ("reference", "compact"):
+            raise ValueError(f"unknown transcript mode {mode!r}")
+        self.mode, self.order, self.state = mode, order, state
+
+    def round_challenge(self, round_i, A, B, g_hat, k, Q, L_tilde):
+        if self.mode == "reference":
+            # compressed_pivot.py:51-59: A, B, Q normalised; g_hat, k as they are
+            input_list = [A.normalize(), B.normalize(), g_hat, k, Q.normalize(), L_tilde]
+            return pivot.fiat_shamir_hash(input_list, self.order)
+        self.state = hashlib.sha256(self.state + round_i.to_bytes(4, "little")
+                                    + A.to_affine_bytes() + B.to_affine_bytes()).digest()
+        return _challenge(self.state, self.order)
+
+
+# ---- Protocol 4 --------------------------------------------------------------------------------------
+
+def _round_prover_scalars(L_tilde, z_hat, half, gf):
+    """Exponents of k in A_i, B_i and the split witness (compressed_pivot.py:35-42)."""
+    if _on_device(L_tilde.coeffs, z_hat):
+        Lc, z = _coeffs_dev(L_tilde), pivot._as_device(z_hat)
+        z_l, z_r = z[:half], z[half:]
+        gamma_a = Lc[half:].dot(z_l)           # L~(0 || z_l)
+        gamma_b = Lc[:half].dot(z_r)           # L~(z_r || 0)
+        return z_l, z_r, gamma_a, gamma_b
+    z_l, z_r = z_hat[:half], z_hat[half:]
+    gamma_a = int(L_tilde([0] * half + z_l))
+    gamma_b = int(L_tilde(z_r + [0] * half))
+    return z_l, z_r, gamma_a, gamma_b
+
+
+def _fold_form(L_tilde, c, half, gf):
+    """L' = c * L_l + L_r (compressed_pivot.py:70-73)."""
+    assert L_tilde.constant == 0, "Next line assumes L_tilde is a linear form, not affine form."
+    if isinstance(L_tilde.coeffs, ScalarVector):
+        Lc = L_tilde.coeffs
+        return pivot.AffineForm(Lc[:half].axpy(c, Lc[half:]), 0)
+    scaled = [coeff * gf(c) for coeff in L_tilde.coeffs[:half]]
+    return pivot.LinearForm(scaled) + pivot.LinearForm(L_tilde.coeffs[half:])
+
+
+def _fold_witness(z_l, z_r, c, half):
+    """z' = z_l + c * z_r (compressed_pivot.py:76)."""
+    if isinstance(z_l, ScalarVector):
+        return z_r.axpy(c, z_l)
+    return [z_l[i] + c * z_r[i] for i in range(half)]
+
+
+def _fold_commitment(A, Q, B, c):
+    """Q' = A * Q**c * B**(c**2) (compressed_pivot.py:66; the exponent c**2 is not reduced
+    in the reference, which changes nothing for an element of order l)."""
+    return _gmul(_gmul(A, _gpow(Q, c)), _gpow(B, c * c))
+
+
+def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, transcript=None):
+    """Non-interactive Protocol 4, prover (compressed_pivot.py:29-86); the reference's
+    recursion is a loop here, `round_i` keeps its meaning."""
+    g_hat = pivot._points_on_device(g_hat)
+    k, Q = _pt(k), _pt(Q)
+    if not isinstance(transcript, _Transcript):
+        transcript = _Transcript(transcript or "reference", k.order)
+    while True:
+        half = len(g_hat) // 2
+        g_l, g_r = g_hat[:half], g_hat[half:]
+        z_l, z_r, gamma_a, gamma_b = _round_prover_scalars(L_tilde, z_hat, half, gf)
+        logger_cp.debug("Calculate A_i, B_i.")
+        A = _commit(z_l, gamma_a, g_r, k)
+        B = _commit(z_r, gamma_b, g_l, k)
+        proof["A" + str(round_i)] = A
+        proof["B" + str(round_i)] = B
+
+        c = transcript.round_challenge(round_i, A, B, g_hat, k, Q, L_tilde)
+        logger_cp_hout.debug(f"After hash, hash=\n{c}")
+
+        g_hat = g_l.fold(g_r, c)
+        Q = _fold_commitment(A, Q, B, c)
+        L_tilde = _fold_form(L_tilde, c, half, gf)
+        z_hat = _fold_witness(z_l, z_r, c, half)
+        if len(z_hat) <= 2:
+            if isinstance(z_hat, ScalarVector):
+                z_hat = [gf(v) for v in z_hat.to_ints()]
+            proof["z_prime"] = z_hat
+            return proof
+        round_i += 1
+
+
+def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=None):
+    """Non-interactive Protocol 4, verifier (compressed_pivot.py:148-202)."""
+    g_hat = pivot._points_on_device(g_hat)
+    k, Q = _pt(k), _pt(Q)
+    if not isinstance(transcript, _Transcript):
+        transcript = _Transcript(transcript or "reference", k.order)
+    while True:
+        half = len(g_hat) // 2
+        g_l, g_r = g_hat[:half], g_hat[half:]
+        A = _pt(proof["A" + str(round_i)])
+        B = _pt(proof["B" + str(round_i)])
+        c = transcript.round_challenge(round_i, A, B, g_hat, k, Q, L_tilde)
+        g_prime = g_l.fold(g_r, c)
+        Q = _fold_commitment(A, Q, B, c)
+        L_tilde = _fold_form(L_tilde, c, half, gf)
+        if len(g_prime) <= 2:
+            z_prime = proof["z_prime"]
+            Q_check = pivot.vector_commitment(z_prime, int(L_tilde(z_prime)), g_prime, k)
+            logger_cp.debug("Arrived in final step of protocol_4_verifier.")
+            return bool(Q_check == Q)
+        g_hat = g_prime
+        round_i += 1
+
+
+# ---- Protocol 5 ----------------------------------------------------------------------------------------
+
+def _p5_challenges(mode, order, generators, t, A, P, L, y):
+    if mode == "reference":
+        # compressed_pivot.py:117-130
+        input_list = [t, A.normalize(), generators, P.normalize(), L, y]
+        tag = ["First hash of compressed pivot"]
+        c0 = pivot.fiat_shamir_hash(input_list + [0] + tag, order)
+        c1 = pivot.fiat_shamir_hash(input_list + [1] + tag, order)
+        return c0, c1, None
+    seed = _compact_seed(generators, P, L, y, t, A)
+    c0 = _challenge(hashlib.sha256(seed + b"\x00").digest(), order)
+    c1 = _challenge(hashlib.sha256(seed + b"\x01").digest(), order)
+    return c0, c1, seed
+
+
+def _p5_setup(generators, k, Q, seed, mode, order):
+    if mode == "reference":
+        return _Transcript(mode, order)
+    state = hashlib.sha256(b"vmpc-ac20/p4/v1" + seed + k.to_affine_bytes()
+                           + Q.to_affine_bytes()).digest()
+    return _Transcript(mode, order, state)
+
+
+def _extend_form(L, c1):
+    """L~ = (L.coeffs || 0) * c1 (compressed_pivot.py:141)."""
+    if isinstance(L.coeffs, ScalarVector):
+        return pivot.LinearForm(L.coeffs.concat([0]).scale(c1))
+    return pivot.LinearForm(L.coeffs + [0]) * c1
+
+
+def protocol_5_prover(generators, P, L, y, x, gamma, gf, transcript=None, r=None, rho=None):
+    """Compressed Sigma-protocol Pi_c, prover (compressed_pivot.py:89-145).
+
+    Extensions over the reference signature (all optional): `transcript` selects the
+    Fiat-Shamir mode; `r`, `rho` supply the masks instead of drawing them from `prng`
+    (used to keep 2^20 draws off the Python interpreter)."""
+    mode = transcript or TRANSCRIPT
+    g, h, k = generators["g"], _pt(generators["h"]), _pt(generators["k"])
+    P = _pt(P)
+    proof = {}
+    n = len(x)
+    L, y = pivot.affine_to_linear(L, y, n)
+    assert bin(n + 1).count("1") == 1, \
+        "This implementation requires n+1 to be power of 2 (else, use padding with zeros)."
+    order = gf.order
+    device_mode = _on_device(x, L.coeffs) or isinstance(r, ScalarVector)
+
+    if r is None:
+        r = list(prng.randrange(order) for i in range(n))
+    if rho is None:
+        rho = prng.randrange(order)
+    if device_mode:
+        x = pivot._as_device(x)
+        r = pivot._as_device(r)
+        L = pivot.AffineForm(_coeffs_dev(L), L.constant)
+    gv = pivot._points_on_device(g)
+
+    logger_cp.debug("Calculate t.")
+    t = L(r)
+    if device_mode and isinstance(t, int):
+        t = gf(t)
+    logger_cp.debug("Calculate A.")
+    A = pivot.vector_commitment(r, rho, gv, h)
+    proof["t"] = t
+    proof["A"] = A
+
+    gens_for_hash = {"g": g if isinstance(g, PointVector) or mode == "compact" else list(g),
+                     "h": generators["h"], "k": generators["k"]}
+    c0, c1, seed = _p5_challenges(mode, order, gens_for_hash, t, A, P, L, y)
+    logger_cp_hout.debug(f"After hash, hash=\n{c0}, {c1}")
+
+    if device_mode:
+        z = x.axpy(c0, r)
+    else:
+        z = [c0 * x_i + r[i] for i, x_i in enumerate(x)]
+    phi = gf(c0 * gamma + rho)
+    z_hat = z + [phi]
+    g_hat = gv + [h]
+    logger_cp.debug("Calculate Q.")
+    Q = _gmul(_gmul(A, _gpow(P, c0)), _gpow(k, int(c1 * (c0 * y + t))))
+    L_tilde = _extend_form(L, c1)
+    assert _same_residue(L(z) * c1, L_tilde(z_hat), order)
+
+    return protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof,
+                             transcript=_p5_setup(generators, k, Q, seed, mode, order))
+
+
+def protocol_5_verifier(generators, P, L, y, proof, gf, transcript=None):
+    """Compressed Sigma-protocol Pi_c, verifier (compressed_pivot.py:205-239)."""
+    mode = transcript or TRANSCRIPT
+    g, h, k = generators["g"], _pt(generators["h"]), _pt(generators["k"])
+    P = _pt(P)
+    order = gf.order
+    n = len(g)
+    L, y = pivot.affine_to_linear(L, y, n)
+    t = proof["t"]
+    A = _pt(proof["A"])
+    gens_for_hash = {"g": g if isinstance(g, PointVector) or mode == "compact" else list(g),
+                     "h": generators["h"], "k": generators["k"]}
+    c0, c1, seed = _p5_challenges(mode, order, gens_for_hash, t, A, P, L, y)
+    g_hat = pivot._points_on_device(g) + [h]
+    Q = _gmul(_gmul(A, _gpow(P, c0)), _gpow(k, int(c1 * (c0 * y + t))))
+    L_tilde = _extend_form(L, c1)
+    return protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof,
+                               transcript=_p5_setup(generators, k, Q, seed, mode, order))

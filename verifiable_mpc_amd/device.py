@@ -1,0 +1,290 @@
+"""Device-resident vectors of the AC20 hot path: generators (PointVector) and witness /
+linear-form coefficients (ScalarVector), plus the per-process GPU context.
+
+Layout in HBM:
+  PointVector.affine : n x 64 B   x||y, canonical          -> MSM / fold input
+  PointVector.proj   : n x 96 B   X||Y||Z, representative   -> transcript text, exact fold
+  ScalarVector.data  : n x 32 B   canonical residue mod l
+Slices are zero-copy views (pointer + offset), which is what the halving rounds of
+Protocol 4 use (verifiable_mpc/ac20/compressed_pivot.py:35-38).
+"""
+import os
+
+import numpy as np
+
+from . import _native
+from .groups import ORDER, Ed25519Point
+
+_CTX = None
+
+
+def get_context():
+    """One vmpc context per process, on LOCAL_RANK's GPU (one process per GPU)."""
+    global _CTX
+    if _CTX is None:
+        ndev, info = _native.backend_info()
+        if ndev < 1:
+            raise RuntimeError(f"no MI355X visible ({info}); the AC20 hot path has no CPU fallback")
+        dev = int(os.environ.get("LOCAL_RANK", "0")) % ndev
+        _CTX = _native.Context(dev)
+    return _CTX
+
+
+def reset_context():
+    global _CTX
+    if _CTX is not None:
+        _CTX.close()
+    _CTX = None
+
+
+def reduce_scalar(v):
+    """Canonical residue of an int / field element (negative and oversized ints allowed:
+    every base has order l, SURVEY.md hard part 5)."""
+    return int(v) % ORDER
+
+
+class _View:
+    """(buffer, element offset, length) with a fixed element stride."""
+    __slots__ = ("buf", "off", "n", "stride")
+
+    def __init__(self, buf, off, n, stride):
+        self.buf, self.off, self.n, self.stride = buf, off, n, stride
+
+    @property
+    def ptr(self):
+        return self.buf.ptr + self.off * self.stride
+
+    def sub(self, a, b):
+        return _View(self.buf, self.off + a, b - a, self.stride)
+
+
+def _slice_bounds(key, n):
+    a, b, step = key.indices(n)
+    if step != 1:
+        raise ValueError("device vectors only support contiguous slices")
+    return a, max(a, b)
+
+
+class ScalarVector:
+    """n scalars mod l on the device."""
+
+    def __init__(self, view, ctx=None):
+        self.ctx = ctx or get_context()
+        self.v = view
+
+    @classmethod
+    def from_ints(cls, values, ctx=None):
+        ctx = ctx or get_context()
+        arr = _native.ints_to_array([reduce_scalar(v) for v in values], 32)
+        return cls(_View(ctx.upload(arr), 0, len(values), 32), ctx)
+
+    @classmethod
+    def from_array(cls, arr, ctx=None):
+        """(n, 32) uint8 canonical little-endian residues."""
+        ctx = ctx or get_context()
+        arr = _native.as_bytes_array(arr, 32)
+        return cls(_View(ctx.upload(arr), 0, len(arr), 32), ctx)
+
+    @classmethod
+    def empty(cls, n, ctx=None):
+        ctx = ctx or get_context()
+        return cls(_View(ctx.alloc(max(1, 32 * n)), 0, n, 32), ctx)
+
+    def __len__(self):
+        return self.v.n
+
+    @property
+    def ptr(self):
+        return self.v.ptr
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            a, b = _slice_bounds(key, self.v.n)
+            return ScalarVector(self.v.sub(a, b), self.ctx)
+        if key < 0:
+            key += self.v.n
+        raw = self.ctx.download(self.v.ptr + 32 * key, 32)
+        return int.from_bytes(raw.tobytes(), "little")
+
+    def to_ints(self):
+        return _native.array_to_ints(self.ctx.download(self.v.ptr, 32 * self.v.n, (self.v.n, 32)))
+
+    def concat(self, values):
+        """self + [v, ...] as a new vector (z_hat = z + [phi], compressed_pivot.py:136)."""
+        extra = _native.ints_to_array([reduce_scalar(v) for v in values], 32)
+        out = ScalarVector.empty(self.v.n + len(values), self.ctx)
+        self.ctx.copy(out.ptr, self.ptr, 32 * self.v.n)
+        self.ctx.upload_into(out.ptr + 32 * self.v.n, extra)
+        return out
+
+    def __add__(self, other):
+        if isinstance(other, (list, tuple)):
+            return self.concat(other)
+        return NotImplemented
+
+    # ---- arithmetic (csrc/frvec.hip) ------------------------------------------------------
+    def axpy(self, c, y):
+        """c * self + y  (element-wise, mod l)."""
+        assert len(y) == len(self)
+        out = ScalarVector.empty(len(self), self.ctx)
+        self.ctx.fr_axpy(reduce_scalar(c), self.ptr, y.ptr, len(self), out.ptr)
+        return out
+
+    def scale(self, c):
+        out = ScalarVector.empty(len(self), self.ctx)
+        self.ctx.fr_scale(reduce_scalar(c), self.ptr, len(self), out.ptr)
+        return out
+
+    def dot(self, other):
+        assert len(other) == len(self)
+        return self.ctx.fr_dot(self.ptr, other.ptr, len(self))
+
+    def text(self, is_signed=True):
+        """b'v0, v1, ..., ' as produced on the device (uint8 array)."""
+        return self.ctx.format_scalars(self.ptr, len(self), is_signed)
+
+    def __repr__(self):
+        body = self.text().tobytes().decode()
+        return "[" + body[:-2] + "]"
+
+
+class PointVector:
+    """n Ed25519 points on the device, affine always, projective representatives when the
+    reference transcript needs them (`keep_proj`)."""
+
+    def __init__(self, affine_view, proj_view=None, ctx=None):
+        self.ctx = ctx or get_context()
+        self.a = affine_view
+        self.p = proj_view
+        self._digest = None
+
+    # ---- construction ----------------------------------------------------------------------
+    @classmethod
+    def from_points(cls, points, ctx=None, keep_proj=True):
+        """From host Ed25519Point objects (representatives preserved)."""
+        ctx = ctx or get_context()
+        n = len(points)
+        proj = np.frombuffer(b"".join(p.to_proj_bytes() for p in points), dtype=np.uint8)
+        pbuf = ctx.upload(proj.reshape(n, 96) if n else np.zeros((0, 96), np.uint8))
+        abuf = ctx.alloc(max(1, 64 * n))
+        ctx.normalize(pbuf.ptr, n, abuf.ptr)
+        return cls(_View(abuf, 0, n, 64), _View(pbuf, 0, n, 96) if keep_proj else None, ctx)
+
+    @classmethod
+    def from_affine_array(cls, arr, ctx=None, keep_proj=False, validate=True):
+        """(n, 64) uint8 x||y canonical little-endian."""
+        ctx = ctx or get_context()
+        arr = _native.as_bytes_array(arr, 64)
+        n = len(arr)
+        abuf = ctx.upload(arr)
+        if validate and ctx.validate_points(abuf.ptr, n):
+            raise _native.VmpcError(_native.E_NOTONCURVE, "PointVector.from_affine_array")
+        pv = None
+        if keep_proj:
+            pbuf = ctx.alloc(max(1, 96 * n))
+            ctx.affine_to_proj(abuf.ptr, n, pbuf.ptr)
+            pv = _View(pbuf, 0, n, 96)
+        return cls(_View(abuf, 0, n, 64), pv, ctx)
+
+    @classmethod
+    def fixed_base(cls, base, exponents, ctx=None, keep_proj=True):
+        """[base ** r for r in exponents] (circuit_sat_r1cs.py:64-70) on the device;
+        `exponents` is a ScalarVector or a list of ints."""
+        ctx = ctx or get_context()
+        if not isinstance(exponents, ScalarVector):
+            exponents = ScalarVector.from_ints(exponents, ctx)
+        n = len(exponents)
+        bbuf = ctx.upload(np.frombuffer(base.to_proj_bytes(), dtype=np.uint8))
+        abuf = ctx.alloc(max(1, 64 * n))
+        pbuf = ctx.alloc(max(1, 96 * n)) if keep_proj else None
+        ctx.repeat(bbuf.ptr, 1, False, exponents.ptr, n, False, pbuf.ptr if pbuf else None, abuf.ptr)
+        ctx.sync()
+        return cls(_View(abuf, 0, n, 64), _View(pbuf, 0, n, 96) if keep_proj else None, ctx)
+
+    # ---- list protocol ----------------------------------------------------------------------
+    def __len__(self):
+        return self.a.n
+
+    @property
+    def affine_ptr(self):
+        return self.a.ptr
+
+    @property
+    def proj_ptr(self):
+        return self.p.ptr if self.p is not None else None
+
+    @property
+    def has_proj(self):
+        return self.p is not None
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            a, b = _slice_bounds(key, self.a.n)
+            return PointVector(self.a.sub(a, b), self.p.sub(a, b) if self.p is not None else None,
+                               self.ctx)
+        if key < 0:
+            key += self.a.n
+        if self.p is not None:
+            return Ed25519Point.from_proj_bytes(self.ctx.download(self.p.ptr + 96 * key, 96).tobytes())
+        return Ed25519Point.from_affine_bytes(self.ctx.download(self.a.ptr + 64 * key, 64).tobytes())
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def to_points(self):
+        n = len(self)
+        if self.p is not None:
+            raw = self.ctx.download(self.p.ptr, 96 * n).tobytes()
+            return [Ed25519Point.from_proj_bytes(raw[96 * i:96 * i + 96]) for i in range(n)]
+        raw = self.ctx.download(self.a.ptr, 64 * n).tobytes()
+        return [Ed25519Point.from_affine_bytes(raw[64 * i:64 * i + 64]) for i in range(n)]
+
+    def affine_array(self):
+        return self.ctx.download(self.a.ptr, 64 * len(self), (len(self), 64))
+
+    def concat(self, points):
+        """self + [pt, ...] as a new vector (g_hat = g + [h], compressed_pivot.py:138)."""
+        n, m = len(self), len(points)
+        abuf = self.ctx.alloc(64 * (n + m))
+        self.ctx.copy(abuf.ptr, self.a.ptr, 64 * n)
+        self.ctx.upload_into(abuf.ptr + 64 * n,
+                             np.frombuffer(b"".join(p.to_affine_bytes() for p in points), np.uint8))
+        pv = None
+        if self.p is not None:
+            pbuf = self.ctx.alloc(96 * (n + m))
+            self.ctx.copy(pbuf.ptr, self.p.ptr, 96 * n)
+            self.ctx.upload_into(pbuf.ptr + 96 * n,
+                                 np.frombuffer(b"".join(p.to_proj_bytes() for p in points), np.uint8))
+            pv = _View(pbuf, 0, n + m, 96)
+        return PointVector(_View(abuf, 0, n + m, 64), pv, self.ctx)
+
+    def __add__(self, other):
+        if isinstance(other, (list, tuple)):
+            return self.concat(list(other))
+        return NotImplemented
+
+    # ---- kernels -------------------------------------------------------------------------------
+    def fold(self, other, c, keep_proj=None):
+        """[(self[i] ** c) * other[i]] (compressed_pivot.py:64/:178), csrc/exact.hip k_fold."""
+        assert len(self) == len(other)
+        half = len(self)
+        if keep_proj is None:
+            keep_proj = self.p is not None
+        abuf = self.ctx.alloc(max(1, 64 * half))
+        pbuf = self.ctx.alloc(max(1, 96 * half)) if keep_proj else None
+        use_proj = self.p is not None and other.p is not None
+        self.ctx.fold(self.p.ptr if use_proj else self.a.ptr, other.p.ptr if use_proj else other.a.ptr,
+                      not use_proj, reduce_scalar(c), half, pbuf.ptr if pbuf else None, abuf.ptr)
+        return PointVector(_View(abuf, 0, half, 64), _View(pbuf, 0, half, 96) if pbuf else None,
+                           self.ctx)
+
+    def text(self):
+        """b'[X, Y, Z], [X, Y, Z], ..., ' (uint8 array) for the Fiat-Shamir pre-image."""
+        if self.p is None:
+            raise ValueError("projective representatives were not kept for this vector")
+        return self.ctx.format_points(self.p.ptr, len(self))
+
+    def __repr__(self):
+        body = self.text().tobytes().decode()
+        return "[" + body[:-2] + "]"

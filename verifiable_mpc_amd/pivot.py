@@ -1,0 +1,310 @@
+"""Drop-in counterpart of verifiable_mpc/ac20/pivot.py (AC20 Protocol 2 and the
+Pedersen vector commitment) with the group work on MI355X.
+
+Same names, positional arguments, return shapes and error behaviour as the reference:
+    list_mul              pivot.py:26-28
+    AffineForm/LinearForm pivot.py:31-116
+    _int                  pivot.py:119-128
+    fiat_shamir_hash      pivot.py:131-136
+    vector_commitment     pivot.py:139-145
+    affine_to_linear      pivot.py:148-153
+    prove_linear_form_eval / verify_linear_form_proof   pivot.py:156-205
+
+Inputs may be the reference's Python lists (scalars stay Python objects and keep the
+reference's typing semantics, points are sent to the GPU per call) or the device-resident
+vectors of verifiable_mpc_amd.device (everything stays in HBM).
+"""
+import hashlib
+import logging
+from random import SystemRandom
+
+from .device import PointVector, ScalarVector, get_context, reduce_scalar
+from .fields import FiniteFieldElement
+from .groups import EllipticCurvePoint as EllipticCurveElement
+from .groups import Ed25519Point
+
+prng = SystemRandom()
+
+logger_piv = logging.getLogger("pivot")
+logger_piv.setLevel(logging.INFO)
+
+
+class SecureObject:
+    """Placeholder for mpyc.sectypes.SecureObject (pivot.py:17): secret-shared values are
+    the MPyC driver's business and never reach this module."""
+
+
+def list_mul(x):
+    """Product of a list of group elements in the reference's tree order (pivot.py:26-28)."""
+    if isinstance(x, PointVector):
+        if not x.has_proj:
+            raise ValueError("list_mul needs projective representatives")
+        ctx = x.ctx
+        out = ctx.alloc(96)
+        ctx.tree_reduce(x.proj_ptr, len(x), True, out.ptr)
+        return Ed25519Point.from_proj_bytes(ctx.download(out.ptr, 96).tobytes())
+    return list_mul(PointVector.from_points(list(x)))
+
+
+def _is_number(v):
+    return isinstance(v, (int, FiniteFieldElement, SecureObject)) or _duck_field(v)
+
+
+def _duck_field(v):
+    # foreign field elements (e.g. real MPyC GF elements) quack like ours
+    return hasattr(v, "value") and hasattr(type(v), "modulus") and not isinstance(v, EllipticCurveElement)
+
+
+class AffineForm:
+    """Dense affine form over the scalar field (pivot.py:31-95).  `coeffs` is a Python list
+    (reference semantics, element types preserved) or a device ScalarVector."""
+
+    def __init__(self, coeffs, constant):
+        self.coeffs = coeffs
+        self.constant = constant
+
+    def _result_type(self):
+        return type(self)
+
+    def __add__(self, other):
+        if isinstance(other, AffineForm):
+            assert len(self) == len(other), "Length of linear forms to add not consistent."
+            if isinstance(self.coeffs, ScalarVector) or isinstance(other.coeffs, ScalarVector):
+                a, b = _as_device(self.coeffs), _as_device(other.coeffs)
+                new_coeffs = a.axpy(1, b)
+            else:
+                new_coeffs = [self.coeffs[i] + other.coeffs[i] for i in range(len(self))]
+            new_constant = self.constant + other.constant
+        elif _is_number(other):
+            new_coeffs = self.coeffs
+            new_constant = self.constant + other
+        else:
+            raise NotImplementedError(f"Addition of form not defined for type: {type(other)}")
+        return self._sum_type()(new_coeffs, new_constant)
+
+    def _sum_type(self):
+        return type(self)
+
+    def __radd__(self, other):
+        if isinstance(other, int) and other == 0:
+            return self
+        return self.__add__(other)
+
+    def __sub__(self, other):
+        return self + (-1) * other
+
+    def __mul__(self, other):
+        if isinstance(other, (int, FiniteFieldElement)) or _duck_field(other):
+            if isinstance(self.coeffs, ScalarVector):
+                new_coeffs = self.coeffs.scale(other)
+            else:
+                new_coeffs = [coeffs_i * other for coeffs_i in self.coeffs]
+            new_constant = self.constant * other
+        else:
+            raise NotImplementedError(f"Multiplication of form not defined for type: {type(other)}")
+        return type(self)(new_coeffs, new_constant)
+
+    def __rmul__(self, other):
+        return self * other
+
+    def __len__(self):
+        return len(self.coeffs)
+
+    def __eq__(self, other):
+        a, b = self.coeffs, other.coeffs
+        if isinstance(a, ScalarVector):
+            a = a.to_ints()
+        if isinstance(b, ScalarVector):
+            b = b.to_ints()
+        return a == b
+
+    def __repr__(self):
+        return f"{str(self.coeffs)}, {str(self.constant)}"
+
+    def eval(self, values):
+        assert len(values) == len(self.coeffs), \
+            "Length of inputs to be equal to coefficients of linear form."
+        if isinstance(self.coeffs, ScalarVector) or isinstance(values, ScalarVector):
+            dot = _as_device(self.coeffs).dot(_as_device(values))
+            gf = _field_of(self.constant)
+            return (gf(dot) if gf else dot) + self.constant
+        return sum([self.coeffs[i] * values_i for i, values_i in enumerate(values)]) + self.constant
+
+    def __call__(self, values):
+        return self.eval(values)
+
+
+class LinearForm(AffineForm):
+    """pivot.py:98-116: constant forced to 0; sums of linear forms are AffineForms."""
+
+    def __init__(self, coeffs, constant=0):
+        self.coeffs = coeffs
+        self.constant = 0
+
+    def _sum_type(self):
+        return AffineForm
+
+
+def _as_device(v):
+    return v if isinstance(v, ScalarVector) else ScalarVector.from_ints([_residue(c) for c in v])
+
+
+def _residue(v):
+    return reduce_scalar(v.value if _duck_field(v) and not isinstance(v, FiniteFieldElement) else v)
+
+
+def _field_of(v):
+    return type(v) if isinstance(v, FiniteFieldElement) or _duck_field(v) else None
+
+
+def _int(value):
+    """pivot.py:119-128."""
+    if isinstance(value, (int, SecureObject)):
+        return value
+    elif isinstance(value, FiniteFieldElement) or _duck_field(value):
+        return int(value)
+    else:
+        raise NotImplementedError
+
+
+# ---- Fiat-Shamir ---------------------------------------------------------------------------------
+
+def _feed(h, obj):
+    """Stream str(obj) into the hash without materialising it: byte-identical to
+    str(input_list).encode('utf-8') for the object kinds on the AC20 path; device vectors
+    contribute text formatted by csrc/format.hip."""
+    if isinstance(obj, PointVector):
+        h.update(b"[")
+        if len(obj):
+            h.update(memoryview(obj.text())[:-2])
+        h.update(b"]")
+    elif isinstance(obj, ScalarVector):
+        h.update(b"[")
+        if len(obj):
+            h.update(memoryview(obj.text())[:-2])
+        h.update(b"]")
+    elif isinstance(obj, AffineForm):
+        _feed(h, obj.coeffs)
+        h.update(b", ")
+        _feed(h, obj.constant)
+    elif isinstance(obj, list):
+        h.update(b"[")
+        for i, item in enumerate(obj):
+            if i:
+                h.update(b", ")
+            _feed(h, item)
+        h.update(b"]")
+    elif isinstance(obj, dict):
+        h.update(b"{")
+        for i, (k, v) in enumerate(obj.items()):
+            if i:
+                h.update(b", ")
+            h.update(repr(k).encode("utf-8") + b": ")
+            _feed(h, v)
+        h.update(b"}")
+    else:
+        h.update(repr(obj).encode("utf-8"))
+
+
+def fiat_shamir_hash(input_list, order):
+    """pivot.py:131-136: int.from_bytes(sha256(str(input_list)), 'little') % order."""
+    h = hashlib.sha256()
+    _feed(h, input_list)
+    return int.from_bytes(h.digest(), "little") % order
+
+
+# ---- Pedersen vector commitment ----------------------------------------------------------------
+
+def _points_on_device(g):
+    return g if isinstance(g, PointVector) else PointVector.from_points(list(g))
+
+
+def _scalars_on_device(x):
+    if isinstance(x, ScalarVector):
+        return x
+    return ScalarVector.from_ints([_residue(_int(x_i)) for x_i in x])
+
+
+def vector_commitment(x, gamma, g, h, exact_representative=False):
+    """Pedersen vector commitment, Definition 1 of AC20 (pivot.py:139-145):
+    h^gamma * prod_i g_i^{x_i}, as one (len(x)+1)-term Pippenger MSM on the GPU.
+
+    The returned element is affine-normalised (Z = 1).  With exact_representative=True the
+    reference's per-term `**` and reduce tree are replayed on the device instead, giving the
+    same un-normalised (X:Y:Z) the reference would hold (needed only if the caller hashes the
+    commitment without normalising it, e.g. circuit_sat_cb.py:107)."""
+    assert len(g) >= len(x), "Not enough generators."
+    n = len(x)
+    gv = _points_on_device(g)
+    xs = _scalars_on_device(x)
+    ctx = gv.ctx
+    if exact_representative:
+        if not gv.has_proj:
+            raise ValueError("exact_representative needs projective generators")
+        terms = ctx.alloc(max(1, 96 * n))
+        signed = not isinstance(x, ScalarVector) and any(not isinstance(v, int) for v in x)
+        ctx.repeat(gv.proj_ptr, n, False, xs.ptr, n, signed, terms.ptr, None)
+        out = ctx.alloc(96)
+        ctx.tree_reduce(terms.ptr, n, True, out.ptr)
+        prod = Ed25519Point.from_proj_bytes(ctx.download(out.ptr, 96).tobytes())
+        return Ed25519Point.operation(Ed25519Point.repeat(h, _int(gamma)), prod)
+    import numpy as np
+    gam = ctx.upload(np.frombuffer(reduce_scalar(_int(gamma)).to_bytes(32, "little"), np.uint8))
+    hb = ctx.upload(np.frombuffer(h.to_affine_bytes(), np.uint8))
+    out = ctx.alloc(64)
+    ctx.msm(xs.ptr, gv.affine_ptr, n, gam.ptr, hb.ptr, 1, None, out.ptr)
+    ctx.sync()
+    return Ed25519Point.from_affine_bytes(ctx.download(out.ptr, 64).tobytes())
+
+
+def affine_to_linear(L, y, n):
+    """pivot.py:148-153."""
+    if isinstance(L.coeffs, ScalarVector):
+        constant = L.constant          # L(zeros) == constant
+    else:
+        zeros = [0] * n
+        constant = L(zeros)
+    L_linear = L - constant
+    y_linear = y - constant
+    return L_linear, y_linear
+
+
+def prove_linear_form_eval(g, h, P, L, y, x, gamma, gf):
+    """Sigma protocol Pi_s (Protocol 2 of AC20), non-interactive (pivot.py:156-181)."""
+    n = len(x)
+    L, y = affine_to_linear(L, y, n)
+    r = list(gf(prng.randrange(gf.order)) for i in range(n))
+    rho = prng.randrange(gf.order)
+    t = L(r)
+    A = vector_commitment(r, rho, g, h)
+    logger_piv.debug(f"Prover computed A={A}.")
+
+    if isinstance(A, EllipticCurveElement):
+        input_list = [t, A.normalize(), g, h, P.normalize(), L, y]
+    else:
+        input_list = [t, A, g, h, P, L, y]
+
+    c = fiat_shamir_hash(input_list, gf.order)
+    z = [c * x_i + r[i] for i, x_i in enumerate(x)]
+    phi = (c * gamma + rho) % gf.order
+    return z, phi, c
+
+
+def verify_linear_form_proof(g, h, P, L, y, z, phi, c):
+    """pivot.py:184-205."""
+    n = len(z)
+    L, y = affine_to_linear(L, y, n)
+    A_check = vector_commitment(z, phi, g, h) * ((P ** c) ** (-1))
+    t_check = L(z) - c * y
+    logger_piv.debug(f"Verifier computed A_check={A_check}.")
+    logger_piv.debug(f"Verifier computed t_check={t_check}.")
+    order = type(t_check).order
+
+    if isinstance(A_check, EllipticCurveElement):
+        input_list = [t_check, A_check.normalize(), g, h, P.normalize(), L, y]
+    else:
+        input_list = [t_check, A_check, g, h, P, L, y]
+
+    logger_piv.debug(f"Method verify_linear_form_proof: input_list={input_list}.")
+    hash_check = fiat_shamir_hash(input_list, order)
+    return bool(c == hash_check)
