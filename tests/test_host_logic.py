@@ -1,0 +1,107 @@
+"""CPU tests of the host-side mirror of the reference interface (no kernels involved):
+forms, field/group glue, the streaming Fiat-Shamir hash, install()."""
+import random
+
+import pytest
+
+from oracle import ac20_ref as ac
+from oracle import ed25519_ref as ed
+
+import verifiable_mpc_amd as vm
+from verifiable_mpc_amd import pivot
+
+
+def test_linear_form_known_answers():
+    # the reference's own known answers: ac20/test/test_pivot.py:84-90
+    lf = pivot.LinearForm([0, 1, 2])
+    assert (lf + lf + 2 * lf + lf.eval([1, 1, 1]) - lf).eval([1, 2, 3]) == 27
+    assert lf([1, 2, 3]) == 8
+    assert isinstance(lf + lf, pivot.AffineForm) and not isinstance(lf + lf, pivot.LinearForm)
+    assert repr(pivot.AffineForm([1, 2], 5)) == "[1, 2], 5"
+    assert pivot.LinearForm([1, 2], 9).constant == 0
+    with pytest.raises(AssertionError):
+        lf([1, 2])
+    assert sum([lf, lf]) == lf * 2
+
+
+def test_field_elements_follow_signed_repr():
+    gf = vm.GF(ed.ELL)
+    a = gf(ed.ELL - 5)
+    assert repr(a) == "-5" and int(a) == -5 and a.value == ed.ELL - 5
+    assert repr(gf(7) * 3 + 1) == "22" and (gf(1) / gf(3)) * 3 == 1 and gf(2) ** -1 == gf(1) / 2
+    assert ed.scalar_repr(ed.ELL - 5) == repr(a)
+    assert pivot._int(a) == -5 and pivot._int(9) == 9
+
+
+def test_host_point_matches_oracle_representatives():
+    rng = random.Random(1)
+    G = vm.Ed25519Point.generator
+    for _ in range(5):
+        a, b = rng.randrange(ed.ELL), rng.randrange(ed.ELL)
+        pa, pb = vm.Ed25519Point.repeat(G, a), vm.Ed25519Point.repeat(G, -b)
+        assert pa.coords == ed.pt_repeat(ed.BASE, a) and pb.coords == ed.pt_repeat(ed.BASE, -b)
+        s = vm.Ed25519Point.operation(pa, pb)
+        assert s.coords == ed.pt_add(pa.coords, pb.coords)
+        assert repr(s) == ed.pt_repr(s.coords)
+        assert s.normalize().coords == ed.pt_normalize(s.coords)
+        assert s == s.normalize() and hash(s) == hash(s.normalize())
+    assert vm.Ed25519Point.from_affine_bytes(pa.to_affine_bytes()) == pa
+    assert vm.Ed25519Point.from_proj_bytes(pa.to_proj_bytes()).coords == pa.coords
+    with pytest.raises(ValueError):
+        vm.Ed25519Point((1, 2, 1), check=True)
+
+
+def test_operator_flags_like_mpyc(monkeypatch):
+    G = vm.Ed25519Point.generator
+    assert (G + G) == vm.Ed25519Point.repeat(G, 2) and (3 * G) == vm.Ed25519Point.repeat(G, 3)
+    monkeypatch.setattr(vm.Ed25519Point, "is_multiplicative", True)
+    monkeypatch.setattr(vm.Ed25519Point, "is_additive", False)
+    assert (G * G) == G ** 2 and (G ** -1) * G == vm.Ed25519Point.identity
+
+
+def test_streaming_hash_equals_str_of_list():
+    gf = vm.GF(ed.ELL)
+    G = vm.Ed25519Point.generator
+    pts = [vm.Ed25519Point.repeat(G, i + 2) for i in range(3)]
+    form = pivot.AffineForm([gf(3), 10**80, gf(-1)], gf(0))
+    lst = [gf(-7), pts[0].normalize(), {"g": pts, "h": G, "k": pts[1]}, form, 0, 1,
+           "First hash of compressed pivot", [], [[1, 2], []]]
+    want = ac.fiat_shamir_hash_text(str(lst), ed.ELL)
+    assert pivot.fiat_shamir_hash(lst, ed.ELL) == want
+
+
+def test_install_patches_reference_modules(monkeypatch):
+    import sys
+    import types
+    pkg = "fake_ref_pkg"
+    mods = {}
+    for name in ("", ".pivot", ".compressed_pivot", ".circuit_sat_r1cs", ".circuit_sat_cb"):
+        m = types.ModuleType(pkg + name)
+        mods[pkg + name] = m
+        monkeypatch.setitem(sys.modules, pkg + name, m)
+    patched = vm.install(pkg)
+    assert mods[pkg + ".pivot"].vector_commitment is pivot.vector_commitment
+    assert mods[pkg + ".compressed_pivot"].protocol_5_prover is vm.compressed_pivot.protocol_5_prover
+    assert mods[pkg + ".circuit_sat_r1cs"].create_generators is vm.circuit_sat.create_generators
+    assert len(patched) == 8
+
+
+def test_product_never_imports_the_oracle():
+    import os
+    root = os.path.dirname(os.path.abspath(vm.__file__))
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_missing_gpu_fails_loudly():
+    n, _ = vm._native.backend_info()
+    if n >= 1:
+        pytest.skip("GPU present")
+    vm.device.reset_context()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        vm.get_context()
+    with pytest.raises(RuntimeError):
+        pivot.vector_commitment([1], 1, [vm.Ed25519Point.generator], vm.Ed25519Point.generator)

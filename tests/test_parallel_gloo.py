@@ -1,0 +1,91 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU commitment's host logic: cyclic sharding,
+the single all-gather of 128-byte partial points, rank-ordered combine.  The oracle stands in
+for the two device routines (local MSM, ordered point sum)."""
+import os
+import random
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ed25519_ref as ed  # noqa: E402
+
+
+def ext_bytes(pt):
+    """(X:Y:Z) -> 128-byte extended encoding X||Y||Z||T with T = XY/Z scaled: use Z' = Z^2."""
+    x, y, z = pt
+    X, Y, Z, T = x * z % ed.P, y * z % ed.P, z * z % ed.P, x * y % ed.P
+    return b"".join(v.to_bytes(32, "little") for v in (X, Y, Z, T))
+
+
+class OracleBackend:
+    def partial(self, scalars, points):
+        acc = ed.IDENTITY
+        for s, p in zip(scalars, points):
+            acc = ed.pt_add(acc, ed.pt_repeat(p, s))
+        return torch.frombuffer(bytearray(ext_bytes(acc)), dtype=torch.uint8)
+
+    def commit_single(self, scalars, points):
+        raise AssertionError("not used")
+
+    def new_gather_buffer(self, world):
+        return torch.zeros((world, 128), dtype=torch.uint8)
+
+    def combine(self, gathered, world):
+        acc = ed.IDENTITY
+        raw = gathered.numpy().tobytes()
+        for r in range(world):          # rank order
+            X, Y, Z = (int.from_bytes(raw[128 * r + 32 * i:128 * r + 32 * i + 32], "little") for i in range(3))
+            acc = ed.pt_add(acc, (X, Y, Z))
+        return ed.pt_affine(acc)
+
+
+def worker(rank, world, port, n, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from verifiable_mpc_amd import parallel
+    rng = random.Random(42)                     # same global inputs on every rank
+    exps = [rng.randrange(1, ed.ELL) for _ in range(n)]
+    pts = [ed.pt_repeat(ed.BASE, e) for e in exps]
+    sc = [rng.randrange(ed.ELL) for _ in range(n)]
+    idx = parallel.cyclic_indices(n, world, rank)
+    sh = parallel.ShardedMsm(None, world, rank, dist, torch, backend=OracleBackend())
+    got = sh.commit([sc[i] for i in idx], [pts[i] for i in idx])
+    want = ed.pt_affine(ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(sc, exps)) % ed.ELL))
+    ret[rank] = (got == want, list(idx[:3]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_commit_world2():
+    world, n = 2, 11                           # ragged: shards of 6 and 5 terms
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(worker, args=(world, free_port(), n, ret), nprocs=world, join=True)
+    assert ret[0][0] and ret[1][0]
+    assert ret[0][1] == [0, 2, 4] and ret[1][1] == [1, 3, 5]
+
+
+def test_cyclic_sharding_helpers():
+    from verifiable_mpc_amd import parallel
+    a = np.arange(10 * 4).reshape(10, 4)
+    parts = [parallel.shard_rows(a, 4, r) for r in range(4)]
+    assert sum(len(p) for p in parts) == 10
+    assert [list(parallel.cyclic_indices(10, 4, r)) for r in range(4)] == [[0, 4, 8], [1, 5, 9], [2, 6], [3, 7]]
+    assert (parts[1] == a[[1, 5, 9]]).all()
