@@ -259,6 +259,80 @@ k_msm_reduce(const uint32_t *__restrict__ buckets, int nb, int chunks, int chunk
 }
 
 // ---- final: window sums, Horner, normalise -----------------------------------------------
+// The Horner recombination  acc = sum_w 2^(c*w) R_w  is a chain of ~253 dependent point
+// doublings: pure latency.  Each doubling / addition has two levels of four independent
+// field multiplications, so a QUAD of lanes computes one point operation: lane q of the quad
+// does the q-th product of each level and the four results are exchanged with DPP quad_perm
+// broadcasts (VALU, no LDS).  Per point operation the critical path is 2 field
+// multiplications instead of 8-9.
+__device__ __forceinline__ fe quad_bcast(const fe &a, int src /*0..3, compile-time after unroll*/) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int v = (int)a.v[i];
+        int o;
+        switch (src) {
+            case 0: o = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true); break;
+            case 1: o = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true); break;
+            case 2: o = __builtin_amdgcn_mov_dpp(v, 0xaa, 0xf, 0xf, true); break;
+            default: o = __builtin_amdgcn_mov_dpp(v, 0xff, 0xf, 0xf, true); break;
+        }
+        r.v[i] = (uint32_t)o;
+    }
+    return r;
+}
+
+__device__ __forceinline__ fe fe_pick4(const fe &a0, const fe &a1, const fe &a2, const fe &a3, int q) {
+    // branch-free: lanes of a quad take different operands in the same instruction stream
+    const uint32_t m0 = 0u - (uint32_t)(q == 0), m1 = 0u - (uint32_t)(q == 1);
+    const uint32_t m2 = 0u - (uint32_t)(q == 2), m3 = 0u - (uint32_t)(q == 3);
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        r.v[i] = (a0.v[i] & m0) | (a1.v[i] & m1) | (a2.v[i] & m2) | (a3.v[i] & m3);
+    return r;
+}
+
+// second level shared by doubling and addition: X3 = E*F, Y3 = G*H, Z3 = F*G, T3 = E*H
+__device__ __forceinline__ void quad_level2(ge_ext &p, const fe &E, const fe &F, const fe &G,
+                                            const fe &H, int q) {
+    fe u = fe_pick4(E, G, F, E, q);
+    fe v = fe_pick4(F, H, G, H, q);
+    fe prod = fe_mul(u, v);
+    p.X = quad_bcast(prod, 0);
+    p.Y = quad_bcast(prod, 1);
+    p.Z = quad_bcast(prod, 2);
+    p.T = quad_bcast(prod, 3);
+}
+
+__device__ __forceinline__ void quad_dbl(ge_ext &p, int q) {
+    fe in = fe_pick4(p.X, p.Y, p.Z, fe_add(p.X, p.Y), q);
+    fe sq = fe_sqr(in);
+    sq = fe_select(sq, fe_dbl(sq), q == 2);           // lane 2 holds C = 2 Z^2
+    fe A = quad_bcast(sq, 0), B = quad_bcast(sq, 1), C = quad_bcast(sq, 2), S = quad_bcast(sq, 3);
+    fe H = fe_add(A, B);
+    fe E = fe_sub(H, S);
+    fe G = fe_sub(A, B);
+    fe F = fe_add(C, G);
+    quad_level2(p, E, F, G, H, q);
+}
+
+// p += r where r is given in cached form (Y+X, Y-X, 2d*T, 2*Z)
+struct ge_cached {
+    fe ypx, ymx, t2d, z2;
+};
+__device__ __forceinline__ void quad_add_cached(ge_ext &p, const ge_cached &r, int q) {
+    fe u = fe_pick4(fe_sub(p.Y, p.X), fe_add(p.Y, p.X), p.T, p.Z, q);
+    fe v = fe_pick4(r.ymx, r.ypx, r.t2d, r.z2, q);
+    fe prod = fe_mul(u, v);
+    fe A = quad_bcast(prod, 0), B = quad_bcast(prod, 1), C = quad_bcast(prod, 2), D = quad_bcast(prod, 3);
+    fe E = fe_sub(B, A);
+    fe F = fe_sub(D, C);
+    fe G = fe_add(D, C);
+    fe H = fe_add(B, A);
+    quad_level2(p, E, F, G, H, q);
+}
+
 __global__ void __launch_bounds__(64)
 k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
             uint32_t *__restrict__ out_ext, uint32_t *__restrict__ out_aff) {
@@ -268,15 +342,27 @@ k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
         ge_ext r = ext_ld(partials + 32 * ((size_t)w * red_blocks));
         for (int j = 1; j < red_blocks; j++)
             r = ge_add(r, ext_ld(partials + 32 * ((size_t)w * red_blocks + j)));
-        ext_st(lds + 32 * w, r);
+        // store in cached form for the cooperative additions below
+        fe_st(lds + 32 * w, fe_add(r.Y, r.X));
+        fe_st(lds + 32 * w + 8, fe_sub(r.Y, r.X));
+        fe_st(lds + 32 * w + 16, fe_mul(r.T, fe_const_d2()));
+        fe_st(lds + 32 * w + 24, fe_dbl(r.Z));
     }
     __syncthreads();
+    // every quad of the wave runs the same chain redundantly (keeps EXEC full for DPP)
+    const int q = threadIdx.x & 3;
+    ge_ext acc = ge_ext_identity();
+    for (int k = W - 1; k >= 0; k--) {
+        if (k != W - 1)
+            for (int j = 0; j < c; j++) quad_dbl(acc, q);
+        ge_cached r;
+        r.ypx = fe_ld(lds + 32 * k);
+        r.ymx = fe_ld(lds + 32 * k + 8);
+        r.t2d = fe_ld(lds + 32 * k + 16);
+        r.z2 = fe_ld(lds + 32 * k + 24);
+        quad_add_cached(acc, r, q);
+    }
     if (threadIdx.x == 0) {
-        ge_ext acc = ext_ld(lds + 32 * (W - 1));
-        for (int k = W - 2; k >= 0; k--) {
-            for (int j = 0; j < c; j++) acc = ge_dbl(acc);
-            acc = ge_add(acc, ext_ld(lds + 32 * k));
-        }
         if (out_ext) ext_st(out_ext, acc);
         if (out_aff) {
             ge_aff a = ge_ext_to_affine(acc);

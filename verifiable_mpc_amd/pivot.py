@@ -56,90 +56,82 @@ def _duck_field(v):
 
 
 class AffineForm:
-    """Dense affine form over the scalar field (pivot.py:31-95).  `coeffs` is a Python list
-    (reference semantics, element types preserved) or a device ScalarVector."""
+    """Dense affine form sum_i coeffs[i] * x_i + constant over the scalar field
+    (pivot.py:31-95).  `coeffs` is either a Python list - element types are then kept exactly
+    as the caller supplied them, like the reference does - or a device ScalarVector."""
 
     def __init__(self, coeffs, constant):
-        self.coeffs = coeffs
-        self.constant = constant
+        self.coeffs, self.constant = coeffs, constant
 
-    def _result_type(self):
-        return type(self)
-
-    def __add__(self, other):
-        if isinstance(other, AffineForm):
-            assert len(self) == len(other), "Length of linear forms to add not consistent."
-            if isinstance(self.coeffs, ScalarVector) or isinstance(other.coeffs, ScalarVector):
-                a, b = _as_device(self.coeffs), _as_device(other.coeffs)
-                new_coeffs = a.axpy(1, b)
-            else:
-                new_coeffs = [self.coeffs[i] + other.coeffs[i] for i in range(len(self))]
-            new_constant = self.constant + other.constant
-        elif _is_number(other):
-            new_coeffs = self.coeffs
-            new_constant = self.constant + other
-        else:
-            raise NotImplementedError(f"Addition of form not defined for type: {type(other)}")
-        return self._sum_type()(new_coeffs, new_constant)
-
+    # which class a sum / shifted form has: the reference keeps type(self) for AffineForm and
+    # degrades LinearForm sums to AffineForm (pivot.py:49, :116)
     def _sum_type(self):
         return type(self)
 
-    def __radd__(self, other):
-        if isinstance(other, int) and other == 0:
-            return self
-        return self.__add__(other)
-
-    def __sub__(self, other):
-        return self + (-1) * other
-
-    def __mul__(self, other):
-        if isinstance(other, (int, FiniteFieldElement)) or _duck_field(other):
-            if isinstance(self.coeffs, ScalarVector):
-                new_coeffs = self.coeffs.scale(other)
-            else:
-                new_coeffs = [coeffs_i * other for coeffs_i in self.coeffs]
-            new_constant = self.constant * other
-        else:
-            raise NotImplementedError(f"Multiplication of form not defined for type: {type(other)}")
-        return type(self)(new_coeffs, new_constant)
-
-    def __rmul__(self, other):
-        return self * other
+    def _device(self):
+        return isinstance(self.coeffs, ScalarVector)
 
     def __len__(self):
         return len(self.coeffs)
 
-    def __eq__(self, other):
-        a, b = self.coeffs, other.coeffs
-        if isinstance(a, ScalarVector):
-            a = a.to_ints()
-        if isinstance(b, ScalarVector):
-            b = b.to_ints()
-        return a == b
-
     def __repr__(self):
         return f"{str(self.coeffs)}, {str(self.constant)}"
+
+    def __eq__(self, other):
+        # coefficients only, as pivot.py:78-79
+        mine, theirs = self.coeffs, other.coeffs
+        mine = mine.to_ints() if isinstance(mine, ScalarVector) else mine
+        theirs = theirs.to_ints() if isinstance(theirs, ScalarVector) else theirs
+        return mine == theirs
+
+    def __add__(self, other):
+        if isinstance(other, AffineForm):
+            assert len(self) == len(other), "Length of linear forms to add not consistent."
+            if self._device() or other._device():
+                summed = _as_device(self.coeffs).axpy(1, _as_device(other.coeffs))
+            else:
+                summed = [a + b for a, b in zip(self.coeffs, other.coeffs)]
+            return self._sum_type()(summed, self.constant + other.constant)
+        if _is_number(other):
+            return self._sum_type()(self.coeffs, self.constant + other)
+        raise NotImplementedError(f"Addition of form not defined for type: {type(other)}")
+
+    def __radd__(self, other):
+        # lets sum([...forms...]) start from the int 0
+        return self if (isinstance(other, int) and other == 0) else self.__add__(other)
+
+    def __sub__(self, other):
+        return self + (-1) * other
+
+    def __mul__(self, factor):
+        if not (isinstance(factor, (int, FiniteFieldElement)) or _duck_field(factor)):
+            raise NotImplementedError(f"Multiplication of form not defined for type: {type(factor)}")
+        if self._device():
+            scaled = self.coeffs.scale(factor)
+        else:
+            scaled = [c * factor for c in self.coeffs]
+        return type(self)(scaled, self.constant * factor)
+
+    __rmul__ = __mul__
 
     def eval(self, values):
         assert len(values) == len(self.coeffs), \
             "Length of inputs to be equal to coefficients of linear form."
-        if isinstance(self.coeffs, ScalarVector) or isinstance(values, ScalarVector):
-            dot = _as_device(self.coeffs).dot(_as_device(values))
-            gf = _field_of(self.constant)
-            return (gf(dot) if gf else dot) + self.constant
-        return sum([self.coeffs[i] * values_i for i, values_i in enumerate(values)]) + self.constant
+        if self._device() or isinstance(values, ScalarVector):
+            inner = _as_device(self.coeffs).dot(_as_device(values))     # csrc/frvec.hip
+            field = _field_of(self.constant)
+            return (field(inner) if field else inner) + self.constant
+        return sum([c * v for c, v in zip(self.coeffs, values)]) + self.constant
 
-    def __call__(self, values):
-        return self.eval(values)
+    __call__ = eval
 
 
 class LinearForm(AffineForm):
-    """pivot.py:98-116: constant forced to 0; sums of linear forms are AffineForms."""
+    """Form without constant term (pivot.py:98-116): the constant argument is ignored and
+    sums of linear forms come back as AffineForm."""
 
     def __init__(self, coeffs, constant=0):
-        self.coeffs = coeffs
-        self.constant = 0
+        super().__init__(coeffs, 0)
 
     def _sum_type(self):
         return AffineForm
@@ -269,42 +261,39 @@ def affine_to_linear(L, y, n):
     return L_linear, y_linear
 
 
+def _pis_challenge(t, A, g, h, P, L, y, order):
+    """Challenge of Pi_s: hash of [t, A, g, h, P, L, y] with A and P normalised when they
+    are curve points (pivot.py:169-174, :194-201)."""
+    if isinstance(A, EllipticCurveElement):
+        A, P = A.normalize(), P.normalize()
+    return fiat_shamir_hash([t, A, g, h, P, L, y], order)
+
+
 def prove_linear_form_eval(g, h, P, L, y, x, gamma, gf):
-    """Sigma protocol Pi_s (Protocol 2 of AC20), non-interactive (pivot.py:156-181)."""
+    """Sigma protocol Pi_s (Protocol 2 of AC20), non-interactive (pivot.py:156-181):
+    returns (z, phi, c)."""
     n = len(x)
     L, y = affine_to_linear(L, y, n)
-    r = list(gf(prng.randrange(gf.order)) for i in range(n))
-    rho = prng.randrange(gf.order)
+    order = gf.order
+    r = [gf(prng.randrange(order)) for _ in range(n)]      # masks: r first, then rho
+    rho = prng.randrange(order)
     t = L(r)
     A = vector_commitment(r, rho, g, h)
     logger_piv.debug(f"Prover computed A={A}.")
-
-    if isinstance(A, EllipticCurveElement):
-        input_list = [t, A.normalize(), g, h, P.normalize(), L, y]
-    else:
-        input_list = [t, A, g, h, P, L, y]
-
-    c = fiat_shamir_hash(input_list, gf.order)
-    z = [c * x_i + r[i] for i, x_i in enumerate(x)]
-    phi = (c * gamma + rho) % gf.order
+    c = _pis_challenge(t, A, g, h, P, L, y, order)
+    z = [c * x_i + r_i for x_i, r_i in zip(x, r)]
+    phi = (c * gamma + rho) % order
     return z, phi, c
 
 
 def verify_linear_form_proof(g, h, P, L, y, z, phi, c):
-    """pivot.py:184-205."""
-    n = len(z)
-    L, y = affine_to_linear(L, y, n)
-    A_check = vector_commitment(z, phi, g, h) * ((P ** c) ** (-1))
+    """Verifier of Pi_s (pivot.py:184-205): recompute the announcement from the response
+    and compare challenges."""
+    L, y = affine_to_linear(L, y, len(z))
+    P = P if isinstance(P, Ed25519Point) else Ed25519Point((int(P[0]), int(P[1]), int(P[2])))
+    # A = commit(z, phi) / P^c
+    P_c_inv = Ed25519Point.inversion(Ed25519Point.repeat(P, int(c)))
+    A_check = Ed25519Point.operation(vector_commitment(z, phi, g, h), P_c_inv)
     t_check = L(z) - c * y
-    logger_piv.debug(f"Verifier computed A_check={A_check}.")
-    logger_piv.debug(f"Verifier computed t_check={t_check}.")
-    order = type(t_check).order
-
-    if isinstance(A_check, EllipticCurveElement):
-        input_list = [t_check, A_check.normalize(), g, h, P.normalize(), L, y]
-    else:
-        input_list = [t_check, A_check, g, h, P, L, y]
-
-    logger_piv.debug(f"Method verify_linear_form_proof: input_list={input_list}.")
-    hash_check = fiat_shamir_hash(input_list, order)
-    return bool(c == hash_check)
+    logger_piv.debug(f"Verifier computed A_check={A_check}, t_check={t_check}.")
+    return bool(c == _pis_challenge(t_check, A_check, g, h, P, L, y, type(t_check).order))
