@@ -111,6 +111,45 @@ def test_msm_every_window_width(nat, ctx, c_bits):
     assert dl_aff(ctx, out.ptr)[0][:2] == want
 
 
+def gpu_points(nat, ctx, exps):
+    """g_i = e_i * B made on the device (vmpc_repeat_dev is checked against the oracle above)."""
+    dbase, dexp = ctx.upload(aff_bytes([ed.BASE])), ctx.upload(sc_bytes(nat, exps))
+    out = ctx.alloc(64 * len(exps))
+    ctx.repeat(dbase.ptr, 1, True, dexp.ptr, len(exps), False, None, out.ptr)
+    ctx.sync()
+    return out
+
+
+@pytest.mark.parametrize("dist", ["commitment", "all_ones", "two_values", "top_heavy"])
+def test_msm_skewed_scalars(nat, ctx, dist):
+    """heavy buckets (zeros / ones / repeated scalars, SURVEY.md 8d cfg 2 'commitment
+    distribution') go through the segment split + workgroup finish path."""
+    rng = random.Random(21)
+    n = 6000
+    exps = [rng.randrange(1, ELL) for _ in range(n)]
+    if dist == "commitment":       # 54 % zeros, 9 % in {1, 2}, 37 % uniform
+        x = [0 if u < 0.54 else (rng.choice([1, 2]) if u < 0.63 else rng.randrange(ELL))
+             for u in (rng.random() for _ in range(n))]
+    elif dist == "all_ones":
+        x = [1] * n
+    elif dist == "two_values":
+        a, b = rng.randrange(ELL), ELL - 1
+        x = [a if i % 3 else b for i in range(n)]
+    else:                           # everything lands in a handful of top-window buckets
+        x = [(1 << 251) + (i % 3) for i in range(n)]
+    pts = gpu_points(nat, ctx, exps)
+    ds, out = ctx.upload(sc_bytes(nat, x)), ctx.alloc(64)
+    want = ed.pt_affine(ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(x, exps)) % ELL))
+    for c_bits in (0, 7, 12):
+        ctx.set_window(c_bits)
+        try:
+            ctx.msm(ds.ptr, pts.ptr, n, None, None, 0, None, out.ptr)
+            ctx.sync()
+        finally:
+            ctx.set_window(0)
+        assert dl_aff(ctx, out.ptr)[0][:2] == want, (dist, c_bits)
+
+
 def test_msm_edge_cases(nat, ctx):
     rng = random.Random(9)
     exps, g = make_points(rng, 8)

@@ -14,7 +14,8 @@
 //   counts   per-bucket totals + per-slice exclusive offsets
 //   scan     exclusive scan of bucket totals -> bucket start offsets
 //   scatter  per (window, slice) workgroup: LDS cursors -> bucket-sorted point indices
-//   bucket   one lane per bucket: mixed additions (7M) over its sorted run
+//   plan     cut every bucket's run into <= 64-entry segments, number them by length
+//   bucket   one lane per segment: mixed additions (7M); finish: LDS tree for split buckets
 //   reduce   per window: chunked running sums + LDS tree -> sum_b b*B_b partials
 //   final    window sums, Horner over windows (c doublings each), one inversion -> affine
 //
@@ -188,36 +189,151 @@ k_msm_scatter(const int16_t *__restrict__ digits, size_t n_total, size_t slice_l
     }
 }
 
-// ---- bucket accumulation: one lane per (window, bucket) --------------------------------
+// ---- bucket accumulation, segment-balanced -----------------------------------------------
+// A lane per bucket is unbalanced three ways: Poisson spread of bucket sizes inside a wave,
+// the under-full top window (scalars < 2^253 leave it 2^3..2^13 times fewer buckets, each
+// that much fuller), and skewed witnesses (many 0/1/small scalars put half the terms into
+// one bucket).  So every bucket's sorted run is cut into segments of <= MSM_SEG entries and
+// ONE LANE PROCESSES ONE SEGMENT; segments are numbered by decreasing length (a counting
+// sort over the 64 possible lengths) so the 64 lanes of a wave run loops of equal trip
+// count.  Buckets that needed more than one segment are finished by a workgroup-wide LDS
+// tree over their partial sums.
+#define MSM_SEG 64
+
+__device__ __forceinline__ size_t bucket_slot(uint32_t ci, int nb1) {
+    // ci = w * nb1 + b (b >= 1)  ->  w * nb + (b - 1)
+    uint32_t w = ci / (uint32_t)nb1;
+    return (size_t)ci - w - 1;
+}
+
+// plan, pass 1: segments per bucket + per-block histogram of segment lengths
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_plan1(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nblocks,
+            uint32_t *__restrict__ nseg, uint32_t *__restrict__ block_hist,
+            uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ ctrl /*[0]=heavy count*/) {
+    __shared__ uint32_t lh[MSM_SEG + 1];
+    __shared__ uint32_t heavy_n, heavy_base;
+    if (threadIdx.x <= MSM_SEG) lh[threadIdx.x] = 0;
+    if (threadIdx.x == 0) heavy_n = 0;
+    __syncthreads();
+    uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cnt = ci < nslots ? counts[ci] : 0;
+    uint32_t full = cnt / MSM_SEG, rem = cnt % MSM_SEG;
+    uint32_t ns = full + (rem ? 1u : 0u);
+    if (ci < nslots) nseg[ci] = ns;
+    if (full) atomicAdd(&lh[MSM_SEG], full);
+    if (rem) atomicAdd(&lh[rem], 1u);
+    uint32_t my_heavy = 0;
+    if (ns > 1) my_heavy = atomicAdd(&heavy_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && heavy_n) heavy_base = atomicAdd(&ctrl[0], heavy_n);
+    __syncthreads();
+    if (ns > 1) heavy_list[heavy_base + my_heavy] = ci;
+    // layout [(SEG - L) * nblocks + block]: longest segments get the smallest task ids
+    if (threadIdx.x >= 1 && threadIdx.x <= MSM_SEG)
+        block_hist[(size_t)(MSM_SEG - threadIdx.x) * nblocks + blockIdx.x] = lh[threadIdx.x];
+}
+
+// plan, pass 2: write the task table (bucket slot, segment index), grouped by length
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_plan2(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nblocks,
+            const uint32_t *__restrict__ block_base, uint2 *__restrict__ tasks) {
+    __shared__ uint32_t cur[MSM_SEG + 1];
+    if (threadIdx.x <= MSM_SEG) cur[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= nslots) return;
+    uint32_t cnt = counts[ci];
+    uint32_t full = cnt / MSM_SEG, rem = cnt % MSM_SEG;
+    if (rem) {
+        uint32_t r = atomicAdd(&cur[rem], 1u);
+        tasks[block_base[(size_t)(MSM_SEG - rem) * nblocks + blockIdx.x] + r] = make_uint2(ci, full);
+    }
+    if (full) {
+        uint32_t r = atomicAdd(&cur[MSM_SEG], full);
+        uint32_t base = block_base[blockIdx.x] + r;
+        for (uint32_t sidx = 0; sidx < full; sidx++) tasks[base + sidx] = make_uint2(ci, sidx);
+    }
+}
+
+__device__ __forceinline__ ge_niels niels_ld(const uint32_t *niels, uint32_t e) {
+    const uint32_t *src = niels + 24 * (size_t)(e & 0x7fffffffu);
+    ge_niels q;
+    q.ymx = fe_ld(src);
+    q.ypx = fe_ld(src + 8);
+    q.t2d = fe_ld(src + 16);
+    return q;
+}
+
+// one lane = one segment of <= MSM_SEG sorted entries
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ sorted,
-             const uint32_t *__restrict__ starts, const uint32_t *__restrict__ counts, int W, int nb,
-             uint32_t *__restrict__ buckets) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)W * nb) return;
-    int w = (int)(t / nb), b = (int)(t % nb) + 1;
-    size_t ci = (size_t)w * (nb + 1) + b;
-    uint32_t start = starts[ci], cnt = counts[ci];
+             const uint32_t *__restrict__ starts, const uint32_t *__restrict__ counts,
+             const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
+             const uint2 *__restrict__ tasks, const uint32_t *__restrict__ n_tasks, int nb1,
+             uint32_t *__restrict__ buckets, uint32_t *__restrict__ partial) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *n_tasks) return;
+    uint2 tk = tasks[t];
+    uint32_t ci = tk.x, sidx = tk.y;
+    uint32_t cnt = counts[ci];
+    uint32_t lo = starts[ci] + sidx * MSM_SEG;
+    uint32_t len = cnt - sidx * MSM_SEG;
+    if (len > MSM_SEG) len = MSM_SEG;
     ge_ext acc = ge_ext_identity();
-    for (uint32_t j = 0; j < cnt; j++) {
-        uint32_t e = sorted[start + j];
-        const uint32_t *src = niels + 24 * (size_t)(e & 0x7fffffffu);
-        ge_niels q;
-        q.ymx = fe_ld(src);
-        q.ypx = fe_ld(src + 8);
-        q.t2d = fe_ld(src + 16);
-        q = ge_niels_select_neg(q, (e >> 31) != 0);
-        acc = ge_madd(acc, q);
+    uint32_t e = sorted[lo];
+    ge_niels q = niels_ld(niels, e);
+    for (uint32_t j = 0; j < len; j++) {
+        // fetch the next term before the 7 multiplications of this one
+        uint32_t jn = j + 1 < len ? j + 1 : j;
+        uint32_t en = sorted[lo + jn];
+        ge_niels qn = niels_ld(niels, en);
+        acc = ge_madd(acc, ge_niels_select_neg(q, (e >> 31) != 0));
+        e = en;
+        q = qn;
     }
-    ext_st(buckets + 32 * t, acc);
+    if (nseg[ci] == 1)
+        ext_st(buckets + 32 * bucket_slot(ci, nb1), acc);
+    else
+        ext_st(partial + 32 * (size_t)(seg_starts[ci] + sidx), acc);
+}
+
+// buckets that took several segments: workgroup tree over their partial sums
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_bucket_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ ctrl,
+                    const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
+                    const uint32_t *__restrict__ partial, int nb1, uint32_t *__restrict__ buckets) {
+    __shared__ uint32_t lds[MSM_BLOCK * 32];
+    const uint32_t n_heavy = ctrl[0];
+    for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        uint32_t ci = heavy_list[h];
+        uint32_t ns = nseg[ci];
+        const uint32_t *src = partial + 32 * (size_t)seg_starts[ci];
+        ge_ext acc = ge_ext_identity();
+        for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x) acc = ge_add(acc, ext_ld(src + 32 * (size_t)j));
+        ext_st(lds + 32 * threadIdx.x, acc);
+        __syncthreads();
+        uint32_t width = ns < MSM_BLOCK ? ns : MSM_BLOCK;   // lanes >= width hold the identity
+        uint32_t stride = 1;
+        while (stride < width) stride <<= 1;
+        for (stride >>= 1; stride >= 1; stride >>= 1) {
+            if (threadIdx.x < stride && threadIdx.x + stride < width)
+                ext_st(lds + 32 * threadIdx.x,
+                       ge_add(ext_ld(lds + 32 * threadIdx.x), ext_ld(lds + 32 * (threadIdx.x + stride))));
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) ext_st(buckets + 32 * bucket_slot(ci, nb1), ext_ld(lds));
+        __syncthreads();
+    }
 }
 
 // ---- reduce: sum_b b * B_b per window ---------------------------------------------------
 // thread = one chunk of `chunk_len` consecutive buckets; running sums inside the chunk,
 // chunk offset by a short double-and-add, then an LDS tree over the workgroup.
 __global__ void __launch_bounds__(MSM_BLOCK)
-k_msm_reduce(const uint32_t *__restrict__ buckets, int nb, int chunks, int chunk_len,
-             int log2_chunk_len, int red_blocks, uint32_t *__restrict__ partials) {
+k_msm_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ counts, int nb,
+             int chunks, int chunk_len, int log2_chunk_len, int red_blocks,
+             uint32_t *__restrict__ partials) {
     __shared__ uint32_t lds[MSM_BLOCK * 32];
     const int w = blockIdx.y;
     const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,9 +341,10 @@ k_msm_reduce(const uint32_t *__restrict__ buckets, int nb, int chunks, int chunk
     if (chunk < chunks) {
         const int lo = chunk * chunk_len;  // 0-based bucket index; bucket value = index + 1
         const uint32_t *bw = buckets + 32 * ((size_t)w * nb + lo);
+        const uint32_t *cw = counts + (size_t)w * (nb + 1) + lo + 1;   // empty buckets are never written
         ge_ext acc = ge_ext_identity(), sum = ge_ext_identity();
         for (int j = chunk_len - 1; j >= 0; j--) {
-            acc = ge_add(acc, ext_ld(bw + 32 * j));
+            if (cw[j]) acc = ge_add(acc, ext_ld(bw + 32 * j));
             sum = ge_add(sum, acc);
         }
         // sum = sum_j (j+1) B_{lo+j}; add lo * acc where lo = chunk * 2^log2_chunk_len
@@ -440,9 +557,13 @@ static void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, msm_plan
 
 struct msm_ws {
     uint32_t *niels, *hist, *counts, *starts, *sorted, *buckets, *partials;
+    uint32_t *nseg, *seg_starts, *block_hist, *block_base, *heavy_list, *ctrl, *seg_partial;
+    uint2 *tasks;
     int16_t *digits;
     void *scan_ws;
     size_t total;
+    uint32_t plan_blocks;
+    size_t t_max;
 };
 
 static void msm_layout(const msm_plan &p, msm_ws &w, char *base) {
@@ -461,7 +582,22 @@ static void msm_layout(const msm_plan &p, msm_ws &w, char *base) {
     w.sorted = (uint32_t *)take((size_t)p.W * p.n_total * 4);
     w.buckets = (uint32_t *)take((size_t)p.W * p.nb * 128);
     w.partials = (uint32_t *)take((size_t)p.W * p.red_blocks * 128);
-    w.scan_ws = take(vmpc_scan_ws_bytes(nbk, 4));
+    // segment planning: at most M/SEG full segments plus one remainder per non-empty bucket
+    size_t m_max = (size_t)p.W * p.n_total;
+    size_t nonempty_max = m_max < (size_t)p.W * p.nb ? m_max : (size_t)p.W * p.nb;
+    w.t_max = m_max / MSM_SEG + nonempty_max;
+    w.plan_blocks = (uint32_t)((nbk + MSM_BLOCK - 1) / MSM_BLOCK);
+    size_t hist_n = (size_t)MSM_SEG * w.plan_blocks;
+    w.nseg = (uint32_t *)take(nbk * 4);
+    w.seg_starts = (uint32_t *)take(nbk * 4);
+    w.block_hist = (uint32_t *)take(hist_n * 4);
+    w.block_base = (uint32_t *)take(hist_n * 4);
+    w.heavy_list = (uint32_t *)take(nbk * 4);
+    w.ctrl = (uint32_t *)take(64);
+    w.tasks = (uint2 *)take(w.t_max * 8);
+    w.seg_partial = (uint32_t *)take(w.t_max * 128);
+    size_t scan_n = nbk > hist_n ? nbk : hist_n;
+    w.scan_ws = take(vmpc_scan_ws_bytes(scan_n, 4));
     w.total = off;
 }
 
@@ -540,16 +676,38 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
         VMPC_KERNEL_CHECK();
     }
     {
+        vmpc_stage_scope s(ctx, "msm_plan");
+        VMPC_HIP_CHECK(hipMemsetAsync(w.ctrl, 0, 64, st));
+        k_msm_plan1<<<w.plan_blocks, MSM_BLOCK, 0, st>>>(w.counts, (uint32_t)nbk, w.plan_blocks, w.nseg,
+                                                        w.block_hist, w.heavy_list, w.ctrl);
+        VMPC_KERNEL_CHECK();
+        size_t hist_n = (size_t)MSM_SEG * w.plan_blocks;
+        VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint32_t>(st, w.block_hist, w.block_base, hist_n,
+                                                            w.scan_ws, w.ctrl + 1)));   // ctrl[1] = #tasks
+        VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint32_t>(st, w.nseg, w.seg_starts, nbk, w.scan_ws,
+                                                            (uint32_t *)nullptr)));
+        k_msm_plan2<<<w.plan_blocks, MSM_BLOCK, 0, st>>>(w.counts, (uint32_t)nbk, w.plan_blocks,
+                                                        w.block_base, w.tasks);
+        VMPC_KERNEL_CHECK();
+    }
+    {
         vmpc_stage_scope s(ctx, "msm_bucket");
-        size_t nt = (size_t)p.W * p.nb;
-        k_msm_bucket<<<(unsigned)((nt + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
-            w.niels, w.sorted, w.starts, w.counts, p.W, p.nb, w.buckets);
+        k_msm_bucket<<<(unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
+            w.niels, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
+            w.buckets, w.seg_partial);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_bucket_finish");
+        k_msm_bucket_finish<<<4 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg,
+                                                                    w.seg_starts, w.seg_partial, p.nb1,
+                                                                    w.buckets);
         VMPC_KERNEL_CHECK();
     }
     {
         vmpc_stage_scope s(ctx, "msm_reduce");
         k_msm_reduce<<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, st>>>(
-            w.buckets, p.nb, p.chunks, p.chunk_len, ilog2(p.chunk_len), p.red_blocks, w.partials);
+            w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, ilog2(p.chunk_len), p.red_blocks, w.partials);
         VMPC_KERNEL_CHECK();
     }
     {
