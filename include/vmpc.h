@@ -55,6 +55,10 @@ int vmpc_ctx_destroy(vmpc_ctx *ctx);
 /* run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
 int vmpc_ctx_set_stream(vmpc_ctx *ctx, void *hip_stream);
 int vmpc_ctx_sync(vmpc_ctx *ctx);
+/* make `waiter`'s stream wait (on the device, no host block) for everything enqueued so far on
+ * `other`'s stream: lets two contexts run independent MSMs (A_i and B_i of one Protocol-4
+ * round, compressed_pivot.py:41-42) concurrently */
+int vmpc_ctx_wait_for(vmpc_ctx *waiter, vmpc_ctx *other);
 int vmpc_malloc(vmpc_ctx *ctx, size_t bytes, void **dptr);
 int vmpc_free(vmpc_ctx *ctx, void *dptr);
 int vmpc_memcpy_h2d(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronous */
@@ -142,6 +146,12 @@ int vmpc_format_points_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *out_
                            uint64_t *len);
 int vmpc_format_scalars_dev(vmpc_ctx *ctx, const void *scalars, size_t n, int is_signed,
                             void *out_text, size_t cap, uint64_t *len);
+
+/* SHA-256 of every `chunk_bytes`-sized piece of a device buffer (last piece may be short):
+ * out_digests[i] = SHA256(data[i*chunk : (i+1)*chunk]), 32 bytes each.  Leaves of the compact
+ * transcript's two-level digests; not used by the reference transcript. */
+int vmpc_sha256_chunks_dev(vmpc_ctx *ctx, const void *data, size_t nbytes, size_t chunk_bytes,
+                           void *out_digests);
 
 #ifdef __cplusplus
 }

@@ -330,3 +330,16 @@ def test_host_one_shots(nat):
     with pytest.raises(nat.VmpcError) as ei:
         nat.ed25519_msm(bad_sc, aff_bytes(g))
     assert ei.value.code == nat.E_NONCANON
+
+
+@pytest.mark.parametrize("nbytes", [1, 55, 56, 63, 64, 65, 4095, 4096, 4097, 3 * 4096 + 100, 70001])
+def test_sha256_chunks(nat, ctx, nbytes):
+    import hashlib
+    rng = np.random.default_rng(nbytes)
+    data = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+    d = ctx.upload(data)
+    for chunk in (4096, 64, 1000):
+        got = ctx.sha256_chunks(d.ptr, nbytes, chunk)
+        raw = data.tobytes()
+        want = b"".join(hashlib.sha256(raw[o:o + chunk]).digest() for o in range(0, nbytes, chunk))
+        assert got == want, (nbytes, chunk)

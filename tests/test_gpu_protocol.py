@@ -37,6 +37,13 @@ def record_hashes(vm, monkeypatch):
         calls.append(c)
         return c
     monkeypatch.setattr(vm.pivot, "fiat_shamir_hash", wrapped)
+    orig_v = vm.pivot.fiat_shamir_hash_variants
+
+    def wrapped_v(common, tails, order):
+        cs = orig_v(common, tails, order)
+        calls.extend(cs)
+        return cs
+    monkeypatch.setattr(vm.pivot, "fiat_shamir_hash_variants", wrapped_v)
     return calls
 
 
@@ -113,9 +120,12 @@ def test_protocol5_first_preimage_text(vm, golden_small, monkeypatch):
     texts = []
 
     class Spy:
-        def __init__(self):
-            self.h = hashlib.sha256()
-            self.buf = bytearray()
+        def __init__(self, h=None, buf=b""):
+            self.h = h or hashlib.sha256()
+            self.buf = bytearray(buf)
+
+        def copy(self):
+            return Spy(self.h.copy(), self.buf)
 
         def update(self, b):
             self.buf += bytes(b)

@@ -25,13 +25,14 @@ SCALAR_BYTES, AFFINE_BYTES, PROJ_BYTES, EXT_BYTES = 32, 64, 96, 128
 # against the header and against the built library)
 SYMBOLS = [
     "vmpc_backend_info", "vmpc_last_error", "vmpc_ctx_create", "vmpc_ctx_destroy",
-    "vmpc_ctx_set_stream", "vmpc_ctx_sync", "vmpc_malloc", "vmpc_free", "vmpc_memcpy_h2d",
+    "vmpc_ctx_set_stream", "vmpc_ctx_sync", "vmpc_ctx_wait_for", "vmpc_malloc", "vmpc_free", "vmpc_memcpy_h2d",
     "vmpc_memcpy_d2h", "vmpc_memcpy_d2d", "vmpc_ctx_profile", "vmpc_ctx_profile_read",
     "vmpc_ctx_set_window", "vmpc_ed25519_msm", "vmpc_ed25519_fold",
     "vmpc_ed25519_fixed_base_batch", "vmpc_fr_axpy", "vmpc_fr_dot", "vmpc_points_validate_dev",
     "vmpc_msm_dev", "vmpc_points_sum_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
     "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
+    "vmpc_sha256_chunks_dev",
 ]
 
 
@@ -63,6 +64,7 @@ def load_library():
         "vmpc_ctx_destroy": (i32, [vp]),
         "vmpc_ctx_set_stream": (i32, [vp, vp]),
         "vmpc_ctx_sync": (i32, [vp]),
+        "vmpc_ctx_wait_for": (i32, [vp, vp]),
         "vmpc_malloc": (i32, [vp, sz, ctypes.POINTER(vp)]),
         "vmpc_free": (i32, [vp, vp]),
         "vmpc_memcpy_h2d": (i32, [vp, vp, vp, sz]),
@@ -89,6 +91,7 @@ def load_library():
         "vmpc_fr_dot_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_format_points_dev": (i32, [vp, vp, sz, vp, sz, u64p]),
         "vmpc_format_scalars_dev": (i32, [vp, vp, sz, i32, vp, sz, u64p]),
+        "vmpc_sha256_chunks_dev": (i32, [vp, vp, sz, sz, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the export is missing
@@ -141,22 +144,32 @@ def array_to_ints(a):
     return [int.from_bytes(raw[i:i + w], "little") for i in range(0, len(raw), w)]
 
 
+def _size_class(nbytes):
+    """power-of-two size classes (>= 256 B) so that the halving rounds reuse blocks"""
+    n = max(int(nbytes), 256)
+    return 1 << (n - 1).bit_length()
+
+
 class DeviceBuffer:
-    """Owned device allocation (vmpc_malloc) - freed with the object."""
+    """Owned device allocation - returned to the context's block cache with the object.
+
+    hipMalloc/hipFree cost 0.1-1 ms and hipFree synchronises the device; a Protocol-5 proof
+    allocates a few vectors per round, so blocks are recycled per size class.  Reuse is safe
+    in stream order: a block handed out again is only touched by work enqueued later on the
+    same context's stream."""
 
     def __init__(self, ctx, nbytes):
         self.ctx = ctx
         self.nbytes = int(nbytes)
-        p = ctypes.c_void_p()
-        _check(ctx.lib.vmpc_malloc(ctx.handle, self.nbytes, ctypes.byref(p)), "vmpc_malloc")
-        self.ptr = p.value
+        self.cap = _size_class(nbytes)
+        self.ptr = ctx._take_block(self.cap)
 
     def at(self, byte_offset):
         return ctypes.c_void_p(self.ptr + int(byte_offset))
 
     def free(self):
         if self.ptr and self.ctx.handle:
-            self.ctx.lib.vmpc_free(self.ctx.handle, ctypes.c_void_p(self.ptr))
+            self.ctx._give_block(self.cap, self.ptr)
         self.ptr = None
 
     def __del__(self):
@@ -175,9 +188,41 @@ class Context:
         _check(self.lib.vmpc_ctx_create(device, ctypes.byref(h)), "vmpc_ctx_create")
         self.handle = h
         self.device = device
+        self._cache = {}          # size class -> [device pointers]
+        self._cached_bytes = 0
+        self.cache_limit = 16 << 30
+
+    def _take_block(self, cap):
+        lst = self._cache.get(cap)
+        if lst:
+            self._cached_bytes -= cap
+            return lst.pop()
+        p = ctypes.c_void_p()
+        rc = self.lib.vmpc_malloc(self.handle, cap, ctypes.byref(p))
+        if rc == E_NOMEM and self._cached_bytes:
+            self.trim()
+            rc = self.lib.vmpc_malloc(self.handle, cap, ctypes.byref(p))
+        _check(rc, "vmpc_malloc")
+        return p.value
+
+    def _give_block(self, cap, ptr):
+        if self._cached_bytes + cap > self.cache_limit:
+            self.lib.vmpc_free(self.handle, ctypes.c_void_p(ptr))
+            return
+        self._cache.setdefault(cap, []).append(ptr)
+        self._cached_bytes += cap
+
+    def trim(self):
+        """release every cached block back to the HIP allocator"""
+        for lst in self._cache.values():
+            for ptr in lst:
+                self.lib.vmpc_free(self.handle, ctypes.c_void_p(ptr))
+        self._cache = {}
+        self._cached_bytes = 0
 
     def close(self):
         if self.handle:
+            self.trim()
             self.lib.vmpc_ctx_destroy(self.handle)
             self.handle = None
 
@@ -218,6 +263,10 @@ class Context:
 
     def sync(self):
         _check(self.lib.vmpc_ctx_sync(self.handle), "vmpc_ctx_sync")
+
+    def wait_for(self, other):
+        """device-side ordering: this context's stream waits for `other`'s work so far"""
+        _check(self.lib.vmpc_ctx_wait_for(self.handle, other.handle), "vmpc_ctx_wait_for")
 
     def set_stream(self, stream_ptr):
         _check(self.lib.vmpc_ctx_set_stream(self.handle, ctypes.c_void_p(stream_ptr)),
@@ -313,6 +362,19 @@ class Context:
         out = self.download(buf.ptr, ln.value)
         buf.free()
         return out
+
+    def sha256_chunks(self, data_ptr, nbytes, chunk_bytes=4096):
+        """bytes object: concatenated 32-byte SHA-256 digests of the chunks of a device buffer"""
+        n_chunks = (nbytes + chunk_bytes - 1) // chunk_bytes
+        if n_chunks == 0:
+            return b""
+        out = DeviceBuffer(self, 32 * n_chunks)
+        _check(self.lib.vmpc_sha256_chunks_dev(self.handle, ctypes.c_void_p(data_ptr), nbytes,
+                                               chunk_bytes, ctypes.c_void_p(out.ptr)),
+               "vmpc_sha256_chunks_dev")
+        res = self.download(out.ptr, 32 * n_chunks).tobytes()
+        out.free()
+        return res
 
     def format_points(self, proj_ptr, n):
         """uint8 array 'item0, item1, ..., ' for n projective points."""

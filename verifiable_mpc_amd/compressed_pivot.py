@@ -85,6 +85,12 @@ def _chunked_digest(tag, data):
     return hashlib.sha256(tag + len(mv).to_bytes(8, "little") + leaves).digest()
 
 
+def _chunked_digest_dev(tag, ctx, ptr, nbytes):
+    """same digest with the leaves hashed on the device (csrc/sha256.hip)"""
+    leaves = ctx.sha256_chunks(ptr, nbytes, CHUNK)
+    return hashlib.sha256(tag + int(nbytes).to_bytes(8, "little") + leaves).digest()
+
+
 def _sc_bytes(v):
     return reduce_scalar(v).to_bytes(32, "little")
 
@@ -95,9 +101,8 @@ def generators_digest(generators):
     if isinstance(g, PointVector) and g._digest is not None:
         return g._digest
     gv = pivot._points_on_device(g)
-    data = gv.affine_array().tobytes() + _pt(generators["h"]).to_affine_bytes() + \
-        _pt(generators["k"]).to_affine_bytes()
-    d = _chunked_digest(b"vmpc-ac20/gens/v1", data)
+    full = PointVector(gv.a, None, gv.ctx).concat([_pt(generators["h"]), _pt(generators["k"])])
+    d = _chunked_digest_dev(b"vmpc-ac20/gens/v1", full.ctx, full.affine_ptr, 64 * len(full))
     if isinstance(g, PointVector):
         g._digest = d
     return d
@@ -106,7 +111,7 @@ def generators_digest(generators):
 def _form_digest(L):
     c = L.coeffs
     if isinstance(c, ScalarVector):
-        data = c.ctx.download(c.ptr, 32 * len(c)).tobytes()
+        return _chunked_digest_dev(b"vmpc-ac20/form/v1", c.ctx, c.ptr, 32 * len(c))
     else:
         data = b"".join(_sc_bytes(pivot._residue(v)) for v in c)
     return _chunked_digest(b"vmpc-ac20/form/v1", data)
@@ -179,6 +184,21 @@ def _fold_commitment(A, Q, B, c):
     return _gmul(_gmul(A, _gpow(Q, c)), _gpow(B, c * c))
 
 
+def _unfold_commitment(Q0, rounds, order):
+    """Q_R from Q' = A * Q**c * B**(c**2) applied R times, as ONE (2R+1)-term MSM:
+    Q_R = (prod_j c_j) Q_0 + sum_i (prod_{j>i} c_j) (A_i + c_i^2 B_i)."""
+    scalars, points = [], []
+    suffix = 1
+    for A, B, c in reversed(rounds):
+        scalars += [suffix, suffix * c * c % order]
+        points += [A, B]
+        suffix = suffix * c % order
+    scalars.append(suffix)
+    points.append(Q0)
+    return pivot.vector_commitment(scalars, 0, PointVector.from_points(points, keep_proj=False),
+                                   Ed25519Point.identity)
+
+
 def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, transcript=None):
     """Non-interactive Protocol 4, prover (compressed_pivot.py:29-86); the reference's
     recursion is a loop here, `round_i` keeps its meaning."""
@@ -191,8 +211,7 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
         g_l, g_r = g_hat[:half], g_hat[half:]
         z_l, z_r, gamma_a, gamma_b = _round_prover_scalars(L_tilde, z_hat, half, gf)
         logger_cp.debug("Calculate A_i, B_i.")
-        A = _commit(z_l, gamma_a, g_r, k)
-        B = _commit(z_r, gamma_b, g_l, k)
+        A, B = pivot.vector_commitment_pair(z_l, gamma_a, g_r, z_r, gamma_b, g_l, k)
         proof["A" + str(round_i)] = A
         proof["B" + str(round_i)] = B
 
@@ -200,7 +219,10 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
         logger_cp_hout.debug(f"After hash, hash=\n{c}")
 
         g_hat = g_l.fold(g_r, c)
-        Q = _fold_commitment(A, Q, B, c)
+        if transcript.mode == "reference":
+            # only the reference pre-image contains Q (compressed_pivot.py:52); the compact
+            # chain binds Q once at the start, so the prover need not track it
+            Q = _fold_commitment(A, Q, B, c)
         L_tilde = _fold_form(L_tilde, c, half, gf)
         z_hat = _fold_witness(z_l, z_r, c, half)
         if len(z_hat) <= 2:
@@ -217,6 +239,7 @@ def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=N
     k, Q = _pt(k), _pt(Q)
     if not isinstance(transcript, _Transcript):
         transcript = _Transcript(transcript or "reference", k.order)
+    deferred = []            # compact mode: (A_i, B_i, c_i), Q unfolded once at the end
     while True:
         half = len(g_hat) // 2
         g_l, g_r = g_hat[:half], g_hat[half:]
@@ -224,12 +247,17 @@ def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=N
         B = _pt(proof["B" + str(round_i)])
         c = transcript.round_challenge(round_i, A, B, g_hat, k, Q, L_tilde)
         g_prime = g_l.fold(g_r, c)
-        Q = _fold_commitment(A, Q, B, c)
+        if transcript.mode == "reference":
+            Q = _fold_commitment(A, Q, B, c)
+        else:
+            deferred.append((A, B, c))
         L_tilde = _fold_form(L_tilde, c, half, gf)
         if len(g_prime) <= 2:
             z_prime = proof["z_prime"]
             Q_check = pivot.vector_commitment(z_prime, int(L_tilde(z_prime)), g_prime, k)
             logger_cp.debug("Arrived in final step of protocol_4_verifier.")
+            if deferred:
+                Q = _unfold_commitment(Q, deferred, transcript.order)
             return bool(Q_check == Q)
         g_hat = g_prime
         round_i += 1
@@ -241,9 +269,8 @@ def _p5_challenges(mode, order, generators, t, A, P, L, y):
     if mode == "reference":
         # compressed_pivot.py:117-130
         input_list = [t, A.normalize(), generators, P.normalize(), L, y]
-        tag = ["First hash of compressed pivot"]
-        c0 = pivot.fiat_shamir_hash(input_list + [0] + tag, order)
-        c1 = pivot.fiat_shamir_hash(input_list + [1] + tag, order)
+        tag = "First hash of compressed pivot"
+        c0, c1 = pivot.fiat_shamir_hash_variants(input_list, [[0, tag], [1, tag]], order)
         return c0, c1, None
     seed = _compact_seed(generators, P, L, y, t, A)
     c0 = _challenge(hashlib.sha256(seed + b"\x00").digest(), order)

@@ -4,6 +4,8 @@
 
 #include "common.cuh"
 
+#define VMPC_IGNORE(expr) ((void)(expr))
+
 thread_local char vmpc_err_buf[512] = {0};
 
 int vmpc_fr_check_dev(vmpc_ctx *ctx, const void *v, size_t n);  // frvec.hip
@@ -52,7 +54,7 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
     e = hipMalloc((void **)&c->d_status, VMPC_ST_WORDS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->d_status, 0, VMPC_ST_WORDS * sizeof(uint32_t));
     if (e != hipSuccess) {
-        hipStreamDestroy(c->stream);
+        VMPC_IGNORE(hipStreamDestroy(c->stream));
         delete c;
         snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "hipMalloc(status): %s", hipGetErrorString(e));
         return VMPC_E_HIP;
@@ -65,17 +67,18 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
 
 extern "C" int vmpc_ctx_destroy(vmpc_ctx *ctx) {
     if (!ctx) return VMPC_E_INVAL;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    VMPC_IGNORE(hipSetDevice(ctx->device));
+    VMPC_IGNORE(hipStreamSynchronize(ctx->stream));
     for (auto &s : ctx->stages)
         for (auto &pr : s.pending) {
-            hipEventDestroy(pr.first);
-            hipEventDestroy(pr.second);
+            VMPC_IGNORE(hipEventDestroy(pr.first));
+            VMPC_IGNORE(hipEventDestroy(pr.second));
         }
-    for (auto e : ctx->event_pool) hipEventDestroy(e);
-    if (ctx->ws) hipFree(ctx->ws);
-    if (ctx->d_status) hipFree(ctx->d_status);
-    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    for (auto e : ctx->event_pool) VMPC_IGNORE(hipEventDestroy(e));
+    if (ctx->xevent) VMPC_IGNORE(hipEventDestroy(ctx->xevent));
+    if (ctx->ws) VMPC_IGNORE(hipFree(ctx->ws));
+    if (ctx->d_status) VMPC_IGNORE(hipFree(ctx->d_status));
+    if (ctx->own_stream) VMPC_IGNORE(hipStreamDestroy(ctx->stream));
     delete ctx;
     return VMPC_OK;
 }
@@ -85,7 +88,7 @@ extern "C" int vmpc_ctx_set_stream(vmpc_ctx *ctx, void *hip_stream) {
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream) {
-        hipStreamDestroy(ctx->stream);
+        VMPC_IGNORE(hipStreamDestroy(ctx->stream));
         ctx->own_stream = false;
     }
     if (hip_stream) {
@@ -110,6 +113,16 @@ extern "C" int vmpc_ctx_sync(vmpc_ctx *ctx) {
         VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         return VMPC_E_NONCANON;
     }
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_ctx_wait_for(vmpc_ctx *waiter, vmpc_ctx *other) {
+    if (!waiter || !other) return VMPC_E_INVAL;
+    if (waiter == other || waiter->stream == other->stream) return VMPC_OK;
+    VMPC_HIP_CHECK(hipSetDevice(other->device));
+    if (!other->xevent) VMPC_HIP_CHECK(hipEventCreateWithFlags(&other->xevent, hipEventDisableTiming));
+    VMPC_HIP_CHECK(hipEventRecord(other->xevent, other->stream));
+    VMPC_HIP_CHECK(hipStreamWaitEvent(waiter->stream, other->xevent, 0));
     return VMPC_OK;
 }
 
@@ -199,7 +212,7 @@ static hipEvent_t take_event(vmpc_ctx *ctx) {
         return e;
     }
     hipEvent_t e = nullptr;
-    hipEventCreate(&e);
+    VMPC_IGNORE(hipEventCreate(&e));
     return e;
 }
 
@@ -215,14 +228,14 @@ int vmpc_stage_begin(vmpc_ctx *ctx, const char *name) {
         idx = (int)ctx->stages.size() - 1;
     }
     hipEvent_t a = take_event(ctx), b = take_event(ctx);
-    hipEventRecord(a, ctx->stream);
+    VMPC_IGNORE(hipEventRecord(a, ctx->stream));
     ctx->stages[idx].pending.push_back({a, b});
     return idx;
 }
 
 void vmpc_stage_end(vmpc_ctx *ctx, int handle) {
     if (handle < 0) return;
-    hipEventRecord(ctx->stages[handle].pending.back().second, ctx->stream);
+    VMPC_IGNORE(hipEventRecord(ctx->stages[handle].pending.back().second, ctx->stream));
 }
 
 extern "C" int vmpc_ctx_profile_read(vmpc_ctx *ctx, char *names, size_t names_len, double *ms,

@@ -51,6 +51,7 @@ struct vmpc_ctx {
     uint32_t *d_status = nullptr;
     int window_override = 0;
     int cu_count = 256;
+    hipEvent_t xevent = nullptr;   // cross-context ordering (vmpc_ctx_wait_for)
     // profiling
     bool profile = false;
     std::vector<vmpc_stage> stages;

@@ -1,0 +1,37 @@
+// Quad-cooperative point arithmetic helpers (gfx950).
+//
+// A point operation has levels of 3-4 independent field multiplications.  In latency-bound
+// kernels (the Horner chain of the MSM, the fold of short vectors) four adjacent lanes share
+// one point: lane q computes the q-th product of a level and the results are exchanged with
+// DPP quad_perm broadcasts (plain VALU moves, no LDS).  EXEC must be full within the quad.
+#pragma once
+#include "fe25519.cuh"
+
+__device__ __forceinline__ fe quad_bcast(const fe &a, int src /*0..3, compile-time after unroll*/) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int v = (int)a.v[i];
+        int o;
+        switch (src) {
+            case 0: o = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true); break;
+            case 1: o = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true); break;
+            case 2: o = __builtin_amdgcn_mov_dpp(v, 0xaa, 0xf, 0xf, true); break;
+            default: o = __builtin_amdgcn_mov_dpp(v, 0xff, 0xf, 0xf, true); break;
+        }
+        r.v[i] = (uint32_t)o;
+    }
+    return r;
+}
+
+__device__ __forceinline__ fe fe_pick4(const fe &a0, const fe &a1, const fe &a2, const fe &a3, int q) {
+    // branch-free: lanes of a quad take different operands in the same instruction stream
+    const uint32_t m0 = 0u - (uint32_t)(q == 0), m1 = 0u - (uint32_t)(q == 1);
+    const uint32_t m2 = 0u - (uint32_t)(q == 2), m3 = 0u - (uint32_t)(q == 3);
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        r.v[i] = (a0.v[i] & m0) | (a1.v[i] & m1) | (a2.v[i] & m2) | (a3.v[i] & m3);
+    return r;
+}
+

@@ -30,11 +30,24 @@ def get_context():
     return _CTX
 
 
+_AUX = None
+
+
+def get_aux_context():
+    """Second context (own stream + workspace) on the same GPU, used to run the two
+    independent MSMs of a Protocol-4 round concurrently."""
+    global _AUX
+    if _AUX is None:
+        _AUX = _native.Context(get_context().device)
+    return _AUX
+
+
 def reset_context():
-    global _CTX
-    if _CTX is not None:
-        _CTX.close()
-    _CTX = None
+    global _CTX, _AUX
+    for c in (_AUX, _CTX):
+        if c is not None:
+            c.close()
+    _CTX = _AUX = None
 
 
 def reduce_scalar(v):

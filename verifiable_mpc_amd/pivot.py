@@ -205,6 +205,28 @@ def fiat_shamir_hash(input_list, order):
     return int.from_bytes(h.digest(), "little") % order
 
 
+def fiat_shamir_hash_variants(common_items, tails, order):
+    """[fiat_shamir_hash(common_items + tail, order) for tail in tails] with the shared
+    prefix hashed once (SHA-256 state copied).  Protocol 5 hashes the same O(N) list twice,
+    differing only in the trailing [0|1, tag] (compressed_pivot.py:125-130)."""
+    h = hashlib.sha256()
+    h.update(b"[")
+    for i, item in enumerate(common_items):
+        if i:
+            h.update(b", ")
+        _feed(h, item)
+    out = []
+    for tail in tails:
+        ht = h.copy()
+        for j, item in enumerate(tail):
+            if common_items or j:
+                ht.update(b", ")
+            _feed(ht, item)
+        ht.update(b"]")
+        out.append(int.from_bytes(ht.digest(), "little") % order)
+    return out
+
+
 # ---- Pedersen vector commitment ----------------------------------------------------------------
 
 def _points_on_device(g):
@@ -240,13 +262,45 @@ def vector_commitment(x, gamma, g, h, exact_representative=False):
         ctx.tree_reduce(terms.ptr, n, True, out.ptr)
         prod = Ed25519Point.from_proj_bytes(ctx.download(out.ptr, 96).tobytes())
         return Ed25519Point.operation(Ed25519Point.repeat(h, _int(gamma)), prod)
+    return _commit_launch(xs, gamma, gv, h, ctx).result()
+
+
+class _PendingCommitment:
+    """An MSM enqueued on a context; result() synchronises that context and fetches the point."""
+
+    def __init__(self, ctx, out, keepalive):
+        self.ctx, self.out, self.keepalive = ctx, out, keepalive
+
+    def result(self):
+        self.ctx.sync()
+        pt = Ed25519Point.from_affine_bytes(self.ctx.download(self.out.ptr, 64).tobytes())
+        self.keepalive = None
+        return pt
+
+
+def _commit_launch(xs, gamma, gv, h, ctx):
+    """enqueue h^gamma * prod g_i^{x_i} on `ctx` (device vectors in, 64-byte affine out)"""
     import numpy as np
+    n = len(xs)
     gam = ctx.upload(np.frombuffer(reduce_scalar(_int(gamma)).to_bytes(32, "little"), np.uint8))
     hb = ctx.upload(np.frombuffer(h.to_affine_bytes(), np.uint8))
     out = ctx.alloc(64)
     ctx.msm(xs.ptr, gv.affine_ptr, n, gam.ptr, hb.ptr, 1, None, out.ptr)
-    ctx.sync()
-    return Ed25519Point.from_affine_bytes(ctx.download(out.ptr, 64).tobytes())
+    return _PendingCommitment(ctx, out, (gam, hb, xs, gv))
+
+
+def vector_commitment_pair(x_a, gamma_a, g_a, x_b, gamma_b, g_b, h):
+    """Two independent commitments with the same h (A_i and B_i of a Protocol-4 round,
+    compressed_pivot.py:41-42) on two streams of the same GPU."""
+    from .device import get_aux_context
+    assert len(g_a) >= len(x_a) and len(g_b) >= len(x_b), "Not enough generators."
+    gva, gvb = _points_on_device(g_a), _points_on_device(g_b)
+    xa, xb = _scalars_on_device(x_a), _scalars_on_device(x_b)
+    main, aux = gva.ctx, get_aux_context()
+    aux.wait_for(main)                 # inputs were produced on the main stream
+    pa = _commit_launch(xa, gamma_a, gva, h, main)
+    pb = _commit_launch(xb, gamma_b, gvb, h, aux)
+    return pa.result(), pb.result()
 
 
 def affine_to_linear(L, y, n):
