@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=17, help="cpu_baseline sample size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prove", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one commitment in flight (default: 2, on two streams of the same GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,11 +136,20 @@ def main():
     scalars = vm.ScalarVector.from_array(rand_scalars(rng, n))
     shard = parallel.ShardedMsm(ctx, world, rank, dist, torch)
 
-    def step():
-        return shard.commit(scalars, points)
+    depth = 1 if args.no_pipeline else shard.n_slots
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(k):
+        """k commitments, up to `depth` in flight; every result is fetched to the host."""
+        pending, last = [], None
+        for i in range(k):
+            pending.append(shard.launch(scalars, points, i % depth))
+            if len(pending) == depth:
+                last = shard.finish(pending.pop(0))
+        while pending:
+            last = shard.finish(pending.pop(0))
+        return last
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -146,8 +157,7 @@ def main():
     ctx.profile_read(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = step()
+    result = run_steps(args.steps)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -179,7 +189,7 @@ def main():
             "vs_baseline": None, "dtype": "u32x8 (255-bit modular integers)", "data": "synthetic",
             "config": {"workload": f"Pedersen vector-commitment MSM, n=2^{args.log2n} Ed25519 "
                                    f"generators per GPU, uniform 252-bit scalars",
-                       "terms_per_gpu": n, "total_terms": world * n,
+                       "terms_per_gpu": n, "total_terms": world * n, "commitments_in_flight": depth,
                        "collective": "all_gather(128 B/rank) + ordered add" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_bucket", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

@@ -26,14 +26,23 @@ def ext_bytes(pt):
 
 
 class OracleBackend:
-    def partial(self, scalars, points):
+    n_slots = 2
+
+    def __init__(self):
+        self.partials = {}
+
+    def launch_partial(self, scalars, points, slot, want_affine):
+        assert not want_affine
         acc = ed.IDENTITY
         for s, p in zip(scalars, points):
             acc = ed.pt_add(acc, ed.pt_repeat(p, s))
-        return torch.frombuffer(bytearray(ext_bytes(acc)), dtype=torch.uint8)
+        self.partials[slot] = torch.frombuffer(bytearray(ext_bytes(acc)), dtype=torch.uint8)
 
-    def commit_single(self, scalars, points):
-        raise AssertionError("not used")
+    def wait(self, slot):
+        pass
+
+    def partial_tensor(self, slot):
+        return self.partials[slot]
 
     def new_gather_buffer(self, world):
         return torch.zeros((world, 128), dtype=torch.uint8)
@@ -60,7 +69,13 @@ def worker(rank, world, port, n, ret):
     sh = parallel.ShardedMsm(None, world, rank, dist, torch, backend=OracleBackend())
     got = sh.commit([sc[i] for i in idx], [pts[i] for i in idx])
     want = ed.pt_affine(ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(sc, exps)) % ed.ELL))
-    ret[rank] = (got == want, list(idx[:3]))
+    # two commitments in flight (slots 0 and 1), finished in order
+    sc2 = [(v * 3 + 1) % ed.ELL for v in sc]
+    h0 = sh.launch([sc[i] for i in idx], [pts[i] for i in idx], 0)
+    h1 = sh.launch([sc2[i] for i in idx], [pts[i] for i in idx], 1)
+    got0, got1 = sh.finish(h0), sh.finish(h1)
+    want2 = ed.pt_affine(ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(sc2, exps)) % ed.ELL))
+    ret[rank] = (got == want and got0 == want and got1 == want2, list(idx[:3]))
     dist.barrier()
     dist.destroy_process_group()
 

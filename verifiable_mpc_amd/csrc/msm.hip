@@ -32,6 +32,12 @@
 #define MSM_MAX_C 16
 #define MSM_BLOCK 256
 #define MSM_SORT_BLOCK 1024
+#ifndef MSM_REDUCE_CHUNKS
+#define MSM_REDUCE_CHUNKS 4096
+#endif
+#ifndef MSM_REDUCE_WAVES
+#define MSM_REDUCE_WAVES 2
+#endif
 
 struct msm_plan {
     size_t n_main, n_extra, n_total;
@@ -299,7 +305,27 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
         ext_st(partial + 32 * (size_t)(seg_starts[ci] + sidx), acc);
 }
 
-// buckets that took several segments: workgroup tree over their partial sums
+// buckets that took several segments.  Lightly split ones (<= MSM_FINISH_SERIAL partial sums,
+// e.g. the under-full top window) are summed by one lane each; heavily split ones (skewed
+// scalars) by a workgroup-wide LDS tree.
+#define MSM_FINISH_SERIAL 8
+
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_bucket_finish_light(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ ctrl,
+                          const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
+                          const uint32_t *__restrict__ partial, int nb1, uint32_t *__restrict__ buckets) {
+    const uint32_t n_heavy = ctrl[0];
+    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n_heavy; h += gridDim.x * blockDim.x) {
+        uint32_t ci = heavy_list[h];
+        uint32_t ns = nseg[ci];
+        if (ns > MSM_FINISH_SERIAL) continue;
+        const uint32_t *src = partial + 32 * (size_t)seg_starts[ci];
+        ge_ext acc = ext_ld(src);
+        for (uint32_t j = 1; j < ns; j++) acc = ge_add(acc, ext_ld(src + 32 * (size_t)j));
+        ext_st(buckets + 32 * bucket_slot(ci, nb1), acc);
+    }
+}
+
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_msm_bucket_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ ctrl,
                     const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
@@ -309,6 +335,7 @@ k_msm_bucket_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__r
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         uint32_t ci = heavy_list[h];
         uint32_t ns = nseg[ci];
+        if (ns <= MSM_FINISH_SERIAL) continue;          // wave-uniform: whole workgroup skips
         const uint32_t *src = partial + 32 * (size_t)seg_starts[ci];
         ge_ext acc = ge_ext_identity();
         for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x) acc = ge_add(acc, ext_ld(src + 32 * (size_t)j));
@@ -331,7 +358,7 @@ k_msm_bucket_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__r
 // ---- reduce: sum_b b * B_b per window ---------------------------------------------------
 // thread = one chunk of `chunk_len` consecutive buckets; running sums inside the chunk,
 // chunk offset by a short double-and-add, then an LDS tree over the workgroup.
-__global__ void __launch_bounds__(MSM_BLOCK)
+__global__ void __launch_bounds__(MSM_BLOCK, MSM_REDUCE_WAVES)
 k_msm_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ counts, int nb,
              int chunks, int chunk_len, int log2_chunk_len, int red_blocks,
              uint32_t *__restrict__ partials) {
@@ -427,16 +454,32 @@ __global__ void __launch_bounds__(64)
 k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
             uint32_t *__restrict__ out_ext, uint32_t *__restrict__ out_aff) {
     __shared__ uint32_t lds[64 * 32];
-    const int w = threadIdx.x;
-    if (w < W) {
-        ge_ext r = ext_ld(partials + 32 * ((size_t)w * red_blocks));
-        for (int j = 1; j < red_blocks; j++)
-            r = ge_add(r, ext_ld(partials + 32 * ((size_t)w * red_blocks + j)));
-        // store in cached form for the cooperative additions below
-        fe_st(lds + 32 * w, fe_add(r.Y, r.X));
-        fe_st(lds + 32 * w + 8, fe_sub(r.Y, r.X));
-        fe_st(lds + 32 * w + 16, fe_mul(r.T, fe_const_d2()));
-        fe_st(lds + 32 * w + 24, fe_dbl(r.Z));
+    // phase 1: window sums.  lpw lanes share a window (strided partials), then a short tree.
+    int lpw = 1;
+    while (lpw * 2 * W <= 64 && lpw * 2 <= red_blocks) lpw *= 2;
+    {
+        const int w = threadIdx.x / lpw, sub = threadIdx.x % lpw;
+        ge_ext r = ge_ext_identity();
+        if (w < W)
+            for (int j = sub; j < red_blocks; j += lpw)
+                r = ge_add(r, ext_ld(partials + 32 * ((size_t)w * red_blocks + j)));
+        ext_st(lds + 32 * threadIdx.x, r);
+        __syncthreads();
+        for (int stride = lpw / 2; stride >= 1; stride >>= 1) {
+            if (w < W && sub < stride)
+                ext_st(lds + 32 * threadIdx.x,
+                       ge_add(ext_ld(lds + 32 * threadIdx.x), ext_ld(lds + 32 * (threadIdx.x + stride))));
+            __syncthreads();
+        }
+        ge_ext tot = ext_ld(lds + 32 * (w < W ? w * lpw : 0));
+        __syncthreads();
+        // window w's sum, in cached form for the cooperative additions, at slot w
+        if (w < W && sub == 0) {
+            fe_st(lds + 32 * w, fe_add(tot.Y, tot.X));
+            fe_st(lds + 32 * w + 8, fe_sub(tot.Y, tot.X));
+            fe_st(lds + 32 * w + 16, fe_mul(tot.T, fe_const_d2()));
+            fe_st(lds + 32 * w + 24, fe_dbl(tot.Z));
+        }
     }
     __syncthreads();
     // every quad of the wave runs the same chain redundantly (keeps EXEC full for DPP)
@@ -521,8 +564,9 @@ static void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, msm_plan
     if (S < 1) S = 1;
     p.S = S;
     p.slice_len = (p.n_total + S - 1) / S;
-    // reduce: up to 2048 chunk-threads per window, chunk length a power of two
-    int chunks = p.nb < 2048 ? p.nb : 2048;
+    // reduce: up to 8192 chunk-lanes per window (chunk length a power of two): the per-lane
+    // work is a dependency chain, so shorter chunks on more lanes cut the latency
+    int chunks = p.nb < MSM_REDUCE_CHUNKS ? p.nb : MSM_REDUCE_CHUNKS;
     p.chunks = chunks;
     p.chunk_len = p.nb / chunks;
     p.red_blocks = (chunks + MSM_BLOCK - 1) / MSM_BLOCK;
@@ -672,7 +716,10 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
     }
     {
         vmpc_stage_scope s(ctx, "msm_bucket_finish");
-        k_msm_bucket_finish<<<4 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg,
+        k_msm_bucket_finish_light<<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(
+            w.heavy_list, w.ctrl, w.nseg, w.seg_starts, w.seg_partial, p.nb1, w.buckets);
+        VMPC_KERNEL_CHECK();
+        k_msm_bucket_finish<<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg,
                                                                     w.seg_starts, w.seg_partial, p.nb1,
                                                                     w.buckets);
         VMPC_KERNEL_CHECK();

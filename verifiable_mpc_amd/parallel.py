@@ -28,43 +28,76 @@ def shard_rows(arr, world, rank):
 
 
 class HipBackend:
-    """Local MSM + ordered combine on the GPU of this process (csrc/msm.hip)."""
+    """Local MSM + ordered combine on the GPU of this process (csrc/msm.hip).
 
-    def __init__(self, ctx, torch):
-        self.ctx, self.torch = ctx, torch
-        self.partial_buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        self.out_aff = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    Two slots (two vmpc contexts = two streams + workspaces on the same GPU) let consecutive
+    commitments overlap: the latency-bound tail of one MSM (bucket reduction, Horner chain)
+    runs next to the throughput-bound head of the next."""
 
-    def partial(self, scalars, points):
-        self.ctx.msm(scalars.ptr, points.affine_ptr, len(scalars), None, None, 0,
-                     self.partial_buf.data_ptr(), None)
-        return self.partial_buf
+    def __init__(self, ctx, torch, n_slots=2):
+        from .device import get_aux_context
+        self.torch = torch
+        self.ctxs = [ctx] + ([get_aux_context()] if n_slots > 1 else [])
+        self.partial_bufs = [torch.zeros(128, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
+        self.out_affs = [torch.zeros(64, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
 
-    def commit_single(self, scalars, points):
-        self.ctx.msm(scalars.ptr, points.affine_ptr, len(scalars), None, None, 0, None,
-                     self.out_aff.data_ptr())
-        return Ed25519Point.from_affine_bytes(self.out_aff.cpu().numpy().tobytes())
+    @property
+    def n_slots(self):
+        return len(self.ctxs)
+
+    def launch_partial(self, scalars, points, slot, want_affine):
+        ctx = self.ctxs[slot]
+        if ctx is not self.ctxs[0]:
+            ctx.wait_for(self.ctxs[0])
+        ctx.msm(scalars.ptr, points.affine_ptr, len(scalars), None, None, 0,
+                None if want_affine else self.partial_bufs[slot].data_ptr(),
+                self.out_affs[slot].data_ptr() if want_affine else None)
+
+    def wait(self, slot):
+        self.ctxs[slot].sync()
+
+    def affine_result(self, slot):
+        self.ctxs[slot].sync()
+        raw = self.ctxs[slot].download(self.out_affs[slot].data_ptr(), 64).tobytes()
+        return Ed25519Point.from_affine_bytes(raw)
+
+    def partial_tensor(self, slot):
+        return self.partial_bufs[slot]
 
     def new_gather_buffer(self, world):
         return self.torch.zeros((world, 128), dtype=self.torch.uint8, device="cuda")
 
     def combine(self, gathered, world):
-        self.ctx.points_sum(gathered.data_ptr(), world, None, self.out_aff.data_ptr())
-        return Ed25519Point.from_affine_bytes(self.out_aff.cpu().numpy().tobytes())
+        ctx = self.ctxs[0]
+        ctx.points_sum(gathered.data_ptr(), world, None, self.out_affs[0].data_ptr())
+        ctx.sync()
+        return Ed25519Point.from_affine_bytes(ctx.download(self.out_affs[0].data_ptr(), 64).tobytes())
 
 
 class ShardedMsm:
-    """commit(scalars_shard, points_shard) -> the commitment over ALL ranks' shards."""
+    """commit(scalars_shard, points_shard) -> the commitment over ALL ranks' shards.
+    launch()/finish() split the call so that up to `n_slots` commitments are in flight."""
 
     def __init__(self, ctx, world, rank, dist=None, torch=None, backend=None):
         self.world, self.rank, self.dist = world, rank, dist
         self.backend = backend if backend is not None else HipBackend(ctx, torch)
         self.gathered = self.backend.new_gather_buffer(world) if world > 1 else None
 
-    def commit(self, scalars, points):
+    @property
+    def n_slots(self):
+        return getattr(self.backend, "n_slots", 1)
+
+    def launch(self, scalars, points, slot=0):
+        self.backend.launch_partial(scalars, points, slot, want_affine=self.world == 1)
+        return slot
+
+    def finish(self, slot):
         if self.world == 1:
-            return self.backend.commit_single(scalars, points)
-        mine = self.backend.partial(scalars, points)
+            return self.backend.affine_result(slot)
+        self.backend.wait(slot)
         # the single curve-point exchange: G x 128 B
-        self.dist.all_gather_into_tensor(self.gathered.view(-1), mine)
+        self.dist.all_gather_into_tensor(self.gathered.view(-1), self.backend.partial_tensor(slot))
         return self.backend.combine(self.gathered, self.world)
+
+    def commit(self, scalars, points):
+        return self.finish(self.launch(scalars, points, 0))
