@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=17, help="cpu_baseline sample size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prove", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the RCCL all-gather + ordered combine even with one rank (self-test)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one commitment in flight (default: 2, on two streams of the same GPU)")
     args = ap.parse_args()
@@ -111,9 +113,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -134,7 +137,7 @@ def main():
     exps = vm.ScalarVector.from_array(rand_scalars(rng, n))
     points = vm.PointVector.fixed_base(group.generator, exps, keep_proj=False)
     scalars = vm.ScalarVector.from_array(rand_scalars(rng, n))
-    shard = parallel.ShardedMsm(ctx, world, rank, dist, torch)
+    shard = parallel.ShardedMsm(ctx, world, rank, dist, torch, force_collective=args.force_collective)
 
     depth = 1 if args.no_pipeline else shard.n_slots
 
@@ -190,7 +193,7 @@ def main():
             "config": {"workload": f"Pedersen vector-commitment MSM, n=2^{args.log2n} Ed25519 "
                                    f"generators per GPU, uniform 252-bit scalars",
                        "terms_per_gpu": n, "total_terms": world * n, "commitments_in_flight": depth,
-                       "collective": "all_gather(128 B/rank) + ordered add" if world > 1 else "none"},
+                       "collective": "all_gather(128 B/rank) + ordered add" if shard.collective else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_bucket", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": None, "avg_kernel_ms": t_bucket * 1e3,

@@ -47,7 +47,7 @@ class OracleBackend:
     def new_gather_buffer(self, world):
         return torch.zeros((world, 128), dtype=torch.uint8)
 
-    def combine(self, gathered, world):
+    def combine(self, gathered, world, slot=0):
         acc = ed.IDENTITY
         raw = gathered.numpy().tobytes()
         for r in range(world):          # rank order

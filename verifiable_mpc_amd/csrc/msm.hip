@@ -32,6 +32,10 @@
 #define MSM_MAX_C 16
 #define MSM_BLOCK 256
 #define MSM_SORT_BLOCK 1024
+// niels record stride in 32-bit words: 24 = packed 96 B, 32 = one 128-B line per gather
+#ifndef MSM_NIELS_STRIDE
+#define MSM_NIELS_STRIDE 24
+#endif
 #ifndef MSM_REDUCE_CHUNKS
 #define MSM_REDUCE_CHUNKS 4096
 #endif
@@ -93,7 +97,7 @@ k_msm_prep(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__re
     a.x = fe_ld(src);
     a.y = fe_ld(src + 8);
     ge_niels q = ge_niels_from_affine(a);
-    uint32_t *dst = niels + 24 * i;
+    uint32_t *dst = niels + MSM_NIELS_STRIDE * i;
     fe_st(dst, q.ymx);
     fe_st(dst + 8, q.ypx);
     fe_st(dst + 16, q.t2d);
@@ -264,7 +268,7 @@ k_msm_plan2(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nbloc
 }
 
 __device__ __forceinline__ ge_niels niels_ld(const uint32_t *niels, uint32_t e) {
-    const uint32_t *src = niels + 24 * (size_t)(e & 0x7fffffffu);
+    const uint32_t *src = niels + MSM_NIELS_STRIDE * (size_t)(e & 0x7fffffffu);
     ge_niels q;
     q.ymx = fe_ld(src);
     q.ypx = fe_ld(src + 8);
@@ -591,7 +595,7 @@ static void msm_layout(const msm_plan &p, msm_ws &w, char *base) {
         return base ? (void *)(base + o) : (void *)nullptr;
     };
     size_t nbk = (size_t)p.W * p.nb1;
-    w.niels = (uint32_t *)take(p.n_total * 96);
+    w.niels = (uint32_t *)take(p.n_total * (MSM_NIELS_STRIDE * 4));
     w.digits = (int16_t *)take((size_t)p.W * p.n_total * 2);
     w.hist = (uint32_t *)take((size_t)p.W * p.S * p.nb1 * 4);
     w.counts = (uint32_t *)take(nbk * 4);

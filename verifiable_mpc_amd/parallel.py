@@ -39,27 +39,28 @@ class HipBackend:
         self.torch = torch
         self.ctxs = [ctx] + ([get_aux_context()] if n_slots > 1 else [])
         self.partial_bufs = [torch.zeros(128, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
-        self.out_affs = [torch.zeros(64, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
+        self.combine_bufs = [torch.zeros(128, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
 
     @property
     def n_slots(self):
         return len(self.ctxs)
 
     def launch_partial(self, scalars, points, slot, want_affine):
+        # the partial (or, single-GPU, final) sum stays in extended coordinates on the device;
+        # normalising one point is O(1) host glue
         ctx = self.ctxs[slot]
         if ctx is not self.ctxs[0]:
             ctx.wait_for(self.ctxs[0])
         ctx.msm(scalars.ptr, points.affine_ptr, len(scalars), None, None, 0,
-                None if want_affine else self.partial_bufs[slot].data_ptr(),
-                self.out_affs[slot].data_ptr() if want_affine else None)
+                self.partial_bufs[slot].data_ptr(), None)
 
     def wait(self, slot):
         self.ctxs[slot].sync()
 
     def affine_result(self, slot):
         self.ctxs[slot].sync()
-        raw = self.ctxs[slot].download(self.out_affs[slot].data_ptr(), 64).tobytes()
-        return Ed25519Point.from_affine_bytes(raw)
+        raw = self.ctxs[slot].download(self.partial_bufs[slot].data_ptr(), 96).tobytes()
+        return Ed25519Point.from_proj_bytes(raw).normalize()
 
     def partial_tensor(self, slot):
         return self.partial_bufs[slot]
@@ -67,37 +68,44 @@ class HipBackend:
     def new_gather_buffer(self, world):
         return self.torch.zeros((world, 128), dtype=self.torch.uint8, device="cuda")
 
-    def combine(self, gathered, world):
-        ctx = self.ctxs[0]
-        ctx.points_sum(gathered.data_ptr(), world, None, self.out_affs[0].data_ptr())
+    def combine(self, gathered, world, slot=0):
+        # on the slot's own (now idle) stream, into its own buffer: never queued behind or
+        # overwriting another commitment in flight
+        ctx = self.ctxs[slot]
+        ctx.points_sum(gathered.data_ptr(), world, self.combine_bufs[slot].data_ptr(), None)
         ctx.sync()
-        return Ed25519Point.from_affine_bytes(ctx.download(self.out_affs[0].data_ptr(), 64).tobytes())
+        raw = ctx.download(self.combine_bufs[slot].data_ptr(), 96).tobytes()
+        return Ed25519Point.from_proj_bytes(raw).normalize()
 
 
 class ShardedMsm:
     """commit(scalars_shard, points_shard) -> the commitment over ALL ranks' shards.
     launch()/finish() split the call so that up to `n_slots` commitments are in flight."""
 
-    def __init__(self, ctx, world, rank, dist=None, torch=None, backend=None):
+    def __init__(self, ctx, world, rank, dist=None, torch=None, backend=None, force_collective=False):
         self.world, self.rank, self.dist = world, rank, dist
         self.backend = backend if backend is not None else HipBackend(ctx, torch)
-        self.gathered = self.backend.new_gather_buffer(world) if world > 1 else None
+        self.collective = world > 1 or force_collective
+        self.sync_device = torch.cuda.synchronize if (torch is not None and backend is None) else None
+        self.gathered = self.backend.new_gather_buffer(world) if self.collective else None
 
     @property
     def n_slots(self):
         return getattr(self.backend, "n_slots", 1)
 
     def launch(self, scalars, points, slot=0):
-        self.backend.launch_partial(scalars, points, slot, want_affine=self.world == 1)
+        self.backend.launch_partial(scalars, points, slot, want_affine=not self.collective)
         return slot
 
     def finish(self, slot):
-        if self.world == 1:
+        if not self.collective:
             return self.backend.affine_result(slot)
-        self.backend.wait(slot)
+        self.backend.wait(slot)                     # partial point is complete
         # the single curve-point exchange: G x 128 B
         self.dist.all_gather_into_tensor(self.gathered.view(-1), self.backend.partial_tensor(slot))
-        return self.backend.combine(self.gathered, self.world)
+        if self.sync_device:
+            self.sync_device()                      # RCCL runs on torch's stream, the combine on ours
+        return self.backend.combine(self.gathered, self.world, slot)
 
     def commit(self, scalars, points):
         return self.finish(self.launch(scalars, points, 0))
