@@ -136,6 +136,13 @@ int vmpc_affine_to_proj_dev(vmpc_ctx *ctx, const void *affine, size_t n, void *o
 int vmpc_fr_axpy_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *x, const void *y, size_t n,
                      void *out);
 int vmpc_fr_scale_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *x, size_t n, void *out);
+/* out[j] = z[j mod 2^low_bits] * prod_{i < rounds} (c_i if bit (low_bits+rounds-1-i) of j is 0
+ * else 1), n = 2^(rounds+low_bits) <= 2^40, rounds <= 20; challenges = rounds x 32 bytes (host).
+ * These are the coefficients of `rounds` applications of the fold of compressed_pivot.py:64
+ * written as one linear map, so that the verifier's final check (compressed_pivot.py:193) becomes
+ * a single N-term MSM over the original generators (used by the compact transcript only). */
+int vmpc_fr_challenge_products_dev(vmpc_ctx *ctx, const uint8_t *challenges, int rounds, int low_bits,
+                                   const void *z, size_t n, void *out);
 /* synchronous: result copied to host */
 int vmpc_fr_dot_dev(vmpc_ctx *ctx, const void *a, const void *b, size_t n, uint8_t out[32]);
 

@@ -32,7 +32,7 @@ SYMBOLS = [
     "vmpc_msm_dev", "vmpc_points_sum_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
     "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
-    "vmpc_sha256_chunks_dev",
+    "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev",
 ]
 
 
@@ -92,6 +92,7 @@ def load_library():
         "vmpc_format_points_dev": (i32, [vp, vp, sz, vp, sz, u64p]),
         "vmpc_format_scalars_dev": (i32, [vp, vp, sz, i32, vp, sz, u64p]),
         "vmpc_sha256_chunks_dev": (i32, [vp, vp, sz, sz, vp]),
+        "vmpc_fr_challenge_products_dev": (i32, [vp, vp, i32, i32, vp, sz, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the export is missing
@@ -346,6 +347,15 @@ class Context:
         cb = ctypes.create_string_buffer(scalar_to_bytes(c), 32)
         _check(self.lib.vmpc_fr_scale_dev(self.handle, cb, ctypes.c_void_p(x_ptr), n,
                                           ctypes.c_void_p(out_ptr)), "vmpc_fr_scale_dev")
+
+    def fr_challenge_products(self, challenges, low_bits, z_ptr, out_ptr):
+        rounds = len(challenges)
+        buf = ctypes.create_string_buffer(b"".join(scalar_to_bytes(c) for c in challenges), 32 * max(rounds, 1))
+        n = 1 << (rounds + low_bits)
+        _check(self.lib.vmpc_fr_challenge_products_dev(self.handle, buf, rounds, low_bits,
+                                                       ctypes.c_void_p(z_ptr), n,
+                                                       ctypes.c_void_p(out_ptr)),
+               "vmpc_fr_challenge_products_dev")
 
     def fr_dot(self, a_ptr, b_ptr, n):
         out = ctypes.create_string_buffer(32)

@@ -184,7 +184,7 @@ def _fold_commitment(A, Q, B, c):
     return _gmul(_gmul(A, _gpow(Q, c)), _gpow(B, c * c))
 
 
-def _unfold_commitment(Q0, rounds, order):
+def _unfold_commitment(Q0, rounds, order, ctx=None):
     """Q_R from Q' = A * Q**c * B**(c**2) applied R times, as ONE (2R+1)-term MSM:
     Q_R = (prod_j c_j) Q_0 + sum_i (prod_{j>i} c_j) (A_i + c_i^2 B_i)."""
     scalars, points = [], []
@@ -195,8 +195,9 @@ def _unfold_commitment(Q0, rounds, order):
         suffix = suffix * c % order
     scalars.append(suffix)
     points.append(Q0)
-    return pivot.vector_commitment(scalars, 0, PointVector.from_points(points, keep_proj=False),
-                                   Ed25519Point.identity)
+    pv = PointVector.from_points(points, ctx, keep_proj=False)
+    return pivot._commit_launch(ScalarVector.from_ints(scalars, pv.ctx), 0, pv, Ed25519Point.identity,
+                                pv.ctx).result()
 
 
 def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, transcript=None):
@@ -233,12 +234,54 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
         round_i += 1
 
 
+def _protocol_4_verifier_compact(g_hat, k, Q, L_tilde, gf, proof, round_i, transcript):
+    """Compact-transcript verifier without materialising any folded vector.
+
+    The challenges only depend on (state, A_i, B_i), so they are all known up front; R folds of
+    g_hat and L_tilde (compressed_pivot.py:178,185-188) are one linear map with coefficients
+    s[j] = prod_i (c_i if the i-th index bit from the top is 0), hence the final check
+    (:193-197)  z'_0 g'_0 + z'_1 g'_1 + L'(z') k == Q_R  is ONE N-term MSM with scalars
+    v[j] = z'_{j mod 2} s[j], gamma = <v, L_tilde>, and Q_R is the (2R+1)-term MSM of
+    _unfold_commitment.  Same accept/reject decision as the round-by-round verifier."""
+    order = transcript.order
+    N = len(g_hat)
+    rounds, deferred = [], []
+    m = N
+    while True:
+        A = _pt(proof["A" + str(round_i)])
+        B = _pt(proof["B" + str(round_i)])
+        c = transcript.round_challenge(round_i, A, B, None, k, Q, None)
+        rounds.append(c)
+        deferred.append((A, B, c))
+        m //= 2
+        if m <= 2:
+            break
+        round_i += 1
+    z_prime = proof["z_prime"]
+    low_bits = (len(z_prime) - 1).bit_length()
+    if N != (1 << (len(rounds) + low_bits)) or len(z_prime) != (1 << low_bits):
+        return False
+    ctx = g_hat.ctx
+    zp = ScalarVector.from_ints([pivot._residue(v) for v in z_prime], ctx)
+    v = ScalarVector.empty(N, ctx)
+    ctx.fr_challenge_products(rounds, low_bits, zp.ptr, v.ptr)
+    gamma = v.dot(_coeffs_dev(L_tilde))
+    from .device import get_aux_context
+    aux = get_aux_context()
+    aux.wait_for(ctx)
+    pending = pivot._commit_launch(v, gamma, g_hat, k, ctx)
+    Q_final = _unfold_commitment(Q, deferred, order, aux)
+    return bool(pending.result() == Q_final)
+
+
 def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=None):
     """Non-interactive Protocol 4, verifier (compressed_pivot.py:148-202)."""
     g_hat = pivot._points_on_device(g_hat)
     k, Q = _pt(k), _pt(Q)
     if not isinstance(transcript, _Transcript):
         transcript = _Transcript(transcript or "reference", k.order)
+    if transcript.mode == "compact" and len(g_hat) >= 4 and (len(g_hat) & (len(g_hat) - 1)) == 0:
+        return _protocol_4_verifier_compact(g_hat, k, Q, L_tilde, gf, proof, round_i, transcript)
     deferred = []            # compact mode: (A_i, B_i, c_i), Q unfolded once at the end
     while True:
         half = len(g_hat) // 2

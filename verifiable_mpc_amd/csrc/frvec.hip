@@ -87,6 +87,33 @@ k_fr_check(const uint32_t *__restrict__ v, size_t n, uint32_t *__restrict__ stat
     }
 }
 
+// v[j] = z[j mod 2^low_bits] * prod_{i<R} (c_i if bit (low_bits + R - 1 - i) of j is 0 else 1)
+// The generator fold g' = c*g_l + g_r (compressed_pivot.py:64) applied R times to a vector of
+// 2^(R+low_bits) elements is the linear map  g_final[t] = sum_{j = t mod 2^low_bits} s[j] * g[j]
+// with these coefficients: round i multiplies the LEFT half (top remaining index bit 0) by c_i.
+// Lets a verifier (or the prover's short tail) replace R element-wise folds by one MSM.
+struct fr_chal_arg {
+    uint32_t c[20][8];
+};
+__global__ void __launch_bounds__(FR_BLOCK)
+k_fr_challenge_products(fr_chal_arg ch, int R, int low_bits, const uint32_t *__restrict__ z,
+                        size_t n, uint32_t *__restrict__ out) {
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+         j += (size_t)gridDim.x * blockDim.x) {
+        fr acc = frv_ld(z + 8 * (j & (((size_t)1 << low_bits) - 1)));
+        for (int i = 0; i < R; i++) {
+            int bit = low_bits + R - 1 - i;
+            if (((j >> bit) & 1) == 0) {
+                fr c;
+#pragma unroll
+                for (int k = 0; k < 8; k++) c.v[k] = ch.c[i][k];
+                acc = fr_mul(acc, c);
+            }
+        }
+        frv_st(out + 8 * j, acc);
+    }
+}
+
 static inline unsigned fr_grid(size_t n) {
     size_t g = (n + FR_BLOCK - 1) / FR_BLOCK;
     return (unsigned)(g > FR_MAX_GRID ? FR_MAX_GRID : (g ? g : 1));
@@ -137,6 +164,27 @@ extern "C" int vmpc_fr_dot_dev(vmpc_ctx *ctx, const void *a, const void *b, size
     }
     VMPC_HIP_CHECK(hipMemcpyAsync(out, res, 32, hipMemcpyDeviceToHost, ctx->stream));
     VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_fr_challenge_products_dev(vmpc_ctx *ctx, const uint8_t *challenges, int rounds,
+                                              int low_bits, const void *z, size_t n, void *out) {
+    if (!ctx || rounds < 0 || rounds > 20 || low_bits < 0 || low_bits > 40 || (rounds && !challenges) ||
+        (n && (!z || !out)))
+        return VMPC_E_INVAL;
+    if (n != ((size_t)1 << (rounds + low_bits))) return VMPC_E_INVAL;
+    fr_chal_arg a;
+    memset(&a, 0, sizeof a);
+    for (int i = 0; i < rounds; i++) {
+        memcpy(a.c[i], challenges + 32 * i, 32);
+        if (fr_geq_l(a.c[i])) return VMPC_E_NONCANON;
+    }
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    vmpc_stage_scope s(ctx, "fr_challenge_products");
+    k_fr_challenge_products<<<fr_grid(n), FR_BLOCK, 0, ctx->stream>>>(a, rounds, low_bits,
+                                                                       (const uint32_t *)z, n,
+                                                                       (uint32_t *)out);
+    VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }
 
