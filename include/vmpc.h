@@ -143,6 +143,11 @@ int vmpc_fr_scale_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *x, size_t 
  * a single N-term MSM over the original generators (used by the compact transcript only). */
 int vmpc_fr_challenge_products_dev(vmpc_ctx *ctx, const uint8_t *challenges, int rounds, int low_bits,
                                    const void *z, size_t n, void *out);
+/* Scalars of A_i / B_i (compressed_pivot.py:41-42) expressed over a base vector of 2^log2_m0
+ * generators to which the last t folds (challenges c_0..c_{t-1}, host, 32 B each) have not been
+ * applied; z is the current witness of 2^(log2_m0 - t) scalars.  out_a / out_b: 2^log2_m0 scalars. */
+int vmpc_fr_tail_scalars_dev(vmpc_ctx *ctx, const uint8_t *challenges, int t, int log2_m0,
+                             const void *z, void *out_a, void *out_b);
 /* synchronous: result copied to host */
 int vmpc_fr_dot_dev(vmpc_ctx *ctx, const void *a, const void *b, size_t n, uint8_t out[32]);
 

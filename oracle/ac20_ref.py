@@ -280,8 +280,8 @@ def protocol_5_prover(generators, P, coeffs, constant, y, x, gamma, r, rho,
     Lt = [(c * c1) % ELL for c in coeffs] + [0]                                  # :141
     assert form_eval(coeffs, 0, z) * c1 % ELL == _dot(Lt, z_hat)                 # :142
     if mode != "reference":
-        state = hashlib.sha256(b"vmpc-ac20/p4/v1" + seed + ed.affine_to_bytes(k)
-                               + ed.affine_to_bytes(Q)).digest()
+        # Q is a function of values already bound by `seed`; it is not hashed again
+        state = hashlib.sha256(b"vmpc-ac20/p4/v2" + seed + ed.affine_to_bytes(k)).digest()
     if trace is not None:
         trace.update({"c0": c0, "c1": c1, "Q0": Q})
     return protocol_4_prover(g_hat, k, Q, Lt, z_hat, proof, mode, state, trace,
@@ -333,6 +333,5 @@ def protocol_5_verifier(generators, P, coeffs, constant, y, proof, mode="referen
                   ed.pt_repeat(k, ed.scalar_int(c1 * (c0 * y + t))))
     Lt = [(c * c1) % ELL for c in coeffs] + [0]
     if mode != "reference":
-        state = hashlib.sha256(b"vmpc-ac20/p4/v1" + seed + ed.affine_to_bytes(k)
-                               + ed.affine_to_bytes(Q)).digest()
+        state = hashlib.sha256(b"vmpc-ac20/p4/v2" + seed + ed.affine_to_bytes(k)).digest()
     return protocol_4_verifier(g_hat, k, Q, Lt, proof, mode, state, _lt_raw(coeffs_raw, c1))

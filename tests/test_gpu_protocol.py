@@ -276,3 +276,40 @@ def test_reference_error_conventions(vm):
         vm.create_generators(3, vm.PivotChoice.koe, group)
     with pytest.raises(NotImplementedError):
         vm.EllipticCurve("BN256")
+
+
+def test_mpc_local_commitment_shares(vm):
+    """mpc_ac20.vector_commitment's local step (mpc_ac20.py:35-42): three parties, threshold 1;
+    the product of the per-party elements equals the plain commitment of the secret vector."""
+    from verifiable_mpc_amd import mpc_ac20
+    rng = random.Random(31)
+    n, parties, threshold = 40, 3, 1
+    group = vm.EllipticCurve("Ed25519", "projective")
+    g = vm.PointVector.fixed_base(group.generator, [rng.randrange(1, ELL) for _ in range(n)])
+    h = group.generator
+    x = [rng.randrange(ELL) for _ in range(n)]
+    gamma = rng.randrange(ELL)
+    shares = mpc_ac20.shamir_shares(x + [gamma], threshold, parties, rng)
+    lam = mpc_ac20.recombination_vector([1, 2, 3])
+    assert [sum(l * s[i] for l, s in zip(lam, shares)) % ELL for i in range(n + 1)] == x + [gamma]
+    parts = [mpc_ac20.local_commitment_share(shares[p][:n], shares[p][n], g, h, lam[p])
+             for p in range(parties)]
+    want = vm.pivot.vector_commitment(x, gamma, g, h)
+    assert mpc_ac20.combine_commitment_shares(parts) == want
+    assert want.coords[:2] == ed.pt_affine(ac.vector_commitment(
+        x, gamma, [p.coords for p in g.to_points()], h.coords))
+
+
+def test_proof_survives_the_wire(vm, golden_small, monkeypatch):
+    from verifiable_mpc_amd import wire
+    case = golden_small["p5"][2]
+    group, gens = build_generators(vm, case, monkeypatch, case["seed"] + 1)
+    gf = vm.GF(group.order)
+    x = [gf(h2i(v)) for v in case["x"]]
+    L = vm.pivot.LinearForm([gf(h2i(v)) for v in case["L"]])
+    gamma, y = h2i(case["gamma"]), gf(h2i(case["y"]))
+    P = vm.pivot.vector_commitment(x, gamma, gens["g"], gens["h"])
+    proof = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, gamma, gf)
+    back, mode = wire.deserialize_proof(wire.serialize_proof(proof), gf)
+    assert mode == "reference"
+    assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, back, gf) is True

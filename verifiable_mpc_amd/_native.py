@@ -32,7 +32,7 @@ SYMBOLS = [
     "vmpc_msm_dev", "vmpc_points_sum_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
     "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
-    "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev",
+    "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev",
 ]
 
 
@@ -93,6 +93,7 @@ def load_library():
         "vmpc_format_scalars_dev": (i32, [vp, vp, sz, i32, vp, sz, u64p]),
         "vmpc_sha256_chunks_dev": (i32, [vp, vp, sz, sz, vp]),
         "vmpc_fr_challenge_products_dev": (i32, [vp, vp, i32, i32, vp, sz, vp]),
+        "vmpc_fr_tail_scalars_dev": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the export is missing
@@ -356,6 +357,13 @@ class Context:
                                                        ctypes.c_void_p(z_ptr), n,
                                                        ctypes.c_void_p(out_ptr)),
                "vmpc_fr_challenge_products_dev")
+
+    def fr_tail_scalars(self, challenges, log2_m0, z_ptr, out_a_ptr, out_b_ptr):
+        t = len(challenges)
+        buf = ctypes.create_string_buffer(b"".join(scalar_to_bytes(c) for c in challenges), 32 * max(t, 1))
+        _check(self.lib.vmpc_fr_tail_scalars_dev(self.handle, buf, t, log2_m0, ctypes.c_void_p(z_ptr),
+                                                 ctypes.c_void_p(out_a_ptr), ctypes.c_void_p(out_b_ptr)),
+               "vmpc_fr_tail_scalars_dev")
 
     def fr_dot(self, a_ptr, b_ptr, n):
         out = ctypes.create_string_buffer(32)

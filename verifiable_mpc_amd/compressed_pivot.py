@@ -40,6 +40,10 @@ logger_cp_hout.setLevel(logging.INFO)
 
 TRANSCRIPT = "reference"
 CHUNK = 4096
+# compact transcript, device mode: once the vector is this short the generator fold is pure
+# latency (a 253-doubling chain per round); the remaining rounds keep the generators fixed and
+# put the challenge products into the MSM scalars instead (csrc/frvec.hip k_fr_tail_scalars)
+TAIL_BASE = 1 << 16
 
 
 # ---- group glue on single elements (independent of the is_additive/is_multiplicative flags) ----
@@ -193,8 +197,10 @@ def _unfold_commitment(Q0, rounds, order, ctx=None):
         scalars += [suffix, suffix * c * c % order]
         points += [A, B]
         suffix = suffix * c % order
-    scalars.append(suffix)
-    points.append(Q0)
+    q_terms = Q0.terms if isinstance(Q0, _LazyQ) else [(1, Q0)]
+    for sc, pt in q_terms:
+        scalars.append(suffix * sc % order)
+        points.append(pt)
     pv = PointVector.from_points(points, ctx, keep_proj=False)
     return pivot._commit_launch(ScalarVector.from_ints(scalars, pv.ctx), 0, pv, Ed25519Point.identity,
                                 pv.ctx).result()
@@ -204,22 +210,41 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
     """Non-interactive Protocol 4, prover (compressed_pivot.py:29-86); the reference's
     recursion is a loop here, `round_i` keeps its meaning."""
     g_hat = pivot._points_on_device(g_hat)
-    k, Q = _pt(k), _pt(Q)
+    k = _pt(k)
+    Q = Q if isinstance(Q, _LazyQ) else _pt(Q)
     if not isinstance(transcript, _Transcript):
         transcript = _Transcript(transcript or "reference", k.order)
+    if transcript.mode == "reference" and isinstance(Q, _LazyQ):
+        Q = Q.point()
+    tail_cs = None           # challenges not yet applied to g_hat (compact tail)
     while True:
-        half = len(g_hat) // 2
-        g_l, g_r = g_hat[:half], g_hat[half:]
+        if _on_device(L_tilde.coeffs, z_hat):
+            z_hat = pivot._as_device(z_hat)
+        m = len(z_hat)
+        half = m // 2
         z_l, z_r, gamma_a, gamma_b = _round_prover_scalars(L_tilde, z_hat, half, gf)
         logger_cp.debug("Calculate A_i, B_i.")
-        A, B = pivot.vector_commitment_pair(z_l, gamma_a, g_r, z_r, gamma_b, g_l, k)
+        if tail_cs is None and transcript.mode == "compact" and isinstance(z_l, ScalarVector) \
+                and len(g_hat) <= TAIL_BASE and len(g_hat) == m and m >= 4:
+            tail_cs = []
+        if tail_cs is not None:
+            ctx = g_hat.ctx
+            v_a, v_b = ScalarVector.empty(len(g_hat), ctx), ScalarVector.empty(len(g_hat), ctx)
+            ctx.fr_tail_scalars(tail_cs, len(g_hat).bit_length() - 1, z_hat.ptr, v_a.ptr, v_b.ptr)
+            A, B = pivot.vector_commitment_pair(v_a, gamma_a, g_hat, v_b, gamma_b, g_hat, k)
+        else:
+            g_l, g_r = g_hat[:half], g_hat[half:]
+            A, B = pivot.vector_commitment_pair(z_l, gamma_a, g_r, z_r, gamma_b, g_l, k)
         proof["A" + str(round_i)] = A
         proof["B" + str(round_i)] = B
 
         c = transcript.round_challenge(round_i, A, B, g_hat, k, Q, L_tilde)
         logger_cp_hout.debug(f"After hash, hash=\n{c}")
 
-        g_hat = g_l.fold(g_r, c)
+        if tail_cs is not None:
+            tail_cs.append(c)
+        else:
+            g_hat = g_l.fold(g_r, c)
         if transcript.mode == "reference":
             # only the reference pre-image contains Q (compressed_pivot.py:52); the compact
             # chain binds Q once at the start, so the prover need not track it
@@ -277,11 +302,14 @@ def _protocol_4_verifier_compact(g_hat, k, Q, L_tilde, gf, proof, round_i, trans
 def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=None):
     """Non-interactive Protocol 4, verifier (compressed_pivot.py:148-202)."""
     g_hat = pivot._points_on_device(g_hat)
-    k, Q = _pt(k), _pt(Q)
+    k = _pt(k)
+    Q = Q if isinstance(Q, _LazyQ) else _pt(Q)
     if not isinstance(transcript, _Transcript):
         transcript = _Transcript(transcript or "reference", k.order)
     if transcript.mode == "compact" and len(g_hat) >= 4 and (len(g_hat) & (len(g_hat) - 1)) == 0:
         return _protocol_4_verifier_compact(g_hat, k, Q, L_tilde, gf, proof, round_i, transcript)
+    if transcript.mode == "reference" and isinstance(Q, _LazyQ):
+        Q = Q.point()
     deferred = []            # compact mode: (A_i, B_i, c_i), Q unfolded once at the end
     while True:
         half = len(g_hat) // 2
@@ -321,12 +349,27 @@ def _p5_challenges(mode, order, generators, t, A, P, L, y):
     return c0, c1, seed
 
 
-def _p5_setup(generators, k, Q, seed, mode, order):
+def _p5_setup(generators, k, seed, mode, order):
     if mode == "reference":
         return _Transcript(mode, order)
-    state = hashlib.sha256(b"vmpc-ac20/p4/v1" + seed + k.to_affine_bytes()
-                           + Q.to_affine_bytes()).digest()
+    # Q = A * P^c0 * k^(c1 (c0 y + t)) is a function of values the seed already binds
+    state = hashlib.sha256(b"vmpc-ac20/p4/v2" + seed + k.to_affine_bytes()).digest()
     return _Transcript(mode, order, state)
+
+
+class _LazyQ:
+    """Q_0 = A * P^c0 * k^e kept as (scalar, point) terms: the compact prover never needs the
+    point, the compact verifier folds the terms into its final MSM."""
+
+    def __init__(self, A, P, k, c0, e, order):
+        self.terms = [(1, A), (c0 % order, P), (e % order, k)]
+
+    def point(self):
+        acc = None
+        for sc, pt in self.terms:
+            term = pt if sc == 1 else _gpow(pt, sc)
+            acc = term if acc is None else _gmul(acc, term)
+        return acc
 
 
 def _extend_form(L, c1):
@@ -385,12 +428,14 @@ def protocol_5_prover(generators, P, L, y, x, gamma, gf, transcript=None, r=None
     z_hat = z + [phi]
     g_hat = gv + [h]
     logger_cp.debug("Calculate Q.")
-    Q = _gmul(_gmul(A, _gpow(P, c0)), _gpow(k, int(c1 * (c0 * y + t))))
+    Q = _LazyQ(A, P, k, c0, int(c1 * (c0 * y + t)), order)
+    if mode == "reference":
+        Q = Q.point()
     L_tilde = _extend_form(L, c1)
     assert _same_residue(L(z) * c1, L_tilde(z_hat), order)
 
     return protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof,
-                             transcript=_p5_setup(generators, k, Q, seed, mode, order))
+                             transcript=_p5_setup(generators, k, seed, mode, order))
 
 
 def protocol_5_verifier(generators, P, L, y, proof, gf, transcript=None):
@@ -407,7 +452,9 @@ def protocol_5_verifier(generators, P, L, y, proof, gf, transcript=None):
                      "h": generators["h"], "k": generators["k"]}
     c0, c1, seed = _p5_challenges(mode, order, gens_for_hash, t, A, P, L, y)
     g_hat = pivot._points_on_device(g) + [h]
-    Q = _gmul(_gmul(A, _gpow(P, c0)), _gpow(k, int(c1 * (c0 * y + t))))
+    Q = _LazyQ(A, P, k, c0, int(c1 * (c0 * y + t)), order)
+    if mode == "reference":
+        Q = Q.point()
     L_tilde = _extend_form(L, c1)
     return protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof,
-                               transcript=_p5_setup(generators, k, Q, seed, mode, order))
+                               transcript=_p5_setup(generators, k, seed, mode, order))

@@ -8,6 +8,8 @@
 //   vmpc_normalize_dev    .normalize() over a vector        compressed_pivot.py:52,118
 // One lane per element; 96-B / 64-B elements are moved with 16-B accesses.  The fold has a
 // wave-uniform scalar (no divergence); repeat predicates per lane.
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "fe25519.cuh"
 #include "fr.cuh"
@@ -15,6 +17,8 @@
 #include "quad.cuh"
 
 #define EX_BLOCK 256
+// vectors up to this many elements use four lanes per element (latency-bound regime)
+#define EX_FOLD_QUAD_MAX (16 * 1024)
 
 __device__ __forceinline__ fe ex_fe_ld(const uint32_t *src) {
     const uint4 *p = reinterpret_cast<const uint4 *>(src);
@@ -62,14 +66,16 @@ struct u256_arg {
 };
 
 // ---- fold ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EX_BLOCK)
+#ifndef EX_FOLD_WAVES
+#define EX_FOLD_WAVES 2
+#endif
+__global__ void __launch_bounds__(EX_BLOCK, EX_FOLD_WAVES)
 k_fold(const uint32_t *__restrict__ gl, const uint32_t *__restrict__ gr, int in_affine, u256_arg c,
        size_t half, uint32_t *__restrict__ out_proj, uint32_t *__restrict__ out_aff) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
-    ge_proj a = ex_load_point(gl, i, in_affine != 0);
-    ge_proj b = ex_load_point(gr, i, in_affine != 0);
-    ge_proj r = ge_proj_add(ge_proj_repeat(a, c.v), b);  // (g_l ** c) * g_r
+    ge_proj r = ge_proj_repeat(ex_load_point(gl, i, in_affine != 0), c.v);   // g_l ** c
+    r = ge_proj_add(r, ex_load_point(gr, i, in_affine != 0));                // * g_r (loaded late)
     ex_store_point(r, i, out_proj, out_aff);
 }
 
@@ -231,7 +237,11 @@ extern "C" int vmpc_fold_dev(vmpc_ctx *ctx, const void *g_l, const void *g_r, in
     memcpy(ca.v, c, 32);
     if (fr_geq_l(ca.v)) return VMPC_E_NONCANON;
     vmpc_stage_scope s(ctx, "fold");
-    if (half <= (size_t)64 * 1024)
+    static const size_t quad_max = [] {
+        const char *e = getenv("VMPC_FOLD_QUAD_MAX");
+        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)EX_FOLD_QUAD_MAX;
+    }();
+    if (half <= quad_max)
         k_fold_quad<<<ex_grid(4 * half), EX_BLOCK, 0, ctx->stream>>>(
             (const uint32_t *)g_l, (const uint32_t *)g_r, in_affine, ca, half, (uint32_t *)out_proj,
             (uint32_t *)out_affine);

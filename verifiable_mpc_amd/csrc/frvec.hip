@@ -114,6 +114,36 @@ k_fr_challenge_products(fr_chal_arg ch, int R, int low_bits, const uint32_t *__r
     }
 }
 
+// Scalars of A_i and B_i (compressed_pivot.py:41-42) over a FIXED base vector g0 of 2^log2_m0
+// generators when the last t folds have NOT been applied to the generators: with
+// s[j] = prod_{r<t} (c_r if bit (log2_m0-1-r) of j is 0 else 1), m = 2^log2_m0 / 2^t, h = m/2,
+//   A = sum_j [ (j mod m) >= h ] * z[(j mod m) - h] * s[j] * g0[j]
+//   B = sum_j [ (j mod m) <  h ] * z[(j mod m) + h] * s[j] * g0[j]
+// (zeros are skipped by the MSM's digit sort).  Lets the short tail of Protocol 4 skip the
+// element-wise generator fold, whose 253-doubling chain is pure latency there.
+__global__ void __launch_bounds__(FR_BLOCK)
+k_fr_tail_scalars(fr_chal_arg ch, int t, int log2_m0, const uint32_t *__restrict__ z,
+                  uint32_t *__restrict__ out_a, uint32_t *__restrict__ out_b) {
+    const size_t m0 = (size_t)1 << log2_m0;
+    const size_t m = m0 >> t, h = m >> 1;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m0;
+         j += (size_t)gridDim.x * blockDim.x) {
+        size_t u = j & (m - 1);
+        bool right = u >= h;
+        fr acc = frv_ld(z + 8 * (right ? u - h : u + h));
+        for (int r = 0; r < t; r++) {
+            if (((j >> (log2_m0 - 1 - r)) & 1) == 0) {
+                fr c;
+#pragma unroll
+                for (int k = 0; k < 8; k++) c.v[k] = ch.c[r][k];
+                acc = fr_mul(acc, c);
+            }
+        }
+        frv_st(out_a + 8 * j, right ? acc : fr_zero());
+        frv_st(out_b + 8 * j, right ? fr_zero() : acc);
+    }
+}
+
 static inline unsigned fr_grid(size_t n) {
     size_t g = (n + FR_BLOCK - 1) / FR_BLOCK;
     return (unsigned)(g > FR_MAX_GRID ? FR_MAX_GRID : (g ? g : 1));
@@ -184,6 +214,25 @@ extern "C" int vmpc_fr_challenge_products_dev(vmpc_ctx *ctx, const uint8_t *chal
     k_fr_challenge_products<<<fr_grid(n), FR_BLOCK, 0, ctx->stream>>>(a, rounds, low_bits,
                                                                        (const uint32_t *)z, n,
                                                                        (uint32_t *)out);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_fr_tail_scalars_dev(vmpc_ctx *ctx, const uint8_t *challenges, int t, int log2_m0,
+                                        const void *z, void *out_a, void *out_b) {
+    if (!ctx || t < 0 || t > 20 || log2_m0 < 1 || log2_m0 > 40 || t >= log2_m0 || (t && !challenges) ||
+        !z || !out_a || !out_b)
+        return VMPC_E_INVAL;
+    fr_chal_arg a;
+    memset(&a, 0, sizeof a);
+    for (int i = 0; i < t; i++) {
+        memcpy(a.c[i], challenges + 32 * i, 32);
+        if (fr_geq_l(a.c[i])) return VMPC_E_NONCANON;
+    }
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    vmpc_stage_scope s(ctx, "fr_tail_scalars");
+    k_fr_tail_scalars<<<fr_grid((size_t)1 << log2_m0), FR_BLOCK, 0, ctx->stream>>>(
+        a, t, log2_m0, (const uint32_t *)z, (uint32_t *)out_a, (uint32_t *)out_b);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }
