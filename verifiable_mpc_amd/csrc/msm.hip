@@ -312,7 +312,7 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
 // buckets that took several segments.  Lightly split ones (<= MSM_FINISH_SERIAL partial sums,
 // e.g. the under-full top window) are summed by one lane each; heavily split ones (skewed
 // scalars) by a workgroup-wide LDS tree.
-#define MSM_FINISH_SERIAL 8
+#define MSM_FINISH_SERIAL 32
 
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_msm_bucket_finish_light(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ ctrl,
