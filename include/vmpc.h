@@ -159,6 +159,22 @@ int vmpc_format_points_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *out_
 int vmpc_format_scalars_dev(vmpc_ctx *ctx, const void *scalars, size_t n, int is_signed,
                             void *out_text, size_t cap, uint64_t *len);
 
+/* ---- BN-256 G1 / G2 (Pinocchio prover MSMs) ----------------------------------
+ * The eight sums of verifiable_mpc/trinocchio/pynocchio.py:229-246
+ *     apply_to_list(point_add, [int(c[i]) * evalkey[...] for i in qap.indices_mid])
+ * on the curve of verifiable_mpc/ac20/pairing.py:44-51 (y^2 = x^3 + 3 over F_p; sextic twist over
+ * F_p[i]/(i^2+1)).  Scalars: 32 B little-endian, canonical < n (the 256-bit group order).
+ * G1 points: 64 B x||y canonical; G2 points: 128 B x.re||x.im||y.re||y.im; the point at infinity
+ * is the all-zero encoding.  Outputs are affine. */
+int vmpc_bn256_g1_msm(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out[64]);
+int vmpc_bn256_g2_msm(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out[128]);
+int vmpc_bn256_g1_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, size_t n,
+                          void *out_affine);
+int vmpc_bn256_g2_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, size_t n,
+                          void *out_affine);
+/* group = 1 (G1) or 2 (G2): canonical encodings and curve equation; *n_bad = offenders (sync) */
+int vmpc_bn256_validate_dev(vmpc_ctx *ctx, int group, const void *points, size_t n, uint64_t *n_bad);
+
 /* SHA-256 of every `chunk_bytes`-sized piece of a device buffer (last piece may be short):
  * out_digests[i] = SHA256(data[i*chunk : (i+1)*chunk]), 32 bytes each.  Leaves of the compact
  * transcript's two-level digests; not used by the reference transcript. */

@@ -30,7 +30,15 @@ sys.path.insert(0, REPO)
 
 # the KoE pivot's BN256 pairing module is out of scope and needs extension fields the
 # shim does not have; a placeholder keeps `import knowledge_of_exponent` working.
-sys.modules["verifiable_mpc.ac20.pairing"] = types.ModuleType("verifiable_mpc.ac20.pairing")
+_pairing_stub = types.ModuleType("verifiable_mpc.ac20.pairing")
+
+
+def _no_pairing(*a, **k):
+    raise NotImplementedError("pairings are outside the shim's scope")
+
+
+_pairing_stub.optimal_ate = _no_pairing
+sys.modules["verifiable_mpc.ac20.pairing"] = _pairing_stub
 
 from mpyc.finfields import GF                                   # noqa: E402 (shim)
 from mpyc.fingroups import EllipticCurve                        # noqa: E402 (shim)
@@ -251,6 +259,58 @@ def demo_case(seed):
     return captured
 
 
+def pynocchio_case(seed):
+    """BASELINE config 5 shape: the reference's Pinocchio key generation and compute_proof
+    (trinocchio/pynocchio.py:101-273) on the demo's program (demos/demo_zkp_pynocchio.py:45-50),
+    BN-256 groups from the shim.  Stores the evaluation-key points the prover reads, the witness,
+    h and the eight proof elements, all affine."""
+    import verifiable_mpc.trinocchio.pynocchio as pynocchio
+    import verifiable_mpc.tools.code_to_qap as c2q
+    import verifiable_mpc.tools.qap_creator as qc
+    bn_curve = EllipticCurve("BN256", "jacobian")
+    bn_twist = EllipticCurve("BN256_twist", "jacobian")
+    g1, g2 = bn_curve.generator, bn_twist.generator
+    modulus = bn_curve.order
+    gf = GF(modulus=modulus)
+    gf.is_signed = False
+    pynocchio.prng = random.Random(seed)
+    inputs = [gf(3)]
+    code = """
+def qeval(x):
+    y = x**3 + x**2 + x
+    return y + x + 5
+"""
+    qap = c2q.QAP(code, gf)
+    td = pynocchio.Trapdoor(modulus)
+    gen = pynocchio.Generators(td, g1, g2)
+    evalkey = pynocchio.generate_evalkey(td, qap, gen)
+    c = qap.calculate_witness(inputs)
+    p_poly = pynocchio.compute_p_poly(qap, c)
+    h, r = p_poly / qap.t
+    assert r == qc.Poly([0] * qap.d)
+    deltas = pynocchio.SampleDeltas(modulus)
+    h = h + pynocchio.compute_h_zk_terms(qap, c, deltas)
+    proof = pynocchio.compute_proof(qap, c, h, evalkey, deltas)
+
+    def enc(pt):
+        v = pt.value
+        if v is None:
+            return None
+        flat = []
+        for cpt in v:
+            flat += list(cpt) if isinstance(cpt, tuple) else [cpt]
+        return [hx(x) for x in flat]
+    try:
+        gf.is_signed = True
+    except Exception:
+        pass
+    return {"seed": seed, "m": qap.m, "d": qap.d, "indices_mid": list(qap.indices_mid),
+            "c": [hx(int(v) % modulus) for v in c], "h": [hx(int(v) % modulus) for v in h.coeffs],
+            "deltas": [hx(deltas.v), hx(deltas.w), hx(deltas.y)],
+            "evalkey": {k: enc(v) for k, v in evalkey.items()},
+            "proof": {k: enc(v) for k, v in proof.items()}}
+
+
 def main():
     out = {
         "forms": forms_case(),
@@ -264,6 +324,14 @@ def main():
         json.dump(out, f, indent=0, sort_keys=True)
     with open(os.path.join(HERE, "ac20_ed25519_n1023.json"), "w") as f:
         json.dump(p5_case(1023, SEED + 500), f, indent=0, sort_keys=True)
+    try:
+        with open(os.path.join(HERE, "pynocchio_bn256.json"), "w") as f:
+            json.dump(pynocchio_case(SEED + 700), f, indent=0, sort_keys=True)
+        print("pynocchio fixture written")
+    except Exception as e:
+        import traceback
+        traceback.print_exc()
+        print("pynocchio fixture not generated:", type(e).__name__, e)
     try:
         demo = demo_case(SEED + 600)
         with open(os.path.join(HERE, "demo_zkp_ac20_elliptic.json"), "w") as f:

@@ -14,9 +14,28 @@ class FiniteGroupElement:
     is_additive = False
     is_multiplicative = False
 
+    def __matmul__(self, other):
+        if not isinstance(other, type(self)):
+            return NotImplemented
+        return type(self).operation(self, other)
+
     def __mul__(self, other):
         cls = type(self)
         if cls.is_multiplicative and isinstance(other, cls):
+            return cls.operation(self, other)
+        if cls.is_additive and isinstance(other, int):
+            return cls.repeat(self, other)
+        return NotImplemented
+
+    def __rmul__(self, other):
+        cls = type(self)
+        if cls.is_additive and isinstance(other, int):
+            return cls.repeat(self, other)
+        return NotImplemented
+
+    def __add__(self, other):
+        cls = type(self)
+        if cls.is_additive and isinstance(other, cls):
             return cls.operation(self, other)
         return NotImplemented
 
@@ -92,6 +111,46 @@ def _make_ed25519():
     return Ed25519Projective
 
 
+def _make_bn256(twist):
+    """BN-256 G1 / twist over oracle/bn256_ref.py (affine inside; the Jacobian representative
+    is irrelevant to the fixtures, which store affine coordinates)."""
+    from oracle import bn256_ref as bn
+    E, G = (bn.E2, bn.G2) if twist else (bn.E1, bn.G1)
+
+    class BN256Element(EllipticCurvePoint):
+        __slots__ = ()
+        is_additive = True
+
+        def __init__(self, value=None):
+            self.value = value          # affine tuple or None (infinity)
+
+        @classmethod
+        def operation(cls, a, b):
+            return cls(E.add(a.value, b.value))
+
+        @classmethod
+        def inversion(cls, a):
+            return cls(E.neg(a.value))
+
+        @classmethod
+        def equality(cls, a, b):
+            return a.value == b.value
+
+        @classmethod
+        def repeat(cls, a, n):
+            return cls(E.mul(int(n), a.value))
+
+        def normalize(self):
+            return self
+
+    BN256Element.order = bn.N
+    BN256Element.field = GF(bn.P)
+    BN256Element.identity = BN256Element(None)
+    BN256Element.generator = BN256Element(G)
+    BN256Element.__name__ = "BN256_twist" if twist else "BN256"
+    return BN256Element
+
+
 class _Unsupported:
     field = None
     order = None
@@ -105,6 +164,8 @@ class _Unsupported:
 def EllipticCurve(curvename="Ed25519", coordinates=None):
     if curvename == "Ed25519" and coordinates in (None, "projective"):
         return _make_ed25519()
+    if curvename in ("BN256", "BN256_twist"):
+        return _make_bn256(curvename == "BN256_twist")
     return type(f"E({curvename})", (_Unsupported, EllipticCurvePoint), {})
 
 

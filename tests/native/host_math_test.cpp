@@ -14,6 +14,7 @@
 #include "../../verifiable_mpc_amd/csrc/ge25519.cuh"
 #include "../../verifiable_mpc_amd/csrc/fr.cuh"
 #include "../../verifiable_mpc_amd/csrc/fmt.cuh"
+#include "../../verifiable_mpc_amd/csrc/sw256.cuh"
 
 static void parse_hex(const std::string &h, uint32_t *out, int limbs) {
     for (int i = 0; i < limbs; i++) out[i] = 0;
@@ -55,6 +56,77 @@ static std::string fehex(const fe &a) {
     return to_hex(c.v, 8);
 }
 static std::string frhex(const fr &a) { return to_hex(a.v, 8); }
+
+// ---- BN-256 helpers: operands are canonical integers, converted to Montgomery form inside
+static fp rd_fp(std::istringstream &is) {
+    std::string h;
+    is >> h;
+    uint32_t w[8];
+    parse_hex(h, w, 8);
+    return Fp1Ops::load(w);
+}
+static std::string fphex(const fp &a) {
+    uint32_t w[8];
+    Fp1Ops::store(w, a);
+    return to_hex(w, 8);
+}
+static fp2 rd_fp2(std::istringstream &is) {
+    fp2 r;
+    r.a = rd_fp(is);
+    r.b = rd_fp(is);
+    return r;
+}
+static std::string fp2hex(const fp2 &a) { return fphex(a.a) + " " + fphex(a.b); }
+template <class F> static typename F::elem rd_el(std::istringstream &is);
+template <> fp rd_el<Fp1Ops>(std::istringstream &is) { return rd_fp(is); }
+template <> fp2 rd_el<Fp2Ops>(std::istringstream &is) { return rd_fp2(is); }
+static std::string elhex(const fp &a) { return fphex(a); }
+static std::string elhex(const fp2 &a) { return fp2hex(a); }
+
+template <class F> static aff<F> rd_aff(std::istringstream &is) {
+    aff<F> r;
+    r.x = rd_el<F>(is);
+    r.y = rd_el<F>(is);
+    r.inf = F::is_zero(r.x) && F::is_zero(r.y);
+    return r;
+}
+template <class F> static std::string affhex(const aff<F> &a) {
+    if (a.inf) return "inf";
+    return elhex(a.x) + " " + elhex(a.y);
+}
+template <class F> static jac<F> lift(const aff<F> &a) {
+    jac<F> r = jac_identity<F>();
+    return jac_madd<F>(r, a);
+}
+// curve commands: add (general, via de-normalised operands), madd, dbl, mul k
+template <class F> static void curve_cmd(const std::string &op, std::istringstream &is) {
+    aff<F> a = rd_aff<F>(is);
+    if (op == "dbl") {
+        std::cout << affhex<F>(jac_to_affine<F>(jac_dbl<F>(lift<F>(a)))) << "\n";
+        return;
+    }
+    if (op == "mul") {
+        std::string h;
+        is >> h;
+        uint32_t k[8];
+        parse_hex(h, k, 8);
+        jac<F> acc = jac_identity<F>(), d = lift<F>(a);
+        for (int i = 0; i < 256; i++) {
+            if ((k[i >> 5] >> (i & 31)) & 1u) acc = jac_add<F>(acc, d);
+            d = jac_dbl<F>(d);
+        }
+        std::cout << affhex<F>(jac_to_affine<F>(acc)) << "\n";
+        return;
+    }
+    aff<F> b = rd_aff<F>(is);
+    jac<F> pa = jac_dbl<F>(lift<F>(a));           // 2a, Z != 1
+    if (op == "madd") {
+        std::cout << affhex<F>(jac_to_affine<F>(jac_madd<F>(pa, b))) << "\n";
+    } else {
+        jac<F> pb = jac_add<F>(jac_dbl<F>(lift<F>(b)), jac_identity<F>());   // 2b
+        std::cout << affhex<F>(jac_to_affine<F>(jac_add<F>(pa, pb))) << "\n";
+    }
+}
 
 int main() {
     std::string line;
@@ -165,6 +237,22 @@ int main() {
             }
             ge_aff o = ge_ext_to_affine(r);
             std::cout << fehex(o.x) << " " << fehex(o.y) << " " << (ge_aff_on_curve(o) ? 1 : 0) << "\n";
+        } else if (cmd == "bnmul" || cmd == "bnadd" || cmd == "bnsub") {
+            fp a = rd_fp(is), b = rd_fp(is);
+            std::cout << fphex(cmd == "bnmul" ? fp_mul(a, b) : cmd == "bnadd" ? fp_add(a, b) : fp_sub(a, b)) << "\n";
+        } else if (cmd == "bninv") {
+            fp a = rd_fp(is);
+            std::cout << fphex(fp_inv(a)) << "\n";
+        } else if (cmd == "bn2mul") {
+            fp2 a = rd_fp2(is), b = rd_fp2(is);
+            std::cout << fp2hex(fp2_mul(a, b)) << "\n";
+        } else if (cmd == "bn2sqr" || cmd == "bn2inv") {
+            fp2 a = rd_fp2(is);
+            std::cout << fp2hex(cmd == "bn2sqr" ? fp2_sqr(a) : fp2_inv(a)) << "\n";
+        } else if (cmd.rfind("g1", 0) == 0) {
+            curve_cmd<Fp1Ops>(cmd.substr(2), is);
+        } else if (cmd.rfind("g2", 0) == 0) {
+            curve_cmd<Fp2Ops>(cmd.substr(2), is);
         } else if (cmd == "quit") {
             break;
         } else {

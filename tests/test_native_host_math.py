@@ -134,3 +134,57 @@ def test_extended_formulas(harness):
             lines.append(f"emaddneg {f2(p)} {f2(q)}")
             want.append(f2(ed.pt_add(p3, ed.pt_neg(q))) + " 1")
     assert harness(lines) == want
+
+
+# ---- BN-256 ---------------------------------------------------------------------
+from oracle import bn256_ref as bn
+
+
+def test_bn256_field(harness):
+    rng = random.Random(6)
+    vals = [0, 1, 2, bn.P - 1, bn.P - 2, 2**255, 2**128 - 1] + [rng.randrange(bn.P) for _ in range(60)]
+    lines, want = [], []
+    for _ in range(300):
+        a, b = rng.choice(vals), rng.choice(vals)
+        lines += [f"bnmul {hx(a)} {hx(b)}", f"bnadd {hx(a)} {hx(b)}", f"bnsub {hx(a)} {hx(b)}"]
+        want += [hx(a * b % bn.P), hx((a + b) % bn.P), hx((a - b) % bn.P)]
+    for a in vals[1:20]:
+        lines.append(f"bninv {hx(a)}")
+        want.append(hx(pow(a, bn.P - 2, bn.P)))
+    for _ in range(60):
+        a = (rng.randrange(bn.P), rng.randrange(bn.P))
+        b = (rng.randrange(bn.P), rng.randrange(bn.P))
+        lines += [f"bn2mul {hx(a[0])} {hx(a[1])} {hx(b[0])} {hx(b[1])}", f"bn2sqr {hx(a[0])} {hx(a[1])}",
+                  f"bn2inv {hx(a[0])} {hx(a[1])}"]
+        want += [" ".join(hx(v) for v in bn.Fp2.mul(a, b)), " ".join(hx(v) for v in bn.Fp2.mul(a, a)),
+                 " ".join(hx(v) for v in bn.Fp2.inv(a))]
+    assert harness(lines) == want
+
+
+def _flat(pt):
+    if pt is None:
+        return "inf"
+    out = []
+    for c in pt:
+        out += list(c) if isinstance(c, tuple) else [c]
+    return " ".join(hx(v) for v in out)
+
+
+@pytest.mark.parametrize("which", ["g1", "g2"])
+def test_bn256_curve_ops(harness, which):
+    E, G = (bn.E1, bn.G1) if which == "g1" else (bn.E2, bn.G2)
+    rng = random.Random(7)
+    pts = [E.mul(rng.randrange(1, bn.N), G) for _ in range(5)]
+    lines, want = [], []
+    for p in pts:
+        lines.append(f"{which}dbl {_flat(p)}")
+        want.append(_flat(E.add(p, p)))
+        for q in pts[:3] + [p, E.neg(p), E.add(p, p), E.neg(E.add(p, p))]:
+            lines.append(f"{which}add {_flat(p)} {_flat(q)}")
+            want.append(_flat(E.add(E.add(p, p), E.add(q, q))))
+            lines.append(f"{which}madd {_flat(p)} {_flat(q)}")
+            want.append(_flat(E.add(E.add(p, p), q)))
+        for k in [0, 1, 2, bn.N - 1, bn.N, rng.randrange(bn.N), 2**256 - 1]:
+            lines.append(f"{which}mul {_flat(p)} {hx(k)}")
+            want.append(_flat(E.mul(k, p)))
+    assert harness(lines) == want

@@ -33,6 +33,8 @@ SYMBOLS = [
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
     "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev",
+    "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
+    "vmpc_bn256_validate_dev",
 ]
 
 
@@ -94,6 +96,11 @@ def load_library():
         "vmpc_sha256_chunks_dev": (i32, [vp, vp, sz, sz, vp]),
         "vmpc_fr_challenge_products_dev": (i32, [vp, vp, i32, i32, vp, sz, vp]),
         "vmpc_fr_tail_scalars_dev": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+        "vmpc_bn256_g1_msm": (i32, [vp, vp, sz, vp]),
+        "vmpc_bn256_g2_msm": (i32, [vp, vp, sz, vp]),
+        "vmpc_bn256_g1_msm_dev": (i32, [vp, vp, vp, sz, vp]),
+        "vmpc_bn256_g2_msm_dev": (i32, [vp, vp, vp, sz, vp]),
+        "vmpc_bn256_validate_dev": (i32, [vp, i32, vp, sz, u64p]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the export is missing
@@ -381,6 +388,17 @@ class Context:
         buf.free()
         return out
 
+    def bn256_msm(self, group, scalars_ptr, points_ptr, n, out_ptr):
+        fn = self.lib.vmpc_bn256_g1_msm_dev if group == 1 else self.lib.vmpc_bn256_g2_msm_dev
+        _check(fn(self.handle, ctypes.c_void_p(scalars_ptr), ctypes.c_void_p(points_ptr), n,
+                  ctypes.c_void_p(out_ptr)), f"vmpc_bn256_g{group}_msm_dev")
+
+    def bn256_validate(self, group, points_ptr, n):
+        bad = ctypes.c_uint64()
+        _check(self.lib.vmpc_bn256_validate_dev(self.handle, group, ctypes.c_void_p(points_ptr), n,
+                                                ctypes.byref(bad)), "vmpc_bn256_validate_dev")
+        return bad.value
+
     def sha256_chunks(self, data_ptr, nbytes, chunk_bytes=4096):
         """bytes object: concatenated 32-byte SHA-256 digests of the chunks of a device buffer"""
         n_chunks = (nbytes + chunk_bytes - 1) // chunk_bytes
@@ -452,3 +470,16 @@ def fr_dot(a, b):
     out = ctypes.create_string_buffer(32)
     _check(lib.vmpc_fr_dot(_np_ptr(aa), _np_ptr(ba), len(aa), out), "vmpc_fr_dot")
     return int.from_bytes(out.raw, "little")
+
+
+def bn256_msm(group, scalars, points):
+    """host-buffer one-shot: (n,32) scalars, (n,64|128) points -> affine bytes"""
+    lib = load_library()
+    width = 64 if group == 1 else 128
+    s = as_bytes_array(scalars, 32)
+    p = as_bytes_array(points, width)
+    assert len(s) == len(p)
+    out = np.zeros(width, dtype=np.uint8)
+    fn = lib.vmpc_bn256_g1_msm if group == 1 else lib.vmpc_bn256_g2_msm
+    _check(fn(_np_ptr(s), _np_ptr(p), len(s), _np_ptr(out)), f"vmpc_bn256_g{group}_msm")
+    return out

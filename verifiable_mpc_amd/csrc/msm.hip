@@ -28,30 +28,15 @@
 #include "ge25519.cuh"
 #include "scan.cuh"
 #include "quad.cuh"
+#include "msm_sort.h"
 
-#define MSM_MAX_C 16
-#define MSM_BLOCK 256
-#define MSM_SORT_BLOCK 1024
 // niels record stride in 32-bit words: 24 = packed 96 B, 32 = one 128-B line per gather
 #ifndef MSM_NIELS_STRIDE
 #define MSM_NIELS_STRIDE 24
 #endif
-#ifndef MSM_REDUCE_CHUNKS
-#define MSM_REDUCE_CHUNKS 4096
-#endif
 #ifndef MSM_REDUCE_WAVES
 #define MSM_REDUCE_WAVES 2
 #endif
-
-struct msm_plan {
-    size_t n_main, n_extra, n_total;
-    int c, W, nb, nb1;  // nb = 2^(c-1) buckets per window, nb1 = nb + 1 (bucket 0 unused)
-    int S;              // slices per window in the sort kernels
-    size_t slice_len;
-    int chunks;         // chunk-threads per window in the reduce kernel
-    int chunk_len;      // buckets per chunk (power of two)
-    int red_blocks;     // blocks per window in the reduce kernel
-};
 
 __device__ __forceinline__ void load_u32x8(uint32_t dst[8], const uint32_t *src) {
     const uint4 *p = reinterpret_cast<const uint4 *>(src);
@@ -106,17 +91,23 @@ k_msm_prep(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__re
 // ---- recode: scalar -> signed digits ----------------------------------------------------
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__restrict__ sc_extra,
-             size_t n_total, int16_t *__restrict__ digits, int c, int W,
+             size_t n_total, int16_t *__restrict__ digits, int c, int W, msm_modulus mod,
              uint32_t *__restrict__ status) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
     const uint32_t *src = (i < n_main) ? sc + 8 * i : sc_extra + 8 * (i - n_main);
     uint32_t s[8];
     load_u32x8(s, src);
-    if (fr_geq_l(s)) {
-        atomicAdd(&status[VMPC_ST_NONCANON], 1u);
-        // keep going with the value reduced once (still < 2^256 - l): result is defined,
-        // but the caller is told at the next sync point
+    {   // canonical residue? (s < modulus); the caller is told at the next sync point
+        bool ge = true;
+#pragma unroll
+        for (int k = 7; k >= 0; k--) {
+            if (s[k] != mod.v[k]) {
+                ge = s[k] > mod.v[k];
+                break;
+            }
+        }
+        if (ge) atomicAdd(&status[VMPC_ST_NONCANON], 1u);
     }
     const uint32_t mask = (1u << c) - 1u;
     const uint32_t half = 1u << (c - 1);
@@ -209,13 +200,6 @@ k_msm_scatter(const int16_t *__restrict__ digits, size_t n_total, size_t slice_l
 // sort over the 64 possible lengths) so the 64 lanes of a wave run loops of equal trip
 // count.  Buckets that needed more than one segment are finished by a workgroup-wide LDS
 // tree over their partial sums.
-#define MSM_SEG 64
-
-__device__ __forceinline__ size_t bucket_slot(uint32_t ci, int nb1) {
-    // ci = w * nb1 + b (b >= 1)  ->  w * nb + (b - 1)
-    uint32_t w = ci / (uint32_t)nb1;
-    return (size_t)ci - w - 1;
-}
 
 // plan, pass 1: segments per bucket + per-block histogram of segment lengths
 __global__ void __launch_bounds__(MSM_BLOCK)
@@ -304,7 +288,7 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
         q = qn;
     }
     if (nseg[ci] == 1)
-        ext_st(buckets + 32 * bucket_slot(ci, nb1), acc);
+        ext_st(buckets + 32 * msm_bucket_slot(ci, nb1), acc);
     else
         ext_st(partial + 32 * (size_t)(seg_starts[ci] + sidx), acc);
 }
@@ -312,7 +296,6 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
 // buckets that took several segments.  Lightly split ones (<= MSM_FINISH_SERIAL partial sums,
 // e.g. the under-full top window) are summed by one lane each; heavily split ones (skewed
 // scalars) by a workgroup-wide LDS tree.
-#define MSM_FINISH_SERIAL 32
 
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_msm_bucket_finish_light(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ ctrl,
@@ -326,7 +309,7 @@ k_msm_bucket_finish_light(const uint32_t *__restrict__ heavy_list, const uint32_
         const uint32_t *src = partial + 32 * (size_t)seg_starts[ci];
         ge_ext acc = ext_ld(src);
         for (uint32_t j = 1; j < ns; j++) acc = ge_add(acc, ext_ld(src + 32 * (size_t)j));
-        ext_st(buckets + 32 * bucket_slot(ci, nb1), acc);
+        ext_st(buckets + 32 * msm_bucket_slot(ci, nb1), acc);
     }
 }
 
@@ -354,7 +337,7 @@ k_msm_bucket_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__r
                        ge_add(ext_ld(lds + 32 * threadIdx.x), ext_ld(lds + 32 * (threadIdx.x + stride))));
             __syncthreads();
         }
-        if (threadIdx.x == 0) ext_st(buckets + 32 * bucket_slot(ci, nb1), ext_ld(lds));
+        if (threadIdx.x == 0) ext_st(buckets + 32 * msm_bucket_slot(ci, nb1), ext_ld(lds));
         __syncthreads();
     }
 }
@@ -537,11 +520,11 @@ k_points_validate(const uint32_t *__restrict__ aff, size_t n, unsigned long long
 }
 
 // ---- host side ---------------------------------------------------------------------------
-static int msm_pick_window(size_t n) {
+static int msm_pick_window(size_t n, int scalar_bits) {
     double best = 1e300;
     int best_c = 4;
     for (int c = 4; c <= MSM_MAX_C; c++) {
-        int W = (255 + c - 1) / c;
+        int W = (scalar_bits + 2 + c - 1) / c;
         double cost = (double)W * ((double)n + 2.5 * (double)(1u << (c - 1)));
         if (cost < best) {
             best = cost;
@@ -551,14 +534,21 @@ static int msm_pick_window(size_t n) {
     return best_c;
 }
 
-static void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, msm_plan &p) {
+void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits, msm_plan &p) {
     p.n_main = n_main;
     p.n_extra = n_extra;
     p.n_total = n_main + n_extra;
-    p.c = ctx->window_override ? ctx->window_override : msm_pick_window(p.n_total);
-    if (p.c < 2) p.c = 2;
+    p.scalar_bits = scalar_bits;
+    p.c = ctx->window_override ? ctx->window_override : msm_pick_window(p.n_total, scalar_bits);
+    if (p.c < 4) p.c = 4;
     if (p.c > MSM_MAX_C) p.c = MSM_MAX_C;
-    p.W = (255 + p.c - 1) / p.c;
+    // the signed recoding may carry one bit past the top: W * c >= scalar_bits + 2 keeps the top
+    // window's raw digit below 2^(c-1) (253-bit Ed25519 scalars: W = ceil(255 / c))
+    p.W = (scalar_bits + 2 + p.c - 1) / p.c;
+    while (p.W > 64) {   // the recombination kernels give one lane to each window (64-lane wave)
+        p.c++;
+        p.W = (scalar_bits + 2 + p.c - 1) / p.c;
+    }
     p.nb = 1 << (p.c - 1);
     p.nb1 = p.nb + 1;
     // enough (window, slice) workgroups to cover the chip twice, slices of >= 4096 terms
@@ -568,26 +558,15 @@ static void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, msm_plan
     if (S < 1) S = 1;
     p.S = S;
     p.slice_len = (p.n_total + S - 1) / S;
-    // reduce: up to 8192 chunk-lanes per window (chunk length a power of two): the per-lane
-    // work is a dependency chain, so shorter chunks on more lanes cut the latency
+    // reduce: chunk-lanes per window (chunk length a power of two): the per-lane work is a
+    // dependency chain, so shorter chunks on more lanes cut the latency
     int chunks = p.nb < MSM_REDUCE_CHUNKS ? p.nb : MSM_REDUCE_CHUNKS;
     p.chunks = chunks;
     p.chunk_len = p.nb / chunks;
     p.red_blocks = (chunks + MSM_BLOCK - 1) / MSM_BLOCK;
 }
 
-struct msm_ws {
-    uint32_t *niels, *hist, *counts, *starts, *sorted, *buckets, *partials;
-    uint32_t *nseg, *seg_starts, *block_hist, *block_base, *heavy_list, *ctrl, *seg_partial;
-    uint2 *tasks;
-    int16_t *digits;
-    void *scan_ws;
-    size_t total;
-    uint32_t plan_blocks;
-    size_t t_max;
-};
-
-static void msm_layout(const msm_plan &p, msm_ws &w, char *base) {
+void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, size_t acc_bytes) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
@@ -595,14 +574,14 @@ static void msm_layout(const msm_plan &p, msm_ws &w, char *base) {
         return base ? (void *)(base + o) : (void *)nullptr;
     };
     size_t nbk = (size_t)p.W * p.nb1;
-    w.niels = (uint32_t *)take(p.n_total * (MSM_NIELS_STRIDE * 4));
+    w.entries = (uint32_t *)take(p.n_total * entry_bytes);
     w.digits = (int16_t *)take((size_t)p.W * p.n_total * 2);
     w.hist = (uint32_t *)take((size_t)p.W * p.S * p.nb1 * 4);
     w.counts = (uint32_t *)take(nbk * 4);
     w.starts = (uint32_t *)take(nbk * 4);
     w.sorted = (uint32_t *)take((size_t)p.W * p.n_total * 4);
-    w.buckets = (uint32_t *)take((size_t)p.W * p.nb * 128);
-    w.partials = (uint32_t *)take((size_t)p.W * p.red_blocks * 128);
+    w.buckets = (uint32_t *)take((size_t)p.W * p.nb * acc_bytes);
+    w.partials = (uint32_t *)take((size_t)p.W * p.red_blocks * acc_bytes);
     // segment planning: at most M/SEG full segments plus one remainder per non-empty bucket
     size_t m_max = (size_t)p.W * p.n_total;
     size_t nonempty_max = m_max < (size_t)p.W * p.nb ? m_max : (size_t)p.W * p.nb;
@@ -616,44 +595,16 @@ static void msm_layout(const msm_plan &p, msm_ws &w, char *base) {
     w.heavy_list = (uint32_t *)take(nbk * 4);
     w.ctrl = (uint32_t *)take(64);
     w.tasks = (uint2 *)take(w.t_max * 8);
-    w.seg_partial = (uint32_t *)take(w.t_max * 128);
+    w.seg_partial = (uint32_t *)take(w.t_max * acc_bytes);
     size_t scan_n = nbk > hist_n ? nbk : hist_n;
     w.scan_ws = take(vmpc_scan_ws_bytes(scan_n, 4));
     w.total = off;
 }
 
-static int ilog2(int v) {
-    int r = 0;
-    while ((1 << r) < v) r++;
-    return r;
-}
-
-extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affine_points, size_t n,
-                            const void *extra_scalars, const void *extra_affine_points,
-                            size_t n_extra, void *out_ext, void *out_affine) {
-    if (!ctx || (n && (!scalars || !affine_points)) || (n_extra && (!extra_scalars || !extra_affine_points)))
-        return VMPC_E_INVAL;
-    if (!out_ext && !out_affine) return VMPC_E_INVAL;
-    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scalars, size_t n,
+                   const void *extra_scalars, const msm_modulus &modulus) {
     hipStream_t st = ctx->stream;
-    size_t n_total = n + n_extra;
-    if (n_total == 0) {
-        // empty product = identity (pivot.list_mul's `initial`, pivot.py:28)
-        uint32_t id_ext[32] = {0}, id_aff[16] = {0};
-        id_ext[8] = 1; id_ext[16] = 1; id_aff[8] = 1;
-        if (out_ext) VMPC_HIP_CHECK(hipMemcpyAsync(out_ext, id_ext, 128, hipMemcpyHostToDevice, st));
-        if (out_affine) VMPC_HIP_CHECK(hipMemcpyAsync(out_affine, id_aff, 64, hipMemcpyHostToDevice, st));
-        VMPC_HIP_CHECK(hipStreamSynchronize(st));
-        return VMPC_OK;
-    }
-    if (n_total >= (1ull << 31) / 16) return VMPC_E_INVAL;  // index / offset width
-    msm_plan p;
-    msm_make_plan(ctx, n, n_extra, p);
-    msm_ws w;
-    msm_layout(p, w, nullptr);
-    VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
-    msm_layout(p, w, (char *)ctx->ws);
-
+    const size_t n_total = p.n_total;
     const unsigned gb = (unsigned)((n_total + MSM_BLOCK - 1) / MSM_BLOCK);
     const size_t lds_bytes = (size_t)p.nb1 * 4;
     if (lds_bytes > 48 * 1024) {
@@ -663,16 +614,10 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     {
-        vmpc_stage_scope s(ctx, "msm_prep");
-        k_msm_prep<<<gb, MSM_BLOCK, 0, st>>>((const uint32_t *)affine_points, n,
-                                            (const uint32_t *)extra_affine_points, n_total, w.niels);
-        VMPC_KERNEL_CHECK();
-    }
-    {
         vmpc_stage_scope s(ctx, "msm_recode");
         k_msm_recode<<<gb, MSM_BLOCK, 0, st>>>((const uint32_t *)scalars, n,
                                               (const uint32_t *)extra_scalars, n_total, w.digits, p.c,
-                                              p.W, ctx->d_status);
+                                              p.W, modulus, ctx->d_status);
         VMPC_KERNEL_CHECK();
     }
     {
@@ -711,10 +656,48 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
                                                         w.block_base, w.tasks);
         VMPC_KERNEL_CHECK();
     }
+    return VMPC_OK;
+}
+
+static const msm_modulus ED25519_L = {VMPC_FR_L};
+
+extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affine_points, size_t n,
+                            const void *extra_scalars, const void *extra_affine_points,
+                            size_t n_extra, void *out_ext, void *out_affine) {
+    if (!ctx || (n && (!scalars || !affine_points)) || (n_extra && (!extra_scalars || !extra_affine_points)))
+        return VMPC_E_INVAL;
+    if (!out_ext && !out_affine) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    size_t n_total = n + n_extra;
+    if (n_total == 0) {
+        // empty product = identity (pivot.list_mul's `initial`, pivot.py:28)
+        uint32_t id_ext[32] = {0}, id_aff[16] = {0};
+        id_ext[8] = 1; id_ext[16] = 1; id_aff[8] = 1;
+        if (out_ext) VMPC_HIP_CHECK(hipMemcpyAsync(out_ext, id_ext, 128, hipMemcpyHostToDevice, st));
+        if (out_affine) VMPC_HIP_CHECK(hipMemcpyAsync(out_affine, id_aff, 64, hipMemcpyHostToDevice, st));
+        VMPC_HIP_CHECK(hipStreamSynchronize(st));
+        return VMPC_OK;
+    }
+    if (n_total >= (1ull << 31) / 16) return VMPC_E_INVAL;  // index / offset width
+    msm_plan p;
+    msm_make_plan(ctx, n, n_extra, 253, p);
+    msm_ws w;
+    msm_layout(p, w, nullptr, MSM_NIELS_STRIDE * 4, 128);
+    VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
+    msm_layout(p, w, (char *)ctx->ws, MSM_NIELS_STRIDE * 4, 128);
+
+    {
+        vmpc_stage_scope s(ctx, "msm_prep");
+        k_msm_prep<<<(unsigned)((n_total + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
+            (const uint32_t *)affine_points, n, (const uint32_t *)extra_affine_points, n_total, w.entries);
+        VMPC_KERNEL_CHECK();
+    }
+    VMPC_CHECK(msm_sort_stage(ctx, p, w, scalars, n, extra_scalars, ED25519_L));
     {
         vmpc_stage_scope s(ctx, "msm_bucket");
         k_msm_bucket<<<(unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
-            w.niels, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
+            w.entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
             w.buckets, w.seg_partial);
         VMPC_KERNEL_CHECK();
     }
@@ -731,7 +714,7 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
     {
         vmpc_stage_scope s(ctx, "msm_reduce");
         k_msm_reduce<<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, st>>>(
-            w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, ilog2(p.chunk_len), p.red_blocks, w.partials);
+            w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, msm_ilog2(p.chunk_len), p.red_blocks, w.partials);
         VMPC_KERNEL_CHECK();
     }
     {

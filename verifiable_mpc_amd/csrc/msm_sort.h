@@ -1,0 +1,65 @@
+// Curve-independent half of the Pippenger pipeline (implemented in msm.hip): signed-digit
+// recoding, per-window bucket sort (LDS histograms / cursors), bucket offsets, and the
+// length-balanced segment task table.  Shared by the Ed25519 MSM (msm.hip) and the BN-256
+// G1/G2 MSMs (bn256.hip); the curve-specific kernels (entry preparation, bucket accumulation,
+// bucket reduction, window recombination) live with their curve.
+#pragma once
+#include "common.cuh"
+
+#define MSM_MAX_C 16
+#define MSM_BLOCK 256
+#define MSM_SORT_BLOCK 1024
+#define MSM_SEG 64
+#define MSM_FINISH_SERIAL 32
+#ifndef MSM_REDUCE_CHUNKS
+#define MSM_REDUCE_CHUNKS 4096
+#endif
+
+struct msm_plan {
+    size_t n_main, n_extra, n_total;
+    int scalar_bits;    // scalars are < 2^scalar_bits
+    int c, W, nb, nb1;  // nb = 2^(c-1) buckets per window, nb1 = nb + 1 (bucket 0 unused)
+    int S;              // slices per window in the sort kernels
+    size_t slice_len;
+    int chunks;         // chunk-threads per window in the reduce kernel
+    int chunk_len;      // buckets per chunk (power of two)
+    int red_blocks;     // blocks per window in the reduce kernel
+};
+
+struct msm_ws {
+    uint32_t *entries;      // prepared points, entry_bytes each
+    uint32_t *hist, *counts, *starts, *sorted;
+    uint32_t *buckets;      // W * nb accumulators, acc_bytes each
+    uint32_t *partials;     // W * red_blocks accumulators
+    uint32_t *nseg, *seg_starts, *block_hist, *block_base, *heavy_list, *ctrl;
+    uint32_t *seg_partial;  // per-segment partial sums, acc_bytes each
+    uint2 *tasks;
+    int16_t *digits;
+    void *scan_ws;
+    size_t total;
+    uint32_t plan_blocks;
+    size_t t_max;
+};
+
+struct msm_modulus {
+    uint32_t v[8];
+};
+
+void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits, msm_plan &p);
+void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, size_t acc_bytes);
+// recode -> hist -> counts/scan -> scatter -> plan: fills digits, sorted, starts, counts, nseg,
+// seg_starts, heavy_list, tasks, ctrl[0] = #split buckets, ctrl[1] = #tasks
+int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scalars, size_t n,
+                   const void *extra_scalars, const msm_modulus &modulus);
+
+static inline int msm_ilog2(int v) {
+    int r = 0;
+    while ((1 << r) < v) r++;
+    return r;
+}
+
+// ci = w * nb1 + b (b >= 1)  ->  w * nb + (b - 1)
+__device__ __forceinline__ size_t msm_bucket_slot(uint32_t ci, int nb1) {
+    uint32_t w = ci / (uint32_t)nb1;
+    return (size_t)ci - w - 1;
+}
