@@ -36,6 +36,21 @@ def rand_scalars(rng, n):
     return a
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the latest committed PMC summary (collected with
+    rocprofv3 --pmc in separate passes, profiles/*_pmc_summary.json); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            k = json.load(f)["kernels"].get(kernel)
+        return (k["hbm_bytes_per_launch_corrected"], os.path.basename(files[-1])) if k else (None, None)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(log2_sample, seed):
     from oracle import c_oracle
     n = 1 << log2_sample
@@ -156,8 +171,10 @@ def main():
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
-    ctx.profile(True)
-    ctx.profile_read(reset=True)
+    prof_ctxs = list(getattr(shard.backend, "ctxs", [ctx]))[:depth]
+    for c_ in prof_ctxs:
+        c_.profile(True)
+        c_.profile_read(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     result = run_steps(args.steps)
@@ -165,8 +182,12 @@ def main():
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof = ctx.profile_read(reset=True)
-    ctx.profile(False)
+    prof = {}
+    for c_ in prof_ctxs:       # HIP events on each stream the kernels were launched on
+        for name, (ms, cnt) in c_.profile_read(reset=True).items():
+            a, b = prof.get(name, (0.0, 0))
+            prof[name] = (a + ms, b + cnt)
+        c_.profile(False)
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -182,6 +203,7 @@ def main():
         assert want == result, "MSM property check failed"
 
     if rank == 0:
+        traffic, traffic_src = pmc_traffic("k_msm_bucket")
         bucket_ms, bucket_n = prof.get("msm_bucket", (0.0, 0))
         t_bucket = bucket_ms / max(bucket_n, 1) / 1e3
         achieved = BYTES_PER_TERM * n / t_bucket / 1e9 if t_bucket > 0 else 0.0
@@ -196,7 +218,8 @@ def main():
                        "collective": "all_gather(128 B/rank) + ordered add" if shard.collective else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_bucket", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "avg_kernel_ms": t_bucket * 1e3,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_kernel_ms": t_bucket * 1e3, "launches_timed": bucket_n,
                          "algorithmic_bytes_per_launch": BYTES_PER_TERM * n,
                          "note": "255-bit modular-integer kernel: bound by 32x32 integer "
                                  "multiply-add issue, not HBM (DESIGN.md section 5)"},
