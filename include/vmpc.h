@@ -158,6 +158,16 @@ int vmpc_format_points_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *out_
                            uint64_t *len);
 int vmpc_format_scalars_dev(vmpc_ctx *ctx, const void *scalars, size_t n, int is_signed,
                             void *out_text, size_t cap, uint64_t *len);
+/* Asynchronous forms: text is produced into `dev_text` (cap >= n * 242 for points, n * 81 for
+ * scalars) and copied, with its length, into PINNED host memory (vmpc_host_alloc) on the context's
+ * stream; nothing is valid until that stream has been synchronised (vmpc_ctx_sync). */
+int vmpc_format_points_async_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *dev_text, size_t cap,
+                                 void *host_text, uint64_t *host_len);
+int vmpc_format_scalars_async_dev(vmpc_ctx *ctx, const void *scalars, size_t n, int is_signed,
+                                  void *dev_text, size_t cap, void *host_text, uint64_t *host_len);
+/* page-locked host memory for the asynchronous copies above */
+int vmpc_host_alloc(size_t bytes, void **out);
+int vmpc_host_free(void *p);
 
 /* ---- BN-256 G1 / G2 (Pinocchio prover MSMs) ----------------------------------
  * The eight sums of verifiable_mpc/trinocchio/pynocchio.py:229-246

@@ -32,6 +32,7 @@ SYMBOLS = [
     "vmpc_msm_dev", "vmpc_points_sum_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
     "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
+    "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
     "vmpc_bn256_validate_dev",
@@ -93,6 +94,10 @@ def load_library():
         "vmpc_fr_dot_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_format_points_dev": (i32, [vp, vp, sz, vp, sz, u64p]),
         "vmpc_format_scalars_dev": (i32, [vp, vp, sz, i32, vp, sz, u64p]),
+        "vmpc_format_points_async_dev": (i32, [vp, vp, sz, vp, sz, vp, vp]),
+        "vmpc_format_scalars_async_dev": (i32, [vp, vp, sz, i32, vp, sz, vp, vp]),
+        "vmpc_host_alloc": (i32, [sz, ctypes.POINTER(vp)]),
+        "vmpc_host_free": (i32, [vp]),
         "vmpc_sha256_chunks_dev": (i32, [vp, vp, sz, sz, vp]),
         "vmpc_fr_challenge_products_dev": (i32, [vp, vp, i32, i32, vp, sz, vp]),
         "vmpc_fr_tail_scalars_dev": (i32, [vp, vp, i32, i32, vp, vp, vp]),
@@ -188,6 +193,50 @@ class DeviceBuffer:
             pass
 
 
+class PinnedBuffer:
+    """Page-locked host memory (vmpc_host_alloc) viewed as a uint8 numpy array."""
+
+    def __init__(self, nbytes):
+        lib = load_library()
+        p = ctypes.c_void_p()
+        _check(lib.vmpc_host_alloc(int(nbytes), ctypes.byref(p)), "vmpc_host_alloc")
+        self.ptr, self.nbytes, self._lib = p.value, int(nbytes), lib
+        self.array = np.ctypeslib.as_array((ctypes.c_uint8 * self.nbytes).from_address(self.ptr))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self._lib.vmpc_host_free(ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+
+class PendingText:
+    """Transcript text being formatted and copied on a context's stream (PointVector /
+    ScalarVector .text_begin()); result() synchronises that stream."""
+
+    def __init__(self, ctx, pinned, dev, cap):
+        self.ctx, self.pinned, self.dev, self.cap = ctx, pinned, dev, cap
+
+    def result(self):
+        if self.dev is not None:
+            self.ctx.sync()
+            n = int(np.frombuffer(self.pinned.array[:8], dtype=np.uint64)[0])
+            self._view = self.pinned.array[16:16 + n]
+            self.dev = None
+        return self._view
+
+    def __del__(self):
+        # the pinned block goes back to the pool only when nobody can still read the text
+        try:
+            if self.pinned is not None and self.ctx is not None and self.ctx.handle:
+                self.ctx.sync()
+                self._view = None
+                self.ctx._give_pinned(self.cap + 16, self.pinned)
+                self.pinned = None
+        except Exception:
+            pass
+
+
 class Context:
     """One GPU, one stream (vmpc_ctx)."""
 
@@ -200,6 +249,35 @@ class Context:
         self._cache = {}          # size class -> [device pointers]
         self._cached_bytes = 0
         self.cache_limit = 16 << 30
+        self._pinned = {}         # size class -> [PinnedBuffer]
+
+    def _take_pinned(self, nbytes):
+        cap = _size_class(nbytes)
+        lst = self._pinned.get(cap)
+        return lst.pop() if lst else PinnedBuffer(cap)
+
+    def _give_pinned(self, nbytes, buf):
+        # NB: the array handed to the caller stays valid until the buffer is taken again, i.e.
+        # until the NEXT text_begin of the same size class on this context
+        self._pinned.setdefault(_size_class(nbytes), []).append(buf)
+
+    def format_begin(self, kind, src_ptr, n, is_signed=True):
+        """enqueue formatting + D2H of a vector's transcript text; returns a PendingText"""
+        per = (3 * 78 + 8) if kind == "points" else (78 + 3)
+        cap = n * per + 16
+        pinned = self._take_pinned(cap + 16)
+        dev = DeviceBuffer(self, cap)
+        host_len = ctypes.c_void_p(pinned.ptr)
+        host_text = ctypes.c_void_p(pinned.ptr + 16)
+        if kind == "points":
+            rc = self.lib.vmpc_format_points_async_dev(self.handle, ctypes.c_void_p(src_ptr), n,
+                                                       ctypes.c_void_p(dev.ptr), cap, host_text, host_len)
+        else:
+            rc = self.lib.vmpc_format_scalars_async_dev(self.handle, ctypes.c_void_p(src_ptr), n,
+                                                        1 if is_signed else 0, ctypes.c_void_p(dev.ptr),
+                                                        cap, host_text, host_len)
+        _check(rc, "vmpc_format_async")
+        return PendingText(self, pinned, dev, cap)
 
     def _take_block(self, cap):
         lst = self._cache.get(cap)
@@ -231,6 +309,10 @@ class Context:
 
     def close(self):
         if self.handle:
+            for lst in self._pinned.values():
+                for b in lst:
+                    b.free()
+            self._pinned = {}
             self.trim()
             self.lib.vmpc_ctx_destroy(self.handle)
             self.handle = None

@@ -182,10 +182,42 @@ def _fold_witness(z_l, z_r, c, half):
     return [z_l[i] + c * z_r[i] for i in range(half)]
 
 
-def _fold_commitment(A, Q, B, c):
+class _LazyPoint:
+    """A commitment still being computed on a side stream; behaves like the point for what
+    Protocol 4 does with Q (normalize() for the hash, use as an MSM input)."""
+
+    def __init__(self, pending):
+        self._pending, self._pt = pending, None
+
+    def resolve(self):
+        if self._pt is None:
+            self._pt = self._pending.result()
+            self._pending = None
+        return self._pt
+
+    def normalize(self):
+        return self.resolve().normalize()
+
+    def __eq__(self, other):
+        return self.resolve() == (other.resolve() if isinstance(other, _LazyPoint) else other)
+
+    def __repr__(self):
+        return repr(self.resolve())
+
+
+def _fold_commitment(A, Q, B, c, order=None):
     """Q' = A * Q**c * B**(c**2) (compressed_pivot.py:66; the exponent c**2 is not reduced
-    in the reference, which changes nothing for an element of order l)."""
-    return _gmul(_gmul(A, _gpow(Q, c)), _gpow(B, c * c))
+    in the reference, which changes nothing for an element of order l).  Enqueued as a
+    3-term MSM on a side stream: the two 253-bit ladders overlap the generator fold instead of
+    costing ~3 ms of host big-int time per round; the value is only needed for the next hash."""
+    from .device import get_aux_context
+    order = order or Ed25519Point.order
+    if isinstance(Q, _LazyPoint):
+        Q = Q.resolve()
+    aux = get_aux_context(1)
+    pv = PointVector.from_points([A, Q, B], aux, keep_proj=False)
+    sc = ScalarVector.from_ints([1, c % order, c * c % order], aux)
+    return _LazyPoint(pivot._commit_launch(sc, 0, pv, Ed25519Point.identity, aux))
 
 
 def _unfold_commitment(Q0, rounds, order, ctx=None):
@@ -197,6 +229,8 @@ def _unfold_commitment(Q0, rounds, order, ctx=None):
         scalars += [suffix, suffix * c * c % order]
         points += [A, B]
         suffix = suffix * c % order
+    if isinstance(Q0, _LazyPoint):
+        Q0 = Q0.resolve()
     q_terms = Q0.terms if isinstance(Q0, _LazyQ) else [(1, Q0)]
     for sc, pt in q_terms:
         scalars.append(suffix * sc % order)
@@ -211,7 +245,7 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
     recursion is a loop here, `round_i` keeps its meaning."""
     g_hat = pivot._points_on_device(g_hat)
     k = _pt(k)
-    Q = Q if isinstance(Q, _LazyQ) else _pt(Q)
+    Q = Q if isinstance(Q, (_LazyQ, _LazyPoint)) else _pt(Q)
     if not isinstance(transcript, _Transcript):
         transcript = _Transcript(transcript or "reference", k.order)
     if transcript.mode == "reference" and isinstance(Q, _LazyQ):
@@ -245,11 +279,15 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
             tail_cs.append(c)
         else:
             g_hat = g_l.fold(g_r, c)
+            if transcript.mode == "reference":
+                g_hat.text_begin()       # next round's pre-image: format + copy behind the MSMs
         if transcript.mode == "reference":
             # only the reference pre-image contains Q (compressed_pivot.py:52); the compact
             # chain binds Q once at the start, so the prover need not track it
             Q = _fold_commitment(A, Q, B, c)
         L_tilde = _fold_form(L_tilde, c, half, gf)
+        if transcript.mode == "reference" and isinstance(L_tilde.coeffs, ScalarVector):
+            L_tilde.coeffs.text_begin()
         z_hat = _fold_witness(z_l, z_r, c, half)
         if len(z_hat) <= 2:
             if isinstance(z_hat, ScalarVector):
@@ -303,7 +341,7 @@ def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=N
     """Non-interactive Protocol 4, verifier (compressed_pivot.py:148-202)."""
     g_hat = pivot._points_on_device(g_hat)
     k = _pt(k)
-    Q = Q if isinstance(Q, _LazyQ) else _pt(Q)
+    Q = Q if isinstance(Q, (_LazyQ, _LazyPoint)) else _pt(Q)
     if not isinstance(transcript, _Transcript):
         transcript = _Transcript(transcript or "reference", k.order)
     if transcript.mode == "compact" and len(g_hat) >= 4 and (len(g_hat) & (len(g_hat) - 1)) == 0:
@@ -329,6 +367,8 @@ def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=N
             logger_cp.debug("Arrived in final step of protocol_4_verifier.")
             if deferred:
                 Q = _unfold_commitment(Q, deferred, transcript.order)
+            if isinstance(Q, _LazyPoint):
+                Q = Q.resolve()
             return bool(Q_check == Q)
         g_hat = g_prime
         round_i += 1
@@ -405,6 +445,11 @@ def protocol_5_prover(generators, P, L, y, x, gamma, gf, transcript=None, r=None
         r = pivot._as_device(r)
         L = pivot.AffineForm(_coeffs_dev(L), L.constant)
     gv = pivot._points_on_device(g)
+    if mode == "reference" and device_mode and isinstance(g, PointVector):
+        # the O(N) part of the first pre-image does not depend on A: format and copy it while
+        # the announcement's MSM runs
+        gv.text_begin()
+        L.coeffs.text_begin()
 
     logger_cp.debug("Calculate t.")
     t = L(r)

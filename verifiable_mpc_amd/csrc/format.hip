@@ -109,6 +109,73 @@ static int fmt_common(vmpc_ctx *ctx, const void *src, size_t n, bool points, int
     return VMPC_OK;
 }
 
+// Asynchronous variant: everything (lengths, scan, text, the two device->host copies) is
+// enqueued on the context's stream and the call returns at once.  `host_text` / `host_len` must
+// be pinned (vmpc_host_alloc) and stay valid until the stream has been synchronised; `cap` bytes
+// are copied (the text is at most ~1 % shorter than its worst case).  Lets the pre-image of the
+// next Fiat-Shamir hash be produced and moved while the round's MSMs run.
+static int fmt_async(vmpc_ctx *ctx, const void *src, size_t n, bool points, int is_signed, void *dev_text,
+                     size_t cap, void *host_text, uint64_t *host_len) {
+    if (!ctx || !host_len || (n && (!src || !dev_text || !host_text))) return VMPC_E_INVAL;
+    size_t worst = n * (points ? (3 * 78 + 8) : (78 + 3));
+    if (cap < worst) return VMPC_E_NOMEM;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (n == 0) {
+        *host_len = 0;
+        return VMPC_OK;
+    }
+    size_t need = vmpc_align(n * 4) + vmpc_align(n * 8) + vmpc_scan_ws_bytes(n, 8) + 512;
+    VMPC_CHECK(vmpc_ws_reserve(ctx, need));
+    uint32_t *lens = (uint32_t *)vmpc_ws_take(ctx, n * 4);
+    uint64_t *offs = (uint64_t *)vmpc_ws_take(ctx, n * 8);
+    uint64_t *total = (uint64_t *)vmpc_ws_take(ctx, 8);
+    void *scan_ws = vmpc_ws_take(ctx, vmpc_scan_ws_bytes(n, 8));
+    unsigned g = (unsigned)((n + FMT_BLOCK - 1) / FMT_BLOCK);
+    vmpc_stage_scope s(ctx, "format_async");
+    if (points)
+        k_fmt_points_len<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, lens);
+    else
+        k_fmt_scalars_len<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, is_signed, lens);
+    VMPC_KERNEL_CHECK();
+    VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint64_t>(st, lens, offs, n, scan_ws, total)));
+    if (points)
+        k_fmt_points_write<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, offs, (char *)dev_text);
+    else
+        k_fmt_scalars_write<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, is_signed, offs,
+                                                    (char *)dev_text);
+    VMPC_KERNEL_CHECK();
+    VMPC_HIP_CHECK(hipMemcpyAsync(host_len, total, 8, hipMemcpyDeviceToHost, st));
+    VMPC_HIP_CHECK(hipMemcpyAsync(host_text, dev_text, worst, hipMemcpyDeviceToHost, st));
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_format_points_async_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *dev_text,
+                                            size_t cap, void *host_text, uint64_t *host_len) {
+    return fmt_async(ctx, proj, n, true, 0, dev_text, cap, host_text, host_len);
+}
+
+extern "C" int vmpc_format_scalars_async_dev(vmpc_ctx *ctx, const void *scalars, size_t n, int is_signed,
+                                             void *dev_text, size_t cap, void *host_text,
+                                             uint64_t *host_len) {
+    return fmt_async(ctx, scalars, n, false, is_signed, dev_text, cap, host_text, host_len);
+}
+
+extern "C" int vmpc_host_alloc(size_t bytes, void **out) {
+    if (!out) return VMPC_E_INVAL;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        return VMPC_E_NOMEM;
+    }
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_host_free(void *p) {
+    if (p) VMPC_HIP_CHECK(hipHostFree(p));
+    return VMPC_OK;
+}
+
 extern "C" int vmpc_format_points_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *out_text,
                                       size_t cap, uint64_t *len) {
     return fmt_common(ctx, proj, n, true, 0, out_text, cap, len);

@@ -30,24 +30,24 @@ def get_context():
     return _CTX
 
 
-_AUX = None
+_AUX = {}
 
 
-def get_aux_context():
-    """Second context (own stream + workspace) on the same GPU, used to run the two
-    independent MSMs of a Protocol-4 round concurrently."""
-    global _AUX
-    if _AUX is None:
-        _AUX = _native.Context(get_context().device)
-    return _AUX
+def get_aux_context(index=0):
+    """Additional contexts (own stream + workspace) on the same GPU: index 0 runs B_i next to
+    A_i (the two independent MSMs of a Protocol-4 round), index 1 the small Q' product."""
+    if index not in _AUX:
+        _AUX[index] = _native.Context(get_context().device)
+    return _AUX[index]
 
 
 def reset_context():
-    global _CTX, _AUX
-    for c in (_AUX, _CTX):
+    global _CTX
+    for c in list(_AUX.values()) + [_CTX]:
         if c is not None:
             c.close()
-    _CTX = _AUX = None
+    _AUX.clear()
+    _CTX = None
 
 
 def reduce_scalar(v):
@@ -152,8 +152,19 @@ class ScalarVector:
         assert len(other) == len(self)
         return self.ctx.fr_dot(self.ptr, other.ptr, len(self))
 
+    def text_begin(self, is_signed=True):
+        """start producing the transcript text on the side stream (no host wait): formatting and
+        the device->host copy then overlap the kernels that follow on the main stream"""
+        if len(self):
+            side = get_aux_context(2)
+            side.wait_for(self.ctx)
+            self._pending_text = (is_signed, side.format_begin("scalars", self.ptr, len(self), is_signed))
+
     def text(self, is_signed=True):
         """b'v0, v1, ..., ' as produced on the device (uint8 array)."""
+        pend = getattr(self, "_pending_text", None)
+        if pend is not None and pend[0] == is_signed:
+            return pend[1].result()
         return self.ctx.format_scalars(self.ptr, len(self), is_signed)
 
     def __repr__(self):
@@ -292,10 +303,20 @@ class PointVector:
         return PointVector(_View(abuf, 0, half, 64), _View(pbuf, 0, half, 96) if pbuf else None,
                            self.ctx)
 
+    def text_begin(self):
+        """start producing the transcript text on the side stream (no host wait)"""
+        if self.p is not None and len(self):
+            side = get_aux_context(2)
+            side.wait_for(self.ctx)
+            self._pending_text = side.format_begin("points", self.p.ptr, len(self))
+
     def text(self):
         """b'[X, Y, Z], [X, Y, Z], ..., ' (uint8 array) for the Fiat-Shamir pre-image."""
         if self.p is None:
             raise ValueError("projective representatives were not kept for this vector")
+        pend = getattr(self, "_pending_text", None)
+        if pend is not None:
+            return pend.result()
         return self.ctx.format_points(self.p.ptr, len(self))
 
     def __repr__(self):
