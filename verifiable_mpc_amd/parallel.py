@@ -34,10 +34,13 @@ class HipBackend:
     commitments overlap: the latency-bound tail of one MSM (bucket reduction, Horner chain)
     runs next to the throughput-bound head of the next."""
 
-    def __init__(self, ctx, torch, n_slots=2):
+    def __init__(self, ctx, torch, n_slots=None):
+        import os
         from .device import get_aux_context
+        if n_slots is None:
+            n_slots = int(os.environ.get("VMPC_MSM_SLOTS", "3"))
         self.torch = torch
-        self.ctxs = [ctx] + ([get_aux_context()] if n_slots > 1 else [])
+        self.ctxs = [ctx] + [get_aux_context(10 + i) for i in range(max(0, n_slots - 1))]
         self.partial_bufs = [torch.zeros(128, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
         self.combine_bufs = [torch.zeros(128, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
 
