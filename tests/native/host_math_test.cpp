@@ -40,9 +40,14 @@ static std::string to_hex(const uint32_t *v, int limbs) {
 static fe rd_fe(std::istringstream &is) {
     std::string h;
     is >> h;
-    fe r;
-    parse_hex(h, r.v, 8);
-    return r;
+    uint32_t w[8];
+    parse_hex(h, w, 8);
+    return fe_unpack(w);
+}
+static void rd_raw8(std::istringstream &is, uint32_t w[8]) {
+    std::string h;
+    is >> h;
+    parse_hex(h, w, 8);
 }
 static fr rd_fr(std::istringstream &is) {
     std::string h;
@@ -52,8 +57,8 @@ static fr rd_fr(std::istringstream &is) {
     return r;
 }
 static std::string fehex(const fe &a) {
-    fe c = fe_canon(a);
-    return to_hex(c.v, 8);
+    fe8 c = fe_pack(a);
+    return to_hex(c.w, 8);
 }
 static std::string frhex(const fr &a) { return to_hex(a.v, 8); }
 
@@ -148,14 +153,22 @@ int main() {
             std::cout << fehex(fe_sub(a, b)) << "\n";
         } else if (cmd == "femulu32") {
             fe a = rd_fe(is);
-            fe s = rd_fe(is);
-            std::cout << fehex(fe_mul_u32(a, s.v[0])) << "\n";
+            uint32_t sw[8];
+            rd_raw8(is, sw);
+            std::cout << fehex(fe_mul_u32(a, sw[0])) << "\n";
         } else if (cmd == "feinv") {
             fe a = rd_fe(is);
             std::cout << fehex(fe_inv(a)) << "\n";
         } else if (cmd == "fecanon") {
-            fe a = rd_fe(is);
-            std::cout << fehex(a) << " " << (fe_is_canonical(a) ? 1 : 0) << "\n";
+            uint32_t w[8];
+            rd_raw8(is, w);
+            std::cout << fehex(fe_unpack(w)) << " " << (fe8_is_canonical(w) ? 1 : 0) << "\n";
+        } else if (cmd == "felazy") {
+            // (a + b) * (c + d) with lazy sums, and (a+b)^2: the operand bound of fe_mul / fe_sqr
+            fe a = rd_fe(is), b = rd_fe(is), c = rd_fe(is), d = rd_fe(is);
+            std::cout << fehex(fe_mul(fe_add_lazy(a, b), fe_add_lazy(c, d))) << " "
+                      << fehex(fe_sqr(fe_add_lazy(a, b))) << " " << fehex(fe_sub(fe_add_lazy(a, b), fe_add_lazy(c, d)))
+                      << "\n";
         } else if (cmd == "consts") {
             std::cout << fehex(fe_const_d()) << " " << fehex(fe_const_d2()) << "\n";
         } else if (cmd == "fradd") {
@@ -182,11 +195,12 @@ int main() {
             buf[n] = 0;
             std::cout << buf << " " << fr_repr_len(a, sg != 0) << "\n";
         } else if (cmd == "dec") {
-            fe a = rd_fe(is);
+            uint32_t w[8];
+            rd_raw8(is, w);
             char buf[100];
-            int n = u256_write_decimal(a.v, buf);
+            int n = u256_write_decimal(w, buf);
             buf[n] = 0;
-            std::cout << buf << " " << u256_decimal_len(a.v) << "\n";
+            std::cout << buf << " " << u256_decimal_len(w) << "\n";
         } else if (cmd == "padd" || cmd == "pdbl" || cmd == "prepeat" || cmd == "prepr") {
             ge_proj p;
             p.X = rd_fe(is);
@@ -202,14 +216,15 @@ int main() {
             } else if (cmd == "pdbl") {
                 r = ge_proj_dbl(p);
             } else if (cmd == "prepeat") {
-                fe n = rd_fe(is);
-                r = ge_proj_repeat(p, n.v);
+                uint32_t nw[8];
+                rd_raw8(is, nw);
+                r = ge_proj_repeat(p, nw);
             } else {
-                ge_proj c = ge_proj_canon(p);
+                fe8 cx = fe_pack(p.X), cy = fe_pack(p.Y), cz = fe_pack(p.Z);
                 char buf[300];
-                int n = proj_repr_write(c.X.v, c.Y.v, c.Z.v, buf);
+                int n = proj_repr_write(cx.w, cy.w, cz.w, buf);
                 buf[n] = 0;
-                std::cout << buf << "|" << proj_repr_len(c.X.v, c.Y.v, c.Z.v) << "\n";
+                std::cout << buf << "|" << proj_repr_len(cx.w, cy.w, cz.w) << "\n";
                 continue;
             }
             std::cout << fehex(r.X) << " " << fehex(r.Y) << " " << fehex(r.Z) << "\n";

@@ -58,6 +58,12 @@ def test_field_ops(harness):
             want.append(hx(pow(a, P - 2, P)))
     lines.append("consts")
     want.append(f"{hx(ed.D)} {hx(ed.D2)}")
+    # lazy sums as multiplication operands: the documented bound (one un-carried addition)
+    big = [P - 1, 2**255 - 20, 2**256 - 1, 2**256 - 38, (1 << 255) - 1] + [rng.getrandbits(256) for _ in range(40)]
+    for _ in range(200):
+        a, b, c, d = (rng.choice(big) for _ in range(4))
+        lines.append(f"felazy {hx(a)} {hx(b)} {hx(c)} {hx(d)}")
+        want.append(f"{hx((a + b) * (c + d) % P)} {hx((a + b) ** 2 % P)} {hx((a + b - c - d) % P)}")
     assert harness(lines) == want
 
 

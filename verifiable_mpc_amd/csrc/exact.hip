@@ -20,18 +20,18 @@
 // vectors up to this many elements use four lanes per element (latency-bound regime)
 #define EX_FOLD_QUAD_MAX (16 * 1024)
 
+// public buffers hold packed 32-byte canonical elements: two 16-byte accesses per element
 __device__ __forceinline__ fe ex_fe_ld(const uint32_t *src) {
     const uint4 *p = reinterpret_cast<const uint4 *>(src);
     uint4 a = p[0], b = p[1];
-    fe r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    return r;
+    uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return fe_unpack(w);
 }
 __device__ __forceinline__ void ex_fe_st(uint32_t *dst, const fe &a) {
+    fe8 c = fe_pack(a);
     uint4 *p = reinterpret_cast<uint4 *>(dst);
-    p[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
-    p[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+    p[0] = make_uint4(c.w[0], c.w[1], c.w[2], c.w[3]);
+    p[1] = make_uint4(c.w[4], c.w[5], c.w[6], c.w[7]);
 }
 __device__ __forceinline__ ge_proj ex_load_point(const uint32_t *base, size_t i, bool affine) {
     ge_proj p;
@@ -48,11 +48,10 @@ __device__ __forceinline__ ge_proj ex_load_point(const uint32_t *base, size_t i,
 }
 __device__ __forceinline__ void ex_store_point(const ge_proj &r, size_t i, uint32_t *out_proj,
                                                uint32_t *out_aff) {
-    if (out_proj) {
-        ge_proj c = ge_proj_canon(r);
-        ex_fe_st(out_proj + 24 * i, c.X);
-        ex_fe_st(out_proj + 24 * i + 8, c.Y);
-        ex_fe_st(out_proj + 24 * i + 16, c.Z);
+    if (out_proj) {      // ex_fe_st writes the canonical residue
+        ex_fe_st(out_proj + 24 * i, r.X);
+        ex_fe_st(out_proj + 24 * i + 8, r.Y);
+        ex_fe_st(out_proj + 24 * i + 16, r.Z);
     }
     if (out_aff) {
         ge_aff a = ge_proj_to_affine(r);
@@ -200,7 +199,6 @@ k_tree_level(const uint32_t *__restrict__ in, size_t len, uint32_t *__restrict__
     }
     size_t i = odd + 2 * (t - odd);
     r = ge_proj_add(ex_load_point(in, i, false), ex_load_point(in, i + 1, false));
-    r = ge_proj_canon(r);
     ex_fe_st(out + 24 * t, r.X);
     ex_fe_st(out + 24 * t + 8, r.Y);
     ex_fe_st(out + 24 * t + 16, r.Z);

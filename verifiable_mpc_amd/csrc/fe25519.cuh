@@ -1,19 +1,29 @@
-// GF(2^255-19) arithmetic for gfx950, 8 x 32-bit saturated limbs.
+// GF(2^255-19) arithmetic for gfx950: 10 unsaturated limbs, radix 2^25.5.
 //
 // Replaces the MPyC prime-field element arithmetic that every curve operation of the
 // reference's hot path bottoms out in (verifiable_mpc/ac20/pivot.py:143-144 ->
 // mpyc.fingroups / mpyc.finfields; SURVEY.md section 8a "EllipticCurve element type").
 //
-// Values are kept "loosely reduced": any 256-bit residue representative (0 <= v < 2^256).
-// 2^256 = 38 (mod p), so a carry out of the top limb folds back as +38.  fe_canon()
-// produces the unique representative in [0, p) and is applied before bytes leave the
-// device or two elements are compared.
+// Why unsaturated limbs: on gfx950 a 32x32->64 multiply-add (v_mad_u64_u32) is the only wide
+// multiplier, and CARRIES are what is expensive - a saturated 8 x 32-bit product costs, per
+// partial product, the mad plus a v_addc through the carry-out plus a hazard s_nop plus register
+// pair shuffling (measured: ~385 instructions per multiplication inside the MSM bucket kernel).
+// With limbs of 26/25 bits (value = sum v[i] * 2^ceil(25.5 i)) ten partial products fit a
+// 64-bit accumulator without overflow, the wrap-around of 2^255 = 19 is folded into the
+// operands (19 * g_j), and a product is 100 bare multiply-adds plus one short carry pass;
+// a squaring is 55.  Additions are limb-wise.
 //
-// The products are written as 32x32->64 multiply-adds ((uint64_t)a*b + c) which hipcc
-// lowers to v_mad_u64_u32; there is no MFMA use (255-bit modular integers).
+// Limb bounds: "reduced" means v[even] < 2^26 + 2^16, v[odd] < 2^25 + 2^16.  fe_mul / fe_sqr accept
+// operands with limbs up to 2^27 (even) / 2^26 (odd) - i.e. reduced values or ONE lazy sum of two
+// of them (fe_add_lazy) - and return reduced values; fe_add / fe_sub / fe_neg return reduced values.
+//
+// Memory format (`fe8`): 32 bytes little-endian = 8 LE uint32 words, canonical residue < p on
+// every public buffer (include/vmpc.h).  fe_unpack / fe_pack convert; internal workspaces keep
+// the 10 limbs (40 bytes per element).
 //
 // All functions are VMPC_HD so the same source is unit-tested on the host
-// (tests/native/host_math_test.cpp) against the Python oracle.
+// (tests/native/host_math_test.cpp) against the Python oracle.  No MFMA use (255-bit modular
+// integers).
 #pragma once
 #include <stdint.h>
 
@@ -25,14 +35,19 @@
 #endif
 #endif
 
+#define FE_LIMBS 10
+
 struct fe {
-    uint32_t v[8];
+    uint32_t v[FE_LIMBS];
 };
+
+#define FE_MASK26 0x3ffffffu
+#define FE_MASK25 0x1ffffffu
 
 VMPC_HD fe fe_zero() {
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = 0;
+    for (int i = 0; i < FE_LIMBS; i++) r.v[i] = 0;
     return r;
 }
 
@@ -44,298 +59,266 @@ VMPC_HD fe fe_one() {
 
 VMPC_HD fe fe_from_u32(uint32_t x) {
     fe r = fe_zero();
-    r.v[0] = x;
+    r.v[0] = x & FE_MASK26;
+    r.v[1] = x >> 26;
     return r;
 }
 
-// r = a + b  (mod p, loosely reduced)
+// one carry pass over 32-bit limbs (each < 2^31): result reduced
+VMPC_HD fe fe_carry32(const uint32_t h_in[FE_LIMBS]) {
+    uint32_t h[FE_LIMBS];
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) h[i] = h_in[i];
+    uint32_t c;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS - 1; i++) {
+        if (i & 1) {
+            c = h[i] >> 25;
+            h[i] &= FE_MASK25;
+        } else {
+            c = h[i] >> 26;
+            h[i] &= FE_MASK26;
+        }
+        h[i + 1] += c;
+    }
+    c = h[9] >> 25;
+    h[9] &= FE_MASK25;
+    h[0] += 19u * c;
+    c = h[0] >> 26;
+    h[0] &= FE_MASK26;
+    h[1] += c;
+    fe r;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) r.v[i] = h[i];
+    return r;
+}
+
+// carry pass over the 64-bit column sums of a product
+VMPC_HD fe fe_carry64(uint64_t h[FE_LIMBS]) {
+    uint64_t c;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS - 1; i++) {
+        if (i & 1) {
+            c = h[i] >> 25;
+            h[i] &= FE_MASK25;
+        } else {
+            c = h[i] >> 26;
+            h[i] &= FE_MASK26;
+        }
+        h[i + 1] += c;
+    }
+    c = h[9] >> 25;
+    h[9] &= FE_MASK25;
+    h[0] += 19u * c;
+    c = h[0] >> 26;
+    h[0] &= FE_MASK26;
+    h[1] += c;
+    fe r;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) r.v[i] = (uint32_t)h[i];
+    return r;
+}
+
+// limb-wise sum, NOT carried: only as an operand of fe_mul / fe_sqr / fe_sub / fe_add of
+// reduced values (see the bounds at the top)
+VMPC_HD fe fe_add_lazy(const fe &a, const fe &b) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+
+// r = a + b, reduced
 VMPC_HD fe fe_add(const fe &a, const fe &b) {
-    fe r;
-    uint64_t c = 0;
+    uint32_t h[FE_LIMBS];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.v[i] + b.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    // fold the carry twice (the second fold can only trigger on a tiny value)
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        uint64_t t = (uint64_t)r.v[0] + 38u * (uint32_t)c;
-        r.v[0] = (uint32_t)t;
-        c = t >> 32;
-#pragma unroll
-        for (int i = 1; i < 8; i++) {
-            c += r.v[i];
-            r.v[i] = (uint32_t)c;
-            c >>= 32;
-        }
-    }
-    return r;
+    for (int i = 0; i < FE_LIMBS; i++) h[i] = a.v[i] + b.v[i];
+    return fe_carry32(h);
 }
 
-// r = a - b  (mod p, loosely reduced)
+// r = a - b, reduced: a + 4p - b limb-wise (b's limbs may be up to 2^27 / 2^26), then one carry
 VMPC_HD fe fe_sub(const fe &a, const fe &b) {
-    fe r;
-    int64_t c = 0;
+    uint32_t h[FE_LIMBS];
+    h[0] = a.v[0] + 0xfffffb4u - b.v[0];          // 4 * (2^26 - 19)
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (int64_t)a.v[i] - (int64_t)b.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;  // arithmetic shift: 0 or -1
-    }
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        int64_t t = (int64_t)r.v[0] - 38 * (-c);  // c is 0 or -1: subtract 38 on borrow
-        r.v[0] = (uint32_t)t;
-        c = t >> 32;
-#pragma unroll
-        for (int i = 1; i < 8; i++) {
-            c += (int64_t)r.v[i];
-            r.v[i] = (uint32_t)c;
-            c >>= 32;
-        }
-    }
-    return r;
+    for (int i = 1; i < FE_LIMBS; i++)
+        h[i] = a.v[i] + ((i & 1) ? 0x7fffffcu : 0xffffffcu) - b.v[i];   // 4*(2^25-1) / 4*(2^26-1)
+    return fe_carry32(h);
 }
 
 VMPC_HD fe fe_neg(const fe &a) { return fe_sub(fe_zero(), a); }
-
-// 512-bit -> 256-bit: t[0..15] -> lo + 38*hi, then fold the small carry.
-VMPC_HD fe fe_reduce512(const uint32_t t[16]) {
-    fe r;
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)t[i + 8] * 38u + t[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    // c < 39: fold twice
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        uint64_t u = (uint64_t)r.v[0] + 38u * (uint32_t)c;
-        r.v[0] = (uint32_t)u;
-        c = u >> 32;
-#pragma unroll
-        for (int i = 1; i < 8; i++) {
-            c += r.v[i];
-            r.v[i] = (uint32_t)c;
-            c >>= 32;
-        }
-    }
-    return r;
-}
-
-// ---- device fast path -------------------------------------------------------------------
-// On gfx950 the generic C forms below compile to 74 v_mad_u64_u32 + 71 64-bit adds + ~200
-// v_mov per multiplication (zero-extended addends need register pairs).  The device path
-// scans product columns with a 96-bit accumulator kept in (acc:64, ovf:32): each partial
-// product is one v_mad_u64_u32 whose carry-out feeds a v_addc, i.e. 64 mads + 64 addc.
-// Measured on MI355X (scripts/fe_bench.hip): 190-216 vs 150 G mul/s chip-wide.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(VMPC_NO_DEVICE_ASM)
-#define VMPC_DEVICE_ASM 1
-__device__ __forceinline__ void fe_mac96(uint64_t &acc, uint32_t &ovf, uint32_t a, uint32_t b) {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-        : "+v"(acc), "+v"(ovf)
-        : "v"(a), "v"(b)
-        : "vcc");
-}
-#endif
+VMPC_HD fe fe_dbl(const fe &a) { return fe_add(a, a); }
 
 // r = a * b
-VMPC_HD fe fe_mul(const fe &a, const fe &b) {
-    uint32_t t[16];
-#ifdef VMPC_DEVICE_ASM
-    uint64_t acc = 0;
-    uint32_t ovf = 0;
+VMPC_HD fe fe_mul(const fe &f, const fe &g) {
+    uint32_t g19[FE_LIMBS], f2[FE_LIMBS];
 #pragma unroll
-    for (int k = 0; k < 15; k++) {
+    for (int j = 0; j < FE_LIMBS; j++) {
+        g19[j] = 19u * g.v[j];
+        f2[j] = 2u * f.v[j];
+    }
+    uint64_t h[FE_LIMBS];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int j = k - i;
-            if (j >= 0 && j < 8) fe_mac96(acc, ovf, a.v[i], b.v[j]);
+    for (int k = 0; k < FE_LIMBS; k++) h[k] = 0;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) {
+#pragma unroll
+        for (int j = 0; j < FE_LIMBS; j++) {
+            const int k = i + j;
+            const bool wrap = k >= FE_LIMBS;
+            const uint32_t fi = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
+            const uint32_t gj = wrap ? g19[j] : g.v[j];
+            h[wrap ? k - FE_LIMBS : k] += (uint64_t)fi * gj;
         }
-        t[k] = (uint32_t)acc;
-        acc = (acc >> 32) | ((uint64_t)ovf << 32);
-        ovf = 0;
     }
-    t[15] = (uint32_t)acc;
-#else
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        c += (uint64_t)a.v[0] * b.v[j];
-        t[j] = (uint32_t)c;
-        c >>= 32;
-    }
-    t[8] = (uint32_t)c;
-#pragma unroll
-    for (int i = 1; i < 8; i++) {
-        c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c += (uint64_t)a.v[i] * b.v[j] + t[i + j];
-            t[i + j] = (uint32_t)c;
-            c >>= 32;
-        }
-        t[i + 8] = (uint32_t)c;
-    }
-#endif
-    return fe_reduce512(t);
+    return fe_carry64(h);
 }
 
-// r = a^2  (off-diagonal products computed once and doubled)
-VMPC_HD fe fe_sqr(const fe &a) {
-    uint32_t t[16];
-#if defined(VMPC_DEVICE_ASM) && defined(VMPC_SQR_ASM)   // measured no faster than the C form: off
-    // per column: off-diagonal products once, doubled as a 96-bit value, plus the square
-    uint64_t acc = 0;
-    uint32_t ovf = 0;
+// r = a^2: 55 products
+VMPC_HD fe fe_sqr(const fe &f) {
+    uint32_t f2[FE_LIMBS], f19[FE_LIMBS], f38[FE_LIMBS];
 #pragma unroll
-    for (int k = 0; k < 15; k++) {
-        uint64_t o = 0;
-        uint32_t oo = 0;
+    for (int j = 0; j < FE_LIMBS; j++) {
+        f2[j] = 2u * f.v[j];
+        f19[j] = 19u * f.v[j];
+        f38[j] = 38u * f.v[j];
+    }
+    uint64_t h[FE_LIMBS];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int j = k - i;
-            if (j > i && j < 8) fe_mac96(o, oo, a.v[i], a.v[j]);
+    for (int k = 0; k < FE_LIMBS; k++) h[k] = 0;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) {
+#pragma unroll
+        for (int j = i; j < FE_LIMBS; j++) {
+            const int k = i + j;
+            const bool wrap = k >= FE_LIMBS;
+            const bool odd2 = (i & 1) && (j & 1);
+            const uint32_t left = (i < j) ? f2[i] : f.v[i];
+            const uint32_t right = wrap ? (odd2 ? f38[j] : f19[j]) : (odd2 ? f2[j] : f.v[j]);
+            h[wrap ? k - FE_LIMBS : k] += (uint64_t)left * right;
         }
-        // (acc, ovf) += 2 * (o, oo)
-        oo = (oo << 1) | (uint32_t)(o >> 63);
-        o <<= 1;
-        uint64_t s = acc + o;
-        ovf += oo + (uint32_t)(s < acc);
-        acc = s;
-        if ((k & 1) == 0) fe_mac96(acc, ovf, a.v[k >> 1], a.v[k >> 1]);
-        t[k] = (uint32_t)acc;
-        acc = (acc >> 32) | ((uint64_t)ovf << 32);
-        ovf = 0;
     }
-    t[15] = (uint32_t)acc;
-#else
-    uint64_t c;
-#pragma unroll
-    for (int i = 0; i < 16; i++) t[i] = 0;
-    // off-diagonal: sum_{i<j} a_i a_j
-#pragma unroll
-    for (int i = 0; i < 7; i++) {
-        c = 0;
-#pragma unroll
-        for (int j = i + 1; j < 8; j++) {
-            c += (uint64_t)a.v[i] * a.v[j] + t[i + j];
-            t[i + j] = (uint32_t)c;
-            c >>= 32;
-        }
-        t[i + 8] = (uint32_t)c;
-    }
-    // double
-    uint32_t top = 0;
-#pragma unroll
-    for (int i = 1; i < 16; i++) {
-        uint32_t nt = t[i] >> 31;
-        t[i] = (t[i] << 1) | top;
-        top = nt;
-    }
-    // add diagonal squares
-    c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t sq = (uint64_t)a.v[i] * a.v[i];
-        c += (uint64_t)t[2 * i] + (uint32_t)sq;
-        t[2 * i] = (uint32_t)c;
-        c >>= 32;
-        c += (uint64_t)t[2 * i + 1] + (uint32_t)(sq >> 32);
-        t[2 * i + 1] = (uint32_t)c;
-        c >>= 32;
-    }
-#endif
-    return fe_reduce512(t);
+    return fe_carry64(h);
 }
 
 // r = a * small (small < 2^32)
 VMPC_HD fe fe_mul_u32(const fe &a, uint32_t s) {
-    fe r;
-    uint64_t c = 0;
+    uint64_t h[FE_LIMBS];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.v[i] * s;
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    // c < 2^32: fold c*38 (up to 38 bits) into limbs 0..1
+    for (int i = 0; i < FE_LIMBS; i++) h[i] = (uint64_t)a.v[i] * s;
+    fe r = fe_carry64(h);          // h[0] may still hold a large 19*c term: one more pass
+    uint32_t t[FE_LIMBS];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        uint64_t u = c * 38u;  // first pass: < 2^38; second pass: c is 0/1
-        uint64_t w = (uint64_t)r.v[0] + (uint32_t)u;
-        r.v[0] = (uint32_t)w;
-        w = (w >> 32) + r.v[1] + (u >> 32);
-        r.v[1] = (uint32_t)w;
-        c = w >> 32;
-#pragma unroll
-        for (int i = 2; i < 8; i++) {
-            c += r.v[i];
-            r.v[i] = (uint32_t)c;
-            c >>= 32;
-        }
-    }
-    return r;
-}
-
-VMPC_HD fe fe_dbl(const fe &a) { return fe_add(a, a); }
-
-// canonical representative in [0, p)
-VMPC_HD fe fe_canon(const fe &a) {
-    // p = 2^255 - 19.  a < 2^256 = 2p + 38, so at most two subtractions of p.
-    fe r = a;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        // s = r - p = r + 19 - 2^255
-        uint32_t s[8];
-        uint64_t c = 19;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            c += r.v[i];
-            s[i] = (uint32_t)c;
-            c >>= 32;
-        }
-        // r >= p  <=>  (r + 19) >= 2^255  <=> bit 255 of (r+19) set or carry out
-        uint32_t ge = (uint32_t)c | (s[7] >> 31);
-        s[7] &= 0x7fffffffu;
-        if (c) s[7] |= 0x80000000u;  // r + 19 >= 2^256: after removing 2^255 the bit stays
-        uint32_t m = 0u - (ge & 1u);
-#pragma unroll
-        for (int i = 0; i < 8; i++) r.v[i] = (s[i] & m) | (r.v[i] & ~m);
-    }
-    return r;
-}
-
-VMPC_HD bool fe_is_zero(const fe &a) {
-    fe c = fe_canon(a);
-    uint32_t o = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o |= c.v[i];
-    return o == 0;
-}
-
-VMPC_HD bool fe_eq(const fe &a, const fe &b) { return fe_is_zero(fe_sub(a, b)); }
-
-// a < p as a raw 256-bit integer (canonical-encoding check at the C-ABI boundary)
-VMPC_HD bool fe_is_canonical(const fe &a) {
-    if (a.v[7] >> 31) return false;
-    if (a.v[7] != 0x7fffffffu) return true;
-#pragma unroll
-    for (int i = 6; i >= 1; i--)
-        if (a.v[i] != 0xffffffffu) return true;
-    return a.v[0] < 0xffffffedu;
+    for (int i = 0; i < FE_LIMBS; i++) t[i] = r.v[i];
+    return fe_carry32(t);
 }
 
 VMPC_HD fe fe_select(const fe &a, const fe &b, bool pick_b) {
     fe r;
     uint32_t m = 0u - (uint32_t)pick_b;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = (b.v[i] & m) | (a.v[i] & ~m);
+    for (int i = 0; i < FE_LIMBS; i++) r.v[i] = (b.v[i] & m) | (a.v[i] & ~m);
     return r;
+}
+
+// ---- packed form: 8 x uint32 little-endian -----------------------------------------------------
+struct fe8 {
+    uint32_t w[8];
+};
+
+// any 256-bit integer -> limbs (bit 255 folds back as +19)
+VMPC_HD fe fe_unpack(const uint32_t w[8]) {
+    fe r;
+    r.v[0] = w[0] & FE_MASK26;
+    r.v[1] = ((w[0] >> 26) | (w[1] << 6)) & FE_MASK25;
+    r.v[2] = ((w[1] >> 19) | (w[2] << 13)) & FE_MASK26;
+    r.v[3] = ((w[2] >> 13) | (w[3] << 19)) & FE_MASK25;
+    r.v[4] = (w[3] >> 6) & FE_MASK26;
+    r.v[5] = w[4] & FE_MASK25;
+    r.v[6] = ((w[4] >> 25) | (w[5] << 7)) & FE_MASK26;
+    r.v[7] = ((w[5] >> 19) | (w[6] << 13)) & FE_MASK25;
+    r.v[8] = ((w[6] >> 12) | (w[7] << 20)) & FE_MASK26;
+    r.v[9] = (w[7] >> 6) & FE_MASK25;
+    r.v[0] += 19u * (w[7] >> 31);
+    return r;
+}
+
+// limbs -> canonical residue in [0, p) as 8 words
+VMPC_HD fe8 fe_pack(const fe &a) {
+    // two carry passes: every limb strictly inside its width, value < 2^255 + 19*2
+    uint32_t t[FE_LIMBS];
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) t[i] = a.v[i];
+    fe r = fe_carry32(t);
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) t[i] = r.v[i];
+    r = fe_carry32(t);
+    // assemble the (at most 256-bit) integer
+    uint64_t acc[8];
+    acc[0] = (uint64_t)r.v[0] + ((uint64_t)r.v[1] << 26);
+    acc[1] = ((uint64_t)r.v[2] << 19);
+    acc[2] = ((uint64_t)r.v[3] << 13);
+    acc[3] = ((uint64_t)r.v[4] << 6);
+    acc[4] = (uint64_t)r.v[5] + ((uint64_t)r.v[6] << 25);
+    acc[5] = ((uint64_t)r.v[7] << 19);
+    acc[6] = ((uint64_t)r.v[8] << 12);
+    acc[7] = ((uint64_t)r.v[9] << 6);
+    uint32_t w[8];
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += acc[i];
+        w[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    // value < 2^256: subtract p while >= p (at most twice; value < 2p + small)
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        uint32_t s[8];
+        uint64_t d = 19;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            d += w[i];
+            s[i] = (uint32_t)d;
+            d >>= 32;
+        }
+        uint32_t ge = (uint32_t)d | (s[7] >> 31);
+        s[7] &= 0x7fffffffu;
+        if (d) s[7] |= 0x80000000u;
+        uint32_t m = 0u - (ge & 1u);
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = (s[i] & m) | (w[i] & ~m);
+    }
+    fe8 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.w[i] = w[i];
+    return o;
+}
+
+// canonical limbs (every limb inside its width, value < p)
+VMPC_HD fe fe_canon(const fe &a) {
+    fe8 p = fe_pack(a);
+    return fe_unpack(p.w);
+}
+
+VMPC_HD bool fe_is_zero(const fe &a) {
+    fe8 c = fe_pack(a);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= c.w[i];
+    return o == 0;
+}
+
+VMPC_HD bool fe_eq(const fe &a, const fe &b) { return fe_is_zero(fe_sub(a, b)); }
+
+// w < p as a raw 256-bit integer (canonical-encoding check at the C-ABI boundary)
+VMPC_HD bool fe8_is_canonical(const uint32_t w[8]) {
+    if (w[7] >> 31) return false;
+    if (w[7] != 0x7fffffffu) return true;
+#pragma unroll
+    for (int i = 6; i >= 1; i--)
+        if (w[i] != 0xffffffffu) return true;
+    return w[0] < 0xffffffedu;
 }
 
 VMPC_HD fe fe_sqr_n(fe a, int n) {
@@ -359,38 +342,46 @@ VMPC_HD fe fe_inv(const fe &z) {
     return fe_mul(fe_sqr_n(z2_250_0, 5), z11);  // 2^255 - 21
 }
 
-// ---- memory format: 32 bytes little-endian == 8 LE uint32 limbs --------------------
-VMPC_HD fe fe_load(const uint32_t *p) {
+// ---- memory: packed 32-byte elements (public buffers) and raw limbs (workspaces) -----------------
+VMPC_HD fe fe_load(const uint32_t *p) { return fe_unpack(p); }
+
+VMPC_HD void fe_store(uint32_t *p, const fe &a) {
+    fe8 c = fe_pack(a);
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = c.w[i];
+}
+
+VMPC_HD fe fe_load_limbs(const uint32_t *p) {
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = p[i];
+    for (int i = 0; i < FE_LIMBS; i++) r.v[i] = p[i];
     return r;
 }
 
-VMPC_HD void fe_store(uint32_t *p, const fe &a) {
+VMPC_HD void fe_store_limbs(uint32_t *p, const fe &a) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) p[i] = a.v[i];
+    for (int i = 0; i < FE_LIMBS; i++) p[i] = a.v[i];
 }
 
-// curve constants (little-endian limbs)
-// d  = -121665/121666
-#define VMPC_FE_D                                                                              \
-    {                                                                                          \
-        { 0x135978a3u, 0x75eb4dcau, 0x4141d8abu, 0x00700a4du, 0x7779e898u, 0x8cc74079u,        \
-          0x2b6ffe73u, 0x52036ceeu }                                                           \
-    }
-// 2d
-#define VMPC_FE_D2                                                                             \
-    {                                                                                          \
-        { 0x26b2f159u, 0xebd69b94u, 0x8283b156u, 0x00e0149au, 0xeef3d130u, 0x198e80f2u,        \
-          0x56dffce7u, 0x2406d9dcu }                                                           \
-    }
-
+// curve constants d = -121665/121666 and 2d (reduced limbs)
 VMPC_HD fe fe_const_d() {
-    fe r = VMPC_FE_D;
+    fe r = {{0x35978a3u, 0x0d37284u, 0x3156ebdu, 0x06a0a0eu, 0x001c029u, 0x179e898u, 0x3a03cbbu,
+             0x1ce7198u, 0x2e2b6ffu, 0x1480db3u}};
     return r;
 }
 VMPC_HD fe fe_const_d2() {
-    fe r = VMPC_FE_D2;
+    fe r = {{0x2b2f159u, 0x1a6e509u, 0x22add7au, 0x0d4141du, 0x0038052u, 0x0f3d130u, 0x3407977u,
+             0x19ce331u, 0x1c56dffu, 0x0901b67u}};
     return r;
 }
+
+// ---- shared helper of the Montgomery fields (sw256.cuh): 96-bit multiply-accumulate ----------------
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VMPC_NO_DEVICE_ASM)
+#define VMPC_DEVICE_ASM 1
+__device__ __forceinline__ void fe_mac96(uint64_t &acc, uint32_t &ovf, uint32_t a, uint32_t b) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(ovf)
+        : "v"(a), "v"(b)
+        : "vcc");
+}
+#endif

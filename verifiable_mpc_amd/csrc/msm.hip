@@ -44,31 +44,102 @@ __device__ __forceinline__ void load_u32x8(uint32_t dst[8], const uint32_t *src)
     dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
     dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
 }
-__device__ __forceinline__ void store_u32x8(uint32_t *dst, const uint32_t src[8]) {
-    uint4 *p = reinterpret_cast<uint4 *>(dst);
-    p[0] = make_uint4(src[0], src[1], src[2], src[3]);
-    p[1] = make_uint4(src[4], src[5], src[6], src[7]);
+// packed 32-byte canonical elements (public buffers)
+__device__ __forceinline__ fe fe_ld8(const uint32_t *src) {
+    uint32_t w[8];
+    load_u32x8(w, src);
+    return fe_unpack(w);
 }
+__device__ __forceinline__ void fe_st8(uint32_t *dst, const fe &a) {
+    fe8 c = fe_pack(a);
+    uint4 *p = reinterpret_cast<uint4 *>(dst);
+    p[0] = make_uint4(c.w[0], c.w[1], c.w[2], c.w[3]);
+    p[1] = make_uint4(c.w[4], c.w[5], c.w[6], c.w[7]);
+}
+// raw limbs (workspace buffers and LDS): 10 words = five 8-byte accesses
 __device__ __forceinline__ fe fe_ld(const uint32_t *src) {
+    const uint2 *p = reinterpret_cast<const uint2 *>(src);
     fe r;
-    load_u32x8(r.v, src);
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS / 2; i++) {
+        uint2 v = p[i];
+        r.v[2 * i] = v.x;
+        r.v[2 * i + 1] = v.y;
+    }
     return r;
 }
-__device__ __forceinline__ void fe_st(uint32_t *dst, const fe &a) { store_u32x8(dst, a.v); }
+__device__ __forceinline__ void fe_st(uint32_t *dst, const fe &a) {
+    uint2 *p = reinterpret_cast<uint2 *>(dst);
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS / 2; i++) p[i] = make_uint2(a.v[2 * i], a.v[2 * i + 1]);
+}
+
+#define EXT_WORDS (4 * FE_LIMBS)      // extended point in a workspace buffer / LDS
+// niels entry: 30 limbs padded to one 128-byte line, moved with eight 16-byte accesses
+#ifndef NIELS_WORDS
+#define NIELS_WORDS 32
+#endif
+
+__device__ __forceinline__ ge_niels niels_ld_line(const uint32_t *src) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(src);
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint4 v = p[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    ge_niels q;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) {
+        q.ymx.v[i] = w[i];
+        q.ypx.v[i] = w[FE_LIMBS + i];
+        q.t2d.v[i] = w[2 * FE_LIMBS + i];
+    }
+    return q;
+}
+__device__ __forceinline__ void niels_st_line(uint32_t *dst, const ge_niels &q) {
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) {
+        w[i] = q.ymx.v[i];
+        w[FE_LIMBS + i] = q.ypx.v[i];
+        w[2 * FE_LIMBS + i] = q.t2d.v[i];
+    }
+    w[30] = 0;
+    w[31] = 0;
+    uint4 *p = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
 
 __device__ __forceinline__ ge_ext ext_ld(const uint32_t *p) {
     ge_ext r;
     r.X = fe_ld(p);
-    r.Y = fe_ld(p + 8);
-    r.Z = fe_ld(p + 16);
-    r.T = fe_ld(p + 24);
+    r.Y = fe_ld(p + FE_LIMBS);
+    r.Z = fe_ld(p + 2 * FE_LIMBS);
+    r.T = fe_ld(p + 3 * FE_LIMBS);
     return r;
 }
 __device__ __forceinline__ void ext_st(uint32_t *p, const ge_ext &a) {
     fe_st(p, a.X);
-    fe_st(p + 8, a.Y);
-    fe_st(p + 16, a.Z);
-    fe_st(p + 24, a.T);
+    fe_st(p + FE_LIMBS, a.Y);
+    fe_st(p + 2 * FE_LIMBS, a.Z);
+    fe_st(p + 3 * FE_LIMBS, a.T);
+}
+// packed 128-byte extended point X||Y||Z||T (public: partial sums exchanged between ranks)
+__device__ __forceinline__ ge_ext ext_ld8(const uint32_t *p) {
+    ge_ext r;
+    r.X = fe_ld8(p);
+    r.Y = fe_ld8(p + 8);
+    r.Z = fe_ld8(p + 16);
+    r.T = fe_ld8(p + 24);
+    return r;
+}
+__device__ __forceinline__ void ext_st8(uint32_t *p, const ge_ext &a) {
+    fe_st8(p, a.X);
+    fe_st8(p + 8, a.Y);
+    fe_st8(p + 16, a.Z);
+    fe_st8(p + 24, a.T);
 }
 
 // ---- prep: affine -> niels ------------------------------------------------------------
@@ -79,13 +150,10 @@ k_msm_prep(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__re
     if (i >= n_total) return;
     const uint32_t *src = (i < n_main) ? aff + 16 * i : aff_extra + 16 * (i - n_main);
     ge_aff a;
-    a.x = fe_ld(src);
-    a.y = fe_ld(src + 8);
+    a.x = fe_ld8(src);
+    a.y = fe_ld8(src + 8);
     ge_niels q = ge_niels_from_affine(a);
-    uint32_t *dst = niels + MSM_NIELS_STRIDE * i;
-    fe_st(dst, q.ymx);
-    fe_st(dst + 8, q.ypx);
-    fe_st(dst + 16, q.t2d);
+    niels_st_line(niels + NIELS_WORDS * i, q);
 }
 
 // ---- recode: scalar -> signed digits ----------------------------------------------------
@@ -252,12 +320,7 @@ k_msm_plan2(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nbloc
 }
 
 __device__ __forceinline__ ge_niels niels_ld(const uint32_t *niels, uint32_t e) {
-    const uint32_t *src = niels + MSM_NIELS_STRIDE * (size_t)(e & 0x7fffffffu);
-    ge_niels q;
-    q.ymx = fe_ld(src);
-    q.ypx = fe_ld(src + 8);
-    q.t2d = fe_ld(src + 16);
-    return q;
+    return niels_ld_line(niels + NIELS_WORDS * (size_t)(e & 0x7fffffffu));
 }
 
 // one lane = one segment of <= MSM_SEG sorted entries
@@ -288,9 +351,9 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
         q = qn;
     }
     if (nseg[ci] == 1)
-        ext_st(buckets + 32 * msm_bucket_slot(ci, nb1), acc);
+        ext_st(buckets + EXT_WORDS * msm_bucket_slot(ci, nb1), acc);
     else
-        ext_st(partial + 32 * (size_t)(seg_starts[ci] + sidx), acc);
+        ext_st(partial + EXT_WORDS * (size_t)(seg_starts[ci] + sidx), acc);
 }
 
 // buckets that took several segments.  Lightly split ones (<= MSM_FINISH_SERIAL partial sums,
@@ -306,10 +369,10 @@ k_msm_bucket_finish_light(const uint32_t *__restrict__ heavy_list, const uint32_
         uint32_t ci = heavy_list[h];
         uint32_t ns = nseg[ci];
         if (ns > MSM_FINISH_SERIAL) continue;
-        const uint32_t *src = partial + 32 * (size_t)seg_starts[ci];
+        const uint32_t *src = partial + EXT_WORDS * (size_t)seg_starts[ci];
         ge_ext acc = ext_ld(src);
-        for (uint32_t j = 1; j < ns; j++) acc = ge_add(acc, ext_ld(src + 32 * (size_t)j));
-        ext_st(buckets + 32 * msm_bucket_slot(ci, nb1), acc);
+        for (uint32_t j = 1; j < ns; j++) acc = ge_add(acc, ext_ld(src + EXT_WORDS * (size_t)j));
+        ext_st(buckets + EXT_WORDS * msm_bucket_slot(ci, nb1), acc);
     }
 }
 
@@ -317,27 +380,27 @@ __global__ void __launch_bounds__(MSM_BLOCK)
 k_msm_bucket_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ ctrl,
                     const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
                     const uint32_t *__restrict__ partial, int nb1, uint32_t *__restrict__ buckets) {
-    __shared__ uint32_t lds[MSM_BLOCK * 32];
+    __shared__ uint32_t lds[MSM_BLOCK * EXT_WORDS];
     const uint32_t n_heavy = ctrl[0];
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         uint32_t ci = heavy_list[h];
         uint32_t ns = nseg[ci];
         if (ns <= MSM_FINISH_SERIAL) continue;          // wave-uniform: whole workgroup skips
-        const uint32_t *src = partial + 32 * (size_t)seg_starts[ci];
+        const uint32_t *src = partial + EXT_WORDS * (size_t)seg_starts[ci];
         ge_ext acc = ge_ext_identity();
-        for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x) acc = ge_add(acc, ext_ld(src + 32 * (size_t)j));
-        ext_st(lds + 32 * threadIdx.x, acc);
+        for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x) acc = ge_add(acc, ext_ld(src + EXT_WORDS * (size_t)j));
+        ext_st(lds + EXT_WORDS * threadIdx.x, acc);
         __syncthreads();
         uint32_t width = ns < MSM_BLOCK ? ns : MSM_BLOCK;   // lanes >= width hold the identity
         uint32_t stride = 1;
         while (stride < width) stride <<= 1;
         for (stride >>= 1; stride >= 1; stride >>= 1) {
             if (threadIdx.x < stride && threadIdx.x + stride < width)
-                ext_st(lds + 32 * threadIdx.x,
-                       ge_add(ext_ld(lds + 32 * threadIdx.x), ext_ld(lds + 32 * (threadIdx.x + stride))));
+                ext_st(lds + EXT_WORDS * threadIdx.x,
+                       ge_add(ext_ld(lds + EXT_WORDS * threadIdx.x), ext_ld(lds + EXT_WORDS * (threadIdx.x + stride))));
             __syncthreads();
         }
-        if (threadIdx.x == 0) ext_st(buckets + 32 * msm_bucket_slot(ci, nb1), ext_ld(lds));
+        if (threadIdx.x == 0) ext_st(buckets + EXT_WORDS * msm_bucket_slot(ci, nb1), ext_ld(lds));
         __syncthreads();
     }
 }
@@ -349,17 +412,17 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_REDUCE_WAVES)
 k_msm_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ counts, int nb,
              int chunks, int chunk_len, int log2_chunk_len, int red_blocks,
              uint32_t *__restrict__ partials) {
-    __shared__ uint32_t lds[MSM_BLOCK * 32];
+    __shared__ uint32_t lds[MSM_BLOCK * EXT_WORDS];
     const int w = blockIdx.y;
     const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
     ge_ext contrib = ge_ext_identity();
     if (chunk < chunks) {
         const int lo = chunk * chunk_len;  // 0-based bucket index; bucket value = index + 1
-        const uint32_t *bw = buckets + 32 * ((size_t)w * nb + lo);
+        const uint32_t *bw = buckets + EXT_WORDS * ((size_t)w * nb + lo);
         const uint32_t *cw = counts + (size_t)w * (nb + 1) + lo + 1;   // empty buckets are never written
         ge_ext acc = ge_ext_identity(), sum = ge_ext_identity();
         for (int j = chunk_len - 1; j >= 0; j--) {
-            if (cw[j]) acc = ge_add(acc, ext_ld(bw + 32 * j));
+            if (cw[j]) acc = ge_add(acc, ext_ld(bw + EXT_WORDS * j));
             sum = ge_add(sum, acc);
         }
         // sum = sum_j (j+1) B_{lo+j}; add lo * acc where lo = chunk * 2^log2_chunk_len
@@ -376,18 +439,18 @@ k_msm_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ 
         }
         contrib = sum;
     }
-    ext_st(lds + 32 * threadIdx.x, contrib);
+    ext_st(lds + EXT_WORDS * threadIdx.x, contrib);
     __syncthreads();
     for (int stride = MSM_BLOCK / 2; stride >= 1; stride >>= 1) {
         if ((int)threadIdx.x < stride) {
-            ge_ext a = ext_ld(lds + 32 * threadIdx.x);
-            ge_ext b = ext_ld(lds + 32 * (threadIdx.x + stride));
-            ext_st(lds + 32 * threadIdx.x, ge_add(a, b));
+            ge_ext a = ext_ld(lds + EXT_WORDS * threadIdx.x);
+            ge_ext b = ext_ld(lds + EXT_WORDS * (threadIdx.x + stride));
+            ext_st(lds + EXT_WORDS * threadIdx.x, ge_add(a, b));
         }
         __syncthreads();
     }
     if (threadIdx.x == 0)
-        ext_st(partials + 32 * ((size_t)w * red_blocks + blockIdx.x), ext_ld(lds));
+        ext_st(partials + EXT_WORDS * ((size_t)w * red_blocks + blockIdx.x), ext_ld(lds));
 }
 
 // ---- final: window sums, Horner, normalise -----------------------------------------------
@@ -440,7 +503,7 @@ __device__ __forceinline__ void quad_add_cached(ge_ext &p, const ge_cached &r, i
 __global__ void __launch_bounds__(64)
 k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
             uint32_t *__restrict__ out_ext, uint32_t *__restrict__ out_aff) {
-    __shared__ uint32_t lds[64 * 32];
+    __shared__ uint32_t lds[64 * EXT_WORDS];
     // phase 1: window sums.  lpw lanes share a window (strided partials), then a short tree.
     int lpw = 1;
     while (lpw * 2 * W <= 64 && lpw * 2 <= red_blocks) lpw *= 2;
@@ -449,23 +512,23 @@ k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
         ge_ext r = ge_ext_identity();
         if (w < W)
             for (int j = sub; j < red_blocks; j += lpw)
-                r = ge_add(r, ext_ld(partials + 32 * ((size_t)w * red_blocks + j)));
-        ext_st(lds + 32 * threadIdx.x, r);
+                r = ge_add(r, ext_ld(partials + EXT_WORDS * ((size_t)w * red_blocks + j)));
+        ext_st(lds + EXT_WORDS * threadIdx.x, r);
         __syncthreads();
         for (int stride = lpw / 2; stride >= 1; stride >>= 1) {
             if (w < W && sub < stride)
-                ext_st(lds + 32 * threadIdx.x,
-                       ge_add(ext_ld(lds + 32 * threadIdx.x), ext_ld(lds + 32 * (threadIdx.x + stride))));
+                ext_st(lds + EXT_WORDS * threadIdx.x,
+                       ge_add(ext_ld(lds + EXT_WORDS * threadIdx.x), ext_ld(lds + EXT_WORDS * (threadIdx.x + stride))));
             __syncthreads();
         }
-        ge_ext tot = ext_ld(lds + 32 * (w < W ? w * lpw : 0));
+        ge_ext tot = ext_ld(lds + EXT_WORDS * (w < W ? w * lpw : 0));
         __syncthreads();
         // window w's sum, in cached form for the cooperative additions, at slot w
         if (w < W && sub == 0) {
-            fe_st(lds + 32 * w, fe_add(tot.Y, tot.X));
-            fe_st(lds + 32 * w + 8, fe_sub(tot.Y, tot.X));
-            fe_st(lds + 32 * w + 16, fe_mul(tot.T, fe_const_d2()));
-            fe_st(lds + 32 * w + 24, fe_dbl(tot.Z));
+            fe_st(lds + EXT_WORDS * w, fe_add(tot.Y, tot.X));
+            fe_st(lds + EXT_WORDS * w + FE_LIMBS, fe_sub(tot.Y, tot.X));
+            fe_st(lds + EXT_WORDS * w + 2 * FE_LIMBS, fe_mul(tot.T, fe_const_d2()));
+            fe_st(lds + EXT_WORDS * w + 3 * FE_LIMBS, fe_dbl(tot.Z));
         }
     }
     __syncthreads();
@@ -476,18 +539,18 @@ k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
         if (k != W - 1)
             for (int j = 0; j < c; j++) quad_dbl(acc, q);
         ge_cached r;
-        r.ypx = fe_ld(lds + 32 * k);
-        r.ymx = fe_ld(lds + 32 * k + 8);
-        r.t2d = fe_ld(lds + 32 * k + 16);
-        r.z2 = fe_ld(lds + 32 * k + 24);
+        r.ypx = fe_ld(lds + EXT_WORDS * k);
+        r.ymx = fe_ld(lds + EXT_WORDS * k + FE_LIMBS);
+        r.t2d = fe_ld(lds + EXT_WORDS * k + 2 * FE_LIMBS);
+        r.z2 = fe_ld(lds + EXT_WORDS * k + 3 * FE_LIMBS);
         quad_add_cached(acc, r, q);
     }
     if (threadIdx.x == 0) {
-        if (out_ext) ext_st(out_ext, acc);
+        if (out_ext) ext_st8(out_ext, acc);        // public: packed 128-byte X||Y||Z||T
         if (out_aff) {
             ge_aff a = ge_ext_to_affine(acc);
-            fe_st(out_aff, a.x);
-            fe_st(out_aff + 8, a.y);
+            fe_st8(out_aff, a.x);
+            fe_st8(out_aff + 8, a.y);
         }
     }
 }
@@ -498,12 +561,12 @@ k_points_sum(const uint32_t *__restrict__ pts, size_t m, uint32_t *__restrict__ 
              uint32_t *__restrict__ out_aff) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     ge_ext acc = ge_ext_identity();
-    for (size_t i = 0; i < m; i++) acc = ge_add(acc, ext_ld(pts + 32 * i));
-    if (out_ext) ext_st(out_ext, acc);
+    for (size_t i = 0; i < m; i++) acc = ge_add(acc, ext_ld8(pts + 32 * i));   // packed inputs
+    if (out_ext) ext_st8(out_ext, acc);
     if (out_aff) {
         ge_aff a = ge_ext_to_affine(acc);
-        fe_st(out_aff, a.x);
-        fe_st(out_aff + 8, a.y);
+        fe_st8(out_aff, a.x);
+        fe_st8(out_aff + 8, a.y);
     }
 }
 
@@ -512,10 +575,13 @@ __global__ void __launch_bounds__(MSM_BLOCK)
 k_points_validate(const uint32_t *__restrict__ aff, size_t n, unsigned long long *__restrict__ bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    uint32_t wx[8], wy[8];
+    load_u32x8(wx, aff + 16 * i);
+    load_u32x8(wy, aff + 16 * i + 8);
     ge_aff a;
-    a.x = fe_ld(aff + 16 * i);
-    a.y = fe_ld(aff + 16 * i + 8);
-    bool ok = fe_is_canonical(a.x) && fe_is_canonical(a.y) && ge_aff_on_curve(a);
+    a.x = fe_unpack(wx);
+    a.y = fe_unpack(wy);
+    bool ok = fe8_is_canonical(wx) && fe8_is_canonical(wy) && ge_aff_on_curve(a);
     if (!ok) atomicAdd(bad, 1ull);
 }
 
@@ -683,9 +749,9 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
     msm_plan p;
     msm_make_plan(ctx, n, n_extra, 253, p);
     msm_ws w;
-    msm_layout(p, w, nullptr, MSM_NIELS_STRIDE * 4, 128);
+    msm_layout(p, w, nullptr, NIELS_WORDS * 4, EXT_WORDS * 4);
     VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
-    msm_layout(p, w, (char *)ctx->ws, MSM_NIELS_STRIDE * 4, 128);
+    msm_layout(p, w, (char *)ctx->ws, NIELS_WORDS * 4, EXT_WORDS * 4);
 
     {
         vmpc_stage_scope s(ctx, "msm_prep");

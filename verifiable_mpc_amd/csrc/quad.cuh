@@ -10,7 +10,7 @@
 __device__ __forceinline__ fe quad_bcast(const fe &a, int src /*0..3, compile-time after unroll*/) {
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < FE_LIMBS; i++) {
         int v = (int)a.v[i];
         int o;
         switch (src) {
@@ -30,7 +30,7 @@ __device__ __forceinline__ fe fe_pick4(const fe &a0, const fe &a1, const fe &a2,
     const uint32_t m2 = 0u - (uint32_t)(q == 2), m3 = 0u - (uint32_t)(q == 3);
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < FE_LIMBS; i++)
         r.v[i] = (a0.v[i] & m0) | (a1.v[i] & m1) | (a2.v[i] & m2) | (a3.v[i] & m3);
     return r;
 }
