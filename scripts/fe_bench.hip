@@ -1,37 +1,13 @@
-// Developer microbenchmark (not product): field-multiplication variants on gfx950.
+// Developer microbenchmark (not product): field-operation latency and chip-wide throughput on
+// gfx950, the yardstick the MSM bucket kernel is priced against.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/fe_bench.hip -o /tmp/fe_bench && /tmp/fe_bench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
-#include "../verifiable_mpc_amd/csrc/fe25519.cuh"
-
-// ---- variant B: product scanning, 96-bit column accumulator via carry-out ----
-__device__ __forceinline__ void mac96(uint64_t &acc, uint32_t &ovf, uint32_t a, uint32_t b) {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-        : "+v"(acc), "+v"(ovf) : "v"(a), "v"(b) : "vcc");
-}
-__device__ __forceinline__ fe fe_mul_ps(const fe &a, const fe &b) {
-    uint32_t t[16];
-    uint64_t acc = 0;
-    uint32_t ovf = 0;
-#pragma unroll
-    for (int k = 0; k < 15; k++) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            int j = k - i;
-            if (j >= 0 && j < 8) mac96(acc, ovf, a.v[i], b.v[j]);
-        }
-        t[k] = (uint32_t)acc;
-        acc = (acc >> 32) | ((uint64_t)ovf << 32);
-        ovf = 0;
-    }
-    t[15] = (uint32_t)acc;
-    return fe_reduce512(t);
-}
+#include "../verifiable_mpc_amd/csrc/ge25519.cuh"
 
 template <int V> __device__ __forceinline__ fe mulv(const fe &a, const fe &b) {
     if (V == 0) return fe_mul(a, b);
-    if (V == 1) return fe_mul_ps(a, b);
     return fe_sqr(a);
 }
 
@@ -56,6 +32,20 @@ template <int V> __global__ void k_chain4(const uint32_t *in, uint32_t *out, int
     }
     fe_store(out + 8 * i, fe_add(fe_add(a, b), fe_add(c, d)));
 }
+// mixed additions with a register-resident niels operand: the bucket kernel without memory
+__global__ void k_madd(const uint32_t *in, uint32_t *out, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ge_aff a;
+    a.x = fe_load(in + 8 * (i & 1023));
+    a.y = fe_load(in + 8 * ((i + 5) & 1023));
+    ge_niels q = ge_niels_from_affine(a);
+    ge_ext p = ge_ext_identity();
+    for (int k = 0; k < iters; k++) {
+        p = ge_madd(p, q);
+        q.t2d.v[0] ^= (uint32_t)k & 1u;
+    }
+    fe_store(out + 8 * i, fe_add(fe_add(p.X, p.Y), fe_add(p.Z, p.T)));
+}
 
 template <typename K> double run(K kern, int blocks, int threads, const uint32_t *din, uint32_t *dout, int iters) {
     hipEvent_t e0, e1;
@@ -77,28 +67,22 @@ int main() {
     hipMalloc(&din, h.size() * 4);
     hipMalloc(&dout, (size_t)8 * 4 * 256 * 1024 * 4);
     hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    // correctness of variant B vs A on a few values
-    {
-        k_chain<0><<<1, 64>>>(din, dout, 50);
-        k_chain<1><<<1, 64>>>(din, dout + 8 * 64, 50);
-        std::vector<uint32_t> r(16 * 64);
-        hipMemcpy(r.data(), dout, r.size() * 4, hipMemcpyDeviceToHost);
-        int bad = 0;
-        for (int i = 0; i < 8 * 64; i++) bad += r[i] != r[i + 8 * 64];
-        printf("variant B vs A mismatches (loosely reduced limbs may differ): %d\n", bad);
-    }
     const int iters = 2000;
-    const char *names[3] = {"fe_mul (library)", "fe_mul (local product scanning)", "fe_sqr (library)"};
-    for (int v = 0; v < 3; v++) {
-        double lat, thr, thr4;
-        if (v == 0) { lat = run(k_chain<0>, 1, 64, din, dout, iters); thr = run(k_chain<0>, 256 * 8, 256, din, dout, iters); thr4 = run(k_chain4<0>, 256 * 8, 256, din, dout, iters / 2); }
-        else if (v == 1) { lat = run(k_chain<1>, 1, 64, din, dout, iters); thr = run(k_chain<1>, 256 * 8, 256, din, dout, iters); thr4 = run(k_chain4<1>, 256 * 8, 256, din, dout, iters / 2); }
-        else { lat = run(k_chain<2>, 1, 64, din, dout, iters); thr = run(k_chain<2>, 256 * 8, 256, din, dout, iters); thr4 = run(k_chain4<2>, 256 * 8, 256, din, dout, iters / 2); }
-        double n_lat = 2.0 * iters;
-        double n_thr = 2.0 * iters * 256 * 8 * 256;
-        double n_thr4 = 4.0 * (iters / 2) * 256 * 8 * 256;
-        printf("%-34s latency %.1f ns/op (1 wave) | throughput %.1f G op/s (chain) | %.1f G op/s (4 chains ILP)\n",
-               names[v], lat * 1e6 / n_lat, n_thr / (thr * 1e-3) / 1e9, n_thr4 / (thr4 * 1e-3) / 1e9);
+    const int B = 256 * 8, T = 256;
+    double lat = run(k_chain<0>, 1, 64, din, dout, iters);
+    double thr = run(k_chain<0>, B, T, din, dout, iters);
+    double thr4 = run(k_chain4<0>, B, T, din, dout, iters / 2);
+    printf("fe_mul  latency %.1f ns (1 wave) | %.1f G/s (chain) | %.1f G/s (4 chains)\n", lat * 1e6 / (2.0 * iters),
+           2.0 * iters * B * T / (thr * 1e-3) / 1e9, 4.0 * (iters / 2) * B * T / (thr4 * 1e-3) / 1e9);
+    lat = run(k_chain<1>, 1, 64, din, dout, iters);
+    thr = run(k_chain<1>, B, T, din, dout, iters);
+    thr4 = run(k_chain4<1>, B, T, din, dout, iters / 2);
+    printf("fe_sqr  latency %.1f ns (1 wave) | %.1f G/s (chain) | %.1f G/s (4 chains)\n", lat * 1e6 / (2.0 * iters),
+           2.0 * iters * B * T / (thr * 1e-3) / 1e9, 4.0 * (iters / 2) * B * T / (thr4 * 1e-3) / 1e9);
+    for (int blocks : {256 * 2, 256 * 3, 256 * 4, 256 * 8}) {
+        double m = run(k_madd, blocks, T, din, dout, 500);
+        printf("ge_madd %d blocks x 256: %.2f G madd/s  (%.1f G fe_mul-equivalents/s)\n", blocks,
+               500.0 * blocks * T / (m * 1e-3) / 1e9, 7 * 500.0 * blocks * T / (m * 1e-3) / 1e9);
     }
     return 0;
 }
