@@ -71,6 +71,11 @@ int vmpc_ctx_profile_read(vmpc_ctx *ctx, char *names, size_t names_len, double *
                           uint64_t *launches, int max_stages, int reset);
 /* Pippenger window width override (0 = automatic); for tuning / tests */
 int vmpc_ctx_set_window(vmpc_ctx *ctx, int c_bits);
+/* the window width and window count the planner uses for an n-term Ed25519 MSM */
+int vmpc_ed25519_msm_plan(vmpc_ctx *ctx, size_t n, int *c_bits, int *windows);
+/* Integer-ALU ceiling of the bucket stage (bench.py roofline leg): mixed additions per second of
+ * a register-resident chain on every lane of the chip - the bucket kernel without memory. */
+int vmpc_ed25519_madd_rate(vmpc_ctx *ctx, int iters, double *madds_per_second);
 
 /* ---- host-buffer one-shots (SURVEY.md 8b proposal) -------------------------------- */
 /* h^gamma-less MSM: out = sum scalars[i] * points[i].

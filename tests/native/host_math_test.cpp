@@ -169,6 +169,12 @@ int main() {
             std::cout << fehex(fe_mul(fe_add_lazy(a, b), fe_add_lazy(c, d))) << " "
                       << fehex(fe_sqr(fe_add_lazy(a, b))) << " " << fehex(fe_sub(fe_add_lazy(a, b), fe_add_lazy(c, d)))
                       << "\n";
+        } else if (cmd == "rawmul") {
+            // fe_mul / fe_sqr on RAW limbs (decimal), at the operand-contract bounds
+            fe a, b;
+            for (int i = 0; i < FE_LIMBS; i++) is >> a.v[i];
+            for (int i = 0; i < FE_LIMBS; i++) is >> b.v[i];
+            std::cout << fehex(fe_mul(a, b)) << " " << fehex(fe_sqr(b)) << "\n";
         } else if (cmd == "consts") {
             std::cout << fehex(fe_const_d()) << " " << fehex(fe_const_d2()) << "\n";
         } else if (cmd == "fradd") {

@@ -67,6 +67,33 @@ def test_field_ops(harness):
     assert harness(lines) == want
 
 
+def _limbs_value(limbs):
+    return sum(v << ((51 * i + 1) // 2) for i, v in enumerate(limbs))
+
+
+def test_field_mul_operand_contract(harness):
+    """fe_mul(f, g) with every even limb of f just below 2^28 and of g just below 2^27.2 (product of
+    maxima 2^55.2), fe_sqr with even limbs just below 2^27.6; odd limbs one bit less: the
+    documented lazy-operand bounds of fe25519.cuh."""
+    rng = random.Random(11)
+    fmax, gmax, smax = (1 << 28) - 1, int(2 ** 27.2), int(2 ** 27.6)
+
+    def vec(hi, full):
+        return [(hi >> (i & 1)) if full or rng.random() < 0.5 else rng.randrange((hi >> (i & 1)) + 1)
+                for i in range(10)]
+
+    cases = [(vec(fmax, True), vec(gmax, True)), (vec(smax, True), vec(smax, True))]
+    for _ in range(300):
+        hi_f, hi_g = rng.choice([(fmax, gmax), (smax, smax)])       # the contract is asymmetric: 19*g < 2^32
+        cases.append((vec(hi_f, False), vec(hi_g, False)))
+    lines = ["rawmul " + " ".join(map(str, f)) + " " + " ".join(map(str, g)) for f, g in cases]
+    for (f, g), o in zip(cases, harness(lines)):
+        got_mul, got_sqr = o.split()
+        assert got_mul == hx(_limbs_value(f) * _limbs_value(g) % P)
+        if max(g[0::2]) <= smax:
+            assert got_sqr == hx(_limbs_value(g) ** 2 % P)
+
+
 def test_scalar_field_ops(harness):
     rng = random.Random(2)
     vals = [0, 1, 2, ELL - 1, ELL - 2, ELL // 2, ELL // 2 + 1, 2**252, 2**252 - 1] + \

@@ -27,7 +27,7 @@ SYMBOLS = [
     "vmpc_backend_info", "vmpc_last_error", "vmpc_ctx_create", "vmpc_ctx_destroy",
     "vmpc_ctx_set_stream", "vmpc_ctx_sync", "vmpc_ctx_wait_for", "vmpc_malloc", "vmpc_free", "vmpc_memcpy_h2d",
     "vmpc_memcpy_d2h", "vmpc_memcpy_d2d", "vmpc_ctx_profile", "vmpc_ctx_profile_read",
-    "vmpc_ctx_set_window", "vmpc_ed25519_msm", "vmpc_ed25519_fold",
+    "vmpc_ctx_set_window", "vmpc_ed25519_msm_plan", "vmpc_ed25519_madd_rate", "vmpc_ed25519_msm", "vmpc_ed25519_fold",
     "vmpc_ed25519_fixed_base_batch", "vmpc_fr_axpy", "vmpc_fr_dot", "vmpc_points_validate_dev",
     "vmpc_msm_dev", "vmpc_points_sum_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
@@ -76,6 +76,8 @@ def load_library():
         "vmpc_ctx_profile": (i32, [vp, i32]),
         "vmpc_ctx_profile_read": (i32, [vp, cp, sz, ctypes.POINTER(ctypes.c_double), u64p, i32, i32]),
         "vmpc_ctx_set_window": (i32, [vp, i32]),
+        "vmpc_ed25519_msm_plan": (i32, [vp, sz, vp, vp]),
+        "vmpc_ed25519_madd_rate": (i32, [vp, i32, vp]),
         "vmpc_ed25519_msm": (i32, [vp, vp, sz, vp]),
         "vmpc_ed25519_fold": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_ed25519_fixed_base_batch": (i32, [vp, vp, sz, vp]),
@@ -365,6 +367,20 @@ class Context:
 
     def set_window(self, c_bits):
         _check(self.lib.vmpc_ctx_set_window(self.handle, int(c_bits)), "vmpc_ctx_set_window")
+
+    def msm_plan(self, n):
+        """(window width c, window count W) the planner picks for an n-term Ed25519 MSM"""
+        c, w = ctypes.c_int(0), ctypes.c_int(0)
+        _check(self.lib.vmpc_ed25519_msm_plan(self.handle, int(n), ctypes.byref(c), ctypes.byref(w)),
+               "vmpc_ed25519_msm_plan")
+        return c.value, w.value
+
+    def madd_rate(self, iters=400):
+        """mixed additions per second of the register-resident ALU ceiling probe"""
+        r = ctypes.c_double(0.0)
+        _check(self.lib.vmpc_ed25519_madd_rate(self.handle, int(iters), ctypes.byref(r)),
+               "vmpc_ed25519_madd_rate")
+        return r.value
 
     def profile(self, enable=True):
         _check(self.lib.vmpc_ctx_profile(self.handle, 1 if enable else 0), "vmpc_ctx_profile")

@@ -13,9 +13,17 @@
 // operands (19 * g_j), and a product is 100 bare multiply-adds plus one short carry pass;
 // a squaring is 55.  Additions are limb-wise.
 //
-// Limb bounds: "reduced" means v[even] < 2^26 + 2^16, v[odd] < 2^25 + 2^16.  fe_mul / fe_sqr accept
-// operands with limbs up to 2^27 (even) / 2^26 (odd) - i.e. reduced values or ONE lazy sum of two
-// of them (fe_add_lazy) - and return reduced values; fe_add / fe_sub / fe_neg return reduced values.
+// Limb bounds.  "reduced" means v[even] <= 2^26 + 2^15, v[odd] <= 2^25 + 2^15: what fe_mul,
+// fe_sqr, fe_add, fe_sub, fe_neg, fe_unpack return.  The *_lazy forms skip the carry pass:
+//   fe_add_lazy(a, b)   limbs a + b
+//   fe_sub_lazy(a, b)   limbs a + 2p - b      (b reduced)
+// Operand contract of fe_mul(f, g), stated for EVEN limbs (odd limbs: one bit less, which every
+// value built from reduced values and the 2p bias satisfies): f < 2^28, g < 2^27.7 with
+// max(f) * max(g) <= 2^55.2 (then the ten 64-bit column sums, each term carrying at most the
+// factors 19 * 2, stay below 2^64, and 19 * g_j fits 32 bits).  Reduced values, one lazy sum or
+// difference of reduced values (< 2^27.6), and `lazy +- reduced` against a reduced partner all
+// satisfy it; the call sites in ge25519.cuh state their bounds.  fe_sqr(f): limbs < 2^27.6.
+// tests/native/host_math_test.cpp drives both at these bounds (command `rawmul`).
 //
 // Memory format (`fe8`): 32 bytes little-endian = 8 LE uint32 words, canonical residue < p on
 // every public buffer (include/vmpc.h).  fe_unpack / fe_pack convert; internal workspaces keep
@@ -127,6 +135,18 @@ VMPC_HD fe fe_add_lazy(const fe &a, const fe &b) {
     for (int i = 0; i < FE_LIMBS; i++) r.v[i] = a.v[i] + b.v[i];
     return r;
 }
+
+// a - b + 2p limb-wise, NOT carried.  b must be reduced (limbs below the 2p limbs 2^27-38,
+// 2^26-2, 2^27-2); the result's limbs are below a's + 2^27 (even) / 2^26 (odd).
+VMPC_HD fe fe_sub_lazy(const fe &a, const fe &b) {
+    fe r;
+    r.v[0] = a.v[0] + 0x7ffffdau - b.v[0];          // 2 * (2^26 - 19)
+#pragma unroll
+    for (int i = 1; i < FE_LIMBS; i++)
+        r.v[i] = a.v[i] + ((i & 1) ? 0x3fffffeu : 0x7fffffeu) - b.v[i];   // 2*(2^25-1) / 2*(2^26-1)
+    return r;
+}
+VMPC_HD fe fe_neg_lazy(const fe &a) { return fe_sub_lazy(fe_zero(), a); }
 
 // r = a + b, reduced
 VMPC_HD fe fe_add(const fe &a, const fe &b) {

@@ -64,65 +64,67 @@ VMPC_HD ge_niels ge_niels_neg(const ge_niels &a) {
     return r;
 }
 
+// t2d of the result may be a lazy negation (limbs < 2^27): it is only ever a product operand
 VMPC_HD ge_niels ge_niels_select_neg(const ge_niels &a, bool neg) {
     ge_niels r;
     r.ymx = fe_select(a.ymx, a.ypx, neg);
     r.ypx = fe_select(a.ypx, a.ymx, neg);
-    r.t2d = fe_select(a.t2d, fe_neg(a.t2d), neg);
+    r.t2d = fe_select(a.t2d, fe_neg_lazy(a.t2d), neg);
     return r;
 }
 
-// mixed addition ext + niels (madd-2008-hwcd-3 shape): 7M
-VMPC_HD ge_ext ge_madd(const ge_ext &p, const ge_niels &q) {
-    fe A = fe_mul(fe_sub(p.Y, p.X), q.ymx);
-    fe B = fe_mul(fe_add(p.Y, p.X), q.ypx);
-    fe C = fe_mul(p.T, q.t2d);
-    fe D = fe_dbl(p.Z);
-    fe E = fe_sub(B, A);
-    fe F = fe_sub(D, C);
-    fe G = fe_add(D, C);
-    fe H = fe_add(B, A);
+// The extended formulas below keep their sums and differences lazy (no carry pass) wherever the
+// fe_mul operand contract allows; only F is carried.  Inputs: coordinates reduced (they are
+// products, constants or unpacked values).  Limb bounds in comments are for even limbs.
+
+// second half shared by madd / add: A, B, C reduced, D < 2^27.1
+VMPC_HD ge_ext ge_hwcd_tail(const fe &A, const fe &B, const fe &C, const fe &D) {
+    fe E = fe_sub_lazy(B, A);      // < 2^27.6
+    fe H = fe_add_lazy(B, A);      // < 2^27.1
+    fe F = fe_sub(D, C);           // carried: reduced
+    fe G = fe_add_lazy(D, C);      // < 2^27.6
     ge_ext r;
-    r.X = fe_mul(E, F);
-    r.Y = fe_mul(G, H);
-    r.T = fe_mul(E, H);
-    r.Z = fe_mul(F, G);
+    r.X = fe_mul(E, F);            // 2^27.6 * 2^26
+    r.Y = fe_mul(G, H);            // 2^27.6 * 2^27.1 = 2^54.7
+    r.T = fe_mul(E, H);            // 2^54.7
+    r.Z = fe_mul(G, F);
     return r;
+}
+
+// mixed addition ext + niels (madd-2008-hwcd-3 shape): 7M.  q.t2d may be a lazy negation.
+VMPC_HD ge_ext ge_madd(const ge_ext &p, const ge_niels &q) {
+    fe A = fe_mul(fe_sub_lazy(p.Y, p.X), q.ymx);     // 2^27.6 * 2^26
+    fe B = fe_mul(fe_add_lazy(p.Y, p.X), q.ypx);     // 2^27.1 * 2^26
+    fe C = fe_mul(p.T, q.t2d);                       // 2^26 * 2^27
+    fe D = fe_add_lazy(p.Z, p.Z);
+    return ge_hwcd_tail(A, B, C, D);
 }
 
 // full addition ext + ext (add-2008-hwcd-3): 9M.  Complete on Ed25519 (a = -1 square... d non-square).
 VMPC_HD ge_ext ge_add(const ge_ext &p, const ge_ext &q) {
-    fe A = fe_mul(fe_sub(p.Y, p.X), fe_sub(q.Y, q.X));
-    fe B = fe_mul(fe_add(p.Y, p.X), fe_add(q.Y, q.X));
+    fe A = fe_mul(fe_sub_lazy(p.Y, p.X), fe_sub_lazy(q.Y, q.X));   // 2^27.6 * 2^27.6 = 2^55.2
+    fe B = fe_mul(fe_add_lazy(p.Y, p.X), fe_add_lazy(q.Y, q.X));   // 2^27.1 * 2^27.1
     fe C = fe_mul(fe_mul(p.T, q.T), fe_const_d2());
-    fe D = fe_dbl(fe_mul(p.Z, q.Z));
-    fe E = fe_sub(B, A);
-    fe F = fe_sub(D, C);
-    fe G = fe_add(D, C);
-    fe H = fe_add(B, A);
-    ge_ext r;
-    r.X = fe_mul(E, F);
-    r.Y = fe_mul(G, H);
-    r.T = fe_mul(E, H);
-    r.Z = fe_mul(F, G);
-    return r;
+    fe zz = fe_mul(p.Z, q.Z);
+    fe D = fe_add_lazy(zz, zz);
+    return ge_hwcd_tail(A, B, C, D);
 }
 
 // doubling (dbl-2008-hwcd, a = -1): 4M + 4S
 VMPC_HD ge_ext ge_dbl(const ge_ext &p) {
     fe A = fe_sqr(p.X);
     fe B = fe_sqr(p.Y);
-    fe C = fe_dbl(fe_sqr(p.Z));
-    fe H = fe_add(A, B);
-    fe xy = fe_add(p.X, p.Y);
-    fe E = fe_sub(H, fe_sqr(xy));
-    fe G = fe_sub(A, B);
-    fe F = fe_add(C, G);
+    fe zz = fe_sqr(p.Z);
+    fe S = fe_sqr(fe_add_lazy(p.X, p.Y));            // 2^27.1
+    fe H = fe_add_lazy(A, B);                        // < 2^27.1
+    fe E = fe_sub_lazy(H, S);                        // < 2^28
+    fe G = fe_sub_lazy(A, B);                        // < 2^27.6
+    fe F = fe_add(fe_add_lazy(zz, zz), G);           // carried: reduced  (2^27.1 + 2^27.6 < 2^31)
     ge_ext r;
-    r.X = fe_mul(E, F);
-    r.Y = fe_mul(G, H);
-    r.T = fe_mul(E, H);
-    r.Z = fe_mul(F, G);
+    r.X = fe_mul(E, F);                              // 2^28 * 2^26
+    r.Y = fe_mul(G, H);                              // 2^54.7
+    r.T = fe_mul(E, H);                              // 2^28 * 2^27.1 = 2^55.1
+    r.Z = fe_mul(G, F);
     return r;
 }
 

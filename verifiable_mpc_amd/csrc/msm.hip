@@ -320,7 +320,11 @@ k_msm_plan2(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nbloc
 }
 
 __device__ __forceinline__ ge_niels niels_ld(const uint32_t *niels, uint32_t e) {
+#ifdef MSM_GATHER_MASK   // experiment: cache-resident gather (wrong results) to expose the ALU time
+    return niels_ld_line(niels + NIELS_WORDS * (size_t)(e & MSM_GATHER_MASK));
+#else
     return niels_ld_line(niels + NIELS_WORDS * (size_t)(e & 0x7fffffffu));
+#endif
 }
 
 // one lane = one segment of <= MSM_SEG sorted entries
@@ -570,6 +574,62 @@ k_points_sum(const uint32_t *__restrict__ pts, size_t m, uint32_t *__restrict__ 
     }
 }
 
+// ---- ALU ceiling probe (bench.py): the bucket stage's inner operation with no memory traffic ---
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_madd_rate(const uint32_t *__restrict__ seed, int iters, uint32_t *__restrict__ sink) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ge_aff a;
+    a.x = fe_ld8(seed);
+    a.y = fe_ld8(seed + 8);
+    a.x.v[0] ^= (uint32_t)i & 0xffu;          // lanes differ; the values need not be on the curve
+    ge_niels q = ge_niels_from_affine(a);
+    ge_ext p = ge_ext_identity();
+    for (int k = 0; k < iters; k++) {
+        p = ge_madd(p, q);
+        q.t2d.v[0] ^= (uint32_t)k & 1u;
+    }
+    fe s = fe_add(fe_add(p.X, p.Y), fe_add(p.Z, p.T));
+    if (s.v[0] == seed[31]) fe_st8(sink, s);   // seed[31] = 2^32-1: never a reduced limb; keeps the chain live
+}
+
+extern "C" int vmpc_ed25519_madd_rate(vmpc_ctx *ctx, int iters, double *madds_per_second) {
+    if (!ctx || !madds_per_second || iters < 1) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    VMPC_CHECK(vmpc_ws_reserve(ctx, 512));
+    uint32_t *buf = (uint32_t *)vmpc_ws_take(ctx, 256);
+    uint32_t host[32] = {0};
+    host[0] = 9;
+    host[8] = 5;
+    host[31] = 0xffffffffu;
+    VMPC_HIP_CHECK(hipMemcpyAsync(buf, host, sizeof host, hipMemcpyHostToDevice, ctx->stream));
+    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    hipEvent_t e0, e1;
+    VMPC_HIP_CHECK(hipEventCreate(&e0));
+    VMPC_HIP_CHECK(hipEventCreate(&e1));
+    const unsigned blocks = 8u * (unsigned)ctx->cu_count;
+    k_madd_rate<<<blocks, MSM_BLOCK, 0, ctx->stream>>>(buf, 8, buf + 32);     // warm-up
+    VMPC_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+    k_madd_rate<<<blocks, MSM_BLOCK, 0, ctx->stream>>>(buf, iters, buf + 32);
+    VMPC_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+    VMPC_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    VMPC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (ms <= 0.f) return VMPC_E_HIP;
+    *madds_per_second = (double)blocks * MSM_BLOCK * (double)iters / (ms * 1e-3);
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_ed25519_msm_plan(vmpc_ctx *ctx, size_t n, int *c_bits, int *windows) {
+    if (!ctx || !c_bits || !windows || n == 0) return VMPC_E_INVAL;
+    msm_plan p;
+    msm_make_plan(ctx, n, 0, 253, p);
+    *c_bits = p.c;
+    *windows = p.W;
+    return VMPC_OK;
+}
+
 // ---- validation ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_points_validate(const uint32_t *__restrict__ aff, size_t n, unsigned long long *__restrict__ bad) {
@@ -586,7 +646,13 @@ k_points_validate(const uint32_t *__restrict__ aff, size_t n, unsigned long long
 }
 
 // ---- host side ---------------------------------------------------------------------------
+// Window width.  Measured on MI355X (scripts/window_sweep.py), not modelled: the tail stages
+// (reduce, recombination) are latency chains whose length barely depends on c, so the widest
+// window the int16 digits allow wins as soon as the bucket stage matters (n > 2^13); below that
+// c = 11 keeps the reduce short.  Both choices also leave the top window of a 253-bit scalar
+// empty or well spread (W*c = 264 resp. 256), where other widths pile n/2 entries into one bucket.
 static int msm_pick_window(size_t n, int scalar_bits) {
+    if (scalar_bits == 253) return n > (1u << 13) ? 16 : 11;   // Ed25519; BN-256 keeps the model
     double best = 1e300;
     int best_c = 4;
     for (int c = 4; c <= MSM_MAX_C; c++) {
