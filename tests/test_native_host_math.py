@@ -82,9 +82,11 @@ def test_field_mul_operand_contract(harness):
         return [(hi >> (i & 1)) if full or rng.random() < 0.5 else rng.randrange((hi >> (i & 1)) + 1)
                 for i in range(10)]
 
-    cases = [(vec(fmax, True), vec(gmax, True)), (vec(smax, True), vec(smax, True))]
+    wide = (int(2 ** 28.4), (1 << 26) + (1 << 15))      # B - C - D against a reduced partner
+    cases = [(vec(fmax, True), vec(gmax, True)), (vec(smax, True), vec(smax, True)),
+             (vec(wide[0], True), vec(wide[1], True))]
     for _ in range(300):
-        hi_f, hi_g = rng.choice([(fmax, gmax), (smax, smax)])       # the contract is asymmetric: 19*g < 2^32
+        hi_f, hi_g = rng.choice([(fmax, gmax), (smax, smax), wide])   # asymmetric contract: 19*g < 2^32
         cases.append((vec(hi_f, False), vec(hi_g, False)))
     lines = ["rawmul " + " ".join(map(str, f)) + " " + " ".join(map(str, g)) for f, g in cases]
     for (f, g), o in zip(cases, harness(lines)):

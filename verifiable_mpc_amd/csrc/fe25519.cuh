@@ -18,7 +18,7 @@
 //   fe_add_lazy(a, b)   limbs a + b
 //   fe_sub_lazy(a, b)   limbs a + 2p - b      (b reduced)
 // Operand contract of fe_mul(f, g), stated for EVEN limbs (odd limbs: one bit less, which every
-// value built from reduced values and the 2p bias satisfies): f < 2^28, g < 2^27.7 with
+// value built from reduced values and the 2p bias satisfies): f < 2^31, g < 2^27.7 with
 // max(f) * max(g) <= 2^55.2 (then the ten 64-bit column sums, each term carrying at most the
 // factors 19 * 2, stay below 2^64, and 19 * g_j fits 32 bits).  Reduced values, one lazy sum or
 // difference of reduced values (< 2^27.6), and `lazy +- reduced` against a reduced partner all

@@ -171,36 +171,37 @@ VMPC_HD bool ge_aff_on_curve(const ge_aff &a) {
 
 // ---------------- projective replay of the reference's formulas ----------------------
 
-// add-2008-bbjlp, a = -1 (oracle/ed25519_ref.py pt_add)
+// add-2008-bbjlp, a = -1 (oracle/ed25519_ref.py pt_add).  Sums stay lazy where the fe_mul operand
+// contract allows - the residues, which is all the replay has to reproduce, are unchanged.
 VMPC_HD ge_proj ge_proj_add(const ge_proj &p, const ge_proj &q) {
     fe A = fe_mul(p.Z, q.Z);
     fe B = fe_sqr(A);
     fe C = fe_mul(p.X, q.X);
     fe D = fe_mul(p.Y, q.Y);
     fe E = fe_mul(fe_mul(fe_const_d(), C), D);
-    fe F = fe_sub(B, E);
-    fe G = fe_add(B, E);
-    fe s = fe_sub(fe_sub(fe_mul(fe_add(p.X, p.Y), fe_add(q.X, q.Y)), C), D);
+    fe F = fe_sub_lazy(B, E);                         // < 2^27.6
+    fe G = fe_add_lazy(B, E);                         // < 2^27.1
+    fe DC = fe_add_lazy(D, C);                        // < 2^27.1
+    fe s = fe_sub(fe_mul(fe_add_lazy(p.X, p.Y), fe_add_lazy(q.X, q.Y)), DC);   // carried
     ge_proj r;
     r.X = fe_mul(fe_mul(A, F), s);
-    r.Y = fe_mul(fe_mul(A, G), fe_add(D, C));
-    r.Z = fe_mul(F, G);
+    r.Y = fe_mul(fe_mul(A, G), DC);
+    r.Z = fe_mul(F, G);                               // 2^27.6 * 2^27.1
     return r;
 }
 
 // dbl-2008-bbjlp, a = -1 (oracle/ed25519_ref.py pt_dbl)
 VMPC_HD ge_proj ge_proj_dbl(const ge_proj &p) {
-    fe xy = fe_add(p.X, p.Y);
-    fe B = fe_sqr(xy);
+    fe B = fe_sqr(fe_add_lazy(p.X, p.Y));
     fe C = fe_sqr(p.X);
     fe D = fe_sqr(p.Y);
-    fe E = fe_neg(C);
-    fe F = fe_add(E, D);
+    fe F = fe_sub_lazy(D, C);                         // E + D with E = -C;  < 2^27.6
     fe H = fe_sqr(p.Z);
-    fe J = fe_sub(F, fe_dbl(H));
+    fe J = fe_sub(F, fe_add_lazy(H, H));              // carried
+    fe nCD = fe_neg(fe_add_lazy(C, D));               // E - D, carried
     ge_proj r;
-    r.X = fe_mul(fe_sub(fe_sub(B, C), D), J);
-    r.Y = fe_mul(F, fe_sub(E, D));
+    r.X = fe_mul(fe_sub_lazy(fe_sub_lazy(B, C), D), J);   // B - C - D < 2^28.4 against a reduced J
+    r.Y = fe_mul(F, nCD);
     r.Z = fe_mul(F, J);
     return r;
 }
