@@ -61,6 +61,10 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
     }
     const char *w = getenv("VMPC_MSM_WINDOW");
     if (w) c->window_override = atoi(w);
+    const char *sr = getenv("VMPC_SORT_RANGE");     // tuning knob: buckets per sort workgroup
+    if (sr && atoi(sr) >= 64) c->sort_range = atoi(sr);
+    const char *ss = getenv("VMPC_SORT_SLICES");
+    if (ss && atoi(ss) >= 1) c->sort_slices = atoi(ss);
     *out = c;
     return VMPC_OK;
 }

@@ -83,16 +83,16 @@ __global__ void __launch_bounds__(MSM_BLOCK)
 gk_bucket(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ sorted,
           const uint32_t *__restrict__ starts, const uint32_t *__restrict__ counts,
           const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
-          const uint2 *__restrict__ tasks, const uint32_t *__restrict__ n_tasks, int nb1,
+          const uint2 *__restrict__ tasks, const uint32_t *__restrict__ n_tasks, int nb1, int seg,
           uint32_t *__restrict__ buckets, uint32_t *__restrict__ partial) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= *n_tasks) return;
     uint2 tk = tasks[t];
     uint32_t ci = tk.x, sidx = tk.y;
     uint32_t cnt = counts[ci];
-    uint32_t lo = starts[ci] + sidx * MSM_SEG;
-    uint32_t len = cnt - sidx * MSM_SEG;
-    if (len > MSM_SEG) len = MSM_SEG;
+    uint32_t lo = starts[ci] + sidx * seg;
+    uint32_t len = cnt - sidx * seg;
+    if (len > (uint32_t)seg) len = seg;
     typename C::acc_t acc = C::identity();
     for (uint32_t j = 0; j < len; j++) {
         uint32_t e = sorted[lo + j];
@@ -266,7 +266,7 @@ static int bn_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, si
         vmpc_stage_scope s(ctx, "bn_bucket");
         gk_bucket<C><<<(unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
             w.entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
-            w.buckets, w.seg_partial);
+            MSM_SEG << p.seg_shift, w.buckets, w.seg_partial);
         VMPC_KERNEL_CHECK();
         gk_finish_light<C, F><<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg,
                                                                       w.seg_starts, w.seg_partial, p.nb1,

@@ -159,10 +159,14 @@ k_msm_prep(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__re
 // ---- recode: scalar -> signed digits ----------------------------------------------------
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__restrict__ sc_extra,
-             size_t n_total, int16_t *__restrict__ digits, int c, int W, msm_modulus mod,
+             size_t n_total, size_t n_pad, int16_t *__restrict__ digits, int c, int W, msm_modulus mod,
              uint32_t *__restrict__ status) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
+    if (i >= n_total) {
+        if (i < n_pad)                       // zero digits = no entry: the sort kernels read whole 16-byte vectors
+            for (int w = 0; w < W; w++) digits[(size_t)w * n_pad + i] = 0;
+        return;
+    }
     const uint32_t *src = (i < n_main) ? sc + 8 * i : sc_extra + 8 * (i - n_main);
     uint32_t s[8];
     load_u32x8(s, src);
@@ -190,7 +194,7 @@ k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__r
             d = (int32_t)raw;
             carry = 0;
         }
-        digits[(size_t)w * n_total + i] = (int16_t)d;
+        digits[(size_t)w * n_pad + i] = (int16_t)d;
         // s >>= c  (c < 32; static limb indices keep s[] in registers)
 #pragma unroll
         for (int k = 0; k < 7; k++) s[k] = (s[k] >> c) | (s[k + 1] << (32 - c));
@@ -198,25 +202,54 @@ k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__r
     }
 }
 
-// ---- hist: per (slice, window) digit histogram in LDS ----------------------------------
+// ---- hist / scatter: bucket sort of one window's digits -----------------------------------
+// A workgroup owns (slice s, bucket range r, window w): it streams the slice's digits (16-byte
+// vectors of 8, re-read once per range - a window's digit row is L2 resident) and handles only
+// the entries whose bucket falls in its range.  Partitioning by BUCKET RANGE rather than only by
+// slice is what makes the scatter's stores combine: all entries of a bucket come from one
+// workgroup (per slice), so the 4-byte stores into that bucket's run meet in one XCD's L2 instead
+// of arriving from 32 workgroups on 8 XCDs (measured: 222 us -> see DESIGN.md section 5), and the
+// LDS array shrinks from 128 KiB to range_len * 4 bytes.
+template <bool SCATTER>
+__device__ __forceinline__ void msm_sort_visit(const int16_t *__restrict__ dw, size_t lo, size_t hi,
+                                               uint32_t lo_b, uint32_t nbr, uint32_t *lds,
+                                               uint32_t *__restrict__ sorted) {
+    for (size_t i = lo + 8 * (size_t)threadIdx.x; i < hi; i += 8 * (size_t)blockDim.x) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(dw + i);
+        const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int d = (int)(int16_t)(word[k >> 1] >> (16 * (k & 1)));
+            const uint32_t a = (uint32_t)(d < 0 ? -d : d);
+            const uint32_t t = a - lo_b;                  // d == 0 wraps: bucket 0 is nobody's
+            if (t < nbr) {
+                if (SCATTER) {
+                    uint32_t pos = atomicAdd(&lds[t], 1u);
+                    sorted[pos] = (uint32_t)(i + k) | (d < 0 ? 0x80000000u : 0u);
+                } else {
+                    atomicAdd(&lds[t], 1u);
+                }
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(MSM_SORT_BLOCK)
-k_msm_hist(const int16_t *__restrict__ digits, size_t n_total, size_t slice_len, int nb1, int S,
-           uint32_t *__restrict__ hist) {
+k_msm_hist(const int16_t *__restrict__ digits, size_t n_pad, size_t slice_len, int nb1, int S, int R,
+           int range_len, uint32_t *__restrict__ hist) {
     extern __shared__ uint32_t lds[];
-    const int s = blockIdx.x, w = blockIdx.y;
-    for (int b = threadIdx.x; b < nb1; b += blockDim.x) lds[b] = 0;
+    const int s = blockIdx.x / R, r = blockIdx.x % R, w = blockIdx.y;   // r fastest: see msm_make_plan (XCD affinity)
+    const uint32_t lo_b = (uint32_t)r * range_len + 1;
+    const uint32_t nbr = min((uint32_t)range_len, (uint32_t)nb1 - lo_b);
+    for (uint32_t b = threadIdx.x; b < nbr; b += blockDim.x) lds[b] = 0;
     __syncthreads();
     size_t lo = (size_t)s * slice_len;
-    size_t hi = lo + slice_len;
-    if (hi > n_total) hi = n_total;
-    const int16_t *dw = digits + (size_t)w * n_total;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        int d = dw[i];
-        if (d != 0) atomicAdd(&lds[d < 0 ? -d : d], 1u);
-    }
+    size_t hi = min(lo + slice_len, n_pad);
+    msm_sort_visit<false>(digits + (size_t)w * n_pad, lo, hi, lo_b, nbr, lds, nullptr);
     __syncthreads();
     uint32_t *out = hist + ((size_t)w * S + s) * nb1;
-    for (int b = threadIdx.x; b < nb1; b += blockDim.x) out[b] = lds[b];
+    for (uint32_t b = threadIdx.x; b < nbr; b += blockDim.x) out[lo_b + b] = lds[b];
+    if (r == 0 && threadIdx.x == 0) out[0] = 0;
 }
 
 // ---- counts: per-bucket totals; hist[w][s][b] becomes the exclusive offset of slice s ---
@@ -237,26 +270,20 @@ k_msm_counts(uint32_t *__restrict__ hist, int W, int S, int nb1, uint32_t *__res
 
 // ---- scatter: bucket-sorted point indices -------------------------------------------------
 __global__ void __launch_bounds__(MSM_SORT_BLOCK)
-k_msm_scatter(const int16_t *__restrict__ digits, size_t n_total, size_t slice_len, int nb1, int S,
-              const uint32_t *__restrict__ hist, const uint32_t *__restrict__ starts,
+k_msm_scatter(const int16_t *__restrict__ digits, size_t n_pad, size_t slice_len, int nb1, int S, int R,
+              int range_len, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ starts,
               uint32_t *__restrict__ sorted) {
     extern __shared__ uint32_t lds[];
-    const int s = blockIdx.x, w = blockIdx.y;
-    const uint32_t *off = hist + ((size_t)w * S + s) * nb1;
-    const uint32_t *st = starts + (size_t)w * nb1;
-    for (int b = threadIdx.x; b < nb1; b += blockDim.x) lds[b] = st[b] + off[b];
+    const int s = blockIdx.x / R, r = blockIdx.x % R, w = blockIdx.y;   // r fastest: see msm_make_plan (XCD affinity)
+    const uint32_t lo_b = (uint32_t)r * range_len + 1;
+    const uint32_t nbr = min((uint32_t)range_len, (uint32_t)nb1 - lo_b);
+    const uint32_t *off = hist + ((size_t)w * S + s) * nb1 + lo_b;
+    const uint32_t *st = starts + (size_t)w * nb1 + lo_b;
+    for (uint32_t b = threadIdx.x; b < nbr; b += blockDim.x) lds[b] = st[b] + off[b];
     __syncthreads();
     size_t lo = (size_t)s * slice_len;
-    size_t hi = lo + slice_len;
-    if (hi > n_total) hi = n_total;
-    const int16_t *dw = digits + (size_t)w * n_total;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        int d = dw[i];
-        if (d != 0) {
-            uint32_t pos = atomicAdd(&lds[d < 0 ? -d : d], 1u);
-            sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
-        }
-    }
+    size_t hi = min(lo + slice_len, n_pad);
+    msm_sort_visit<true>(digits + (size_t)w * n_pad, lo, hi, lo_b, nbr, lds, sorted);
 }
 
 // ---- bucket accumulation, segment-balanced -----------------------------------------------
@@ -272,8 +299,10 @@ k_msm_scatter(const int16_t *__restrict__ digits, size_t n_total, size_t slice_l
 // plan, pass 1: segments per bucket + per-block histogram of segment lengths
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_msm_plan1(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nblocks,
-            uint32_t *__restrict__ nseg, uint32_t *__restrict__ block_hist,
+            int seg_shift, uint32_t *__restrict__ nseg, uint32_t *__restrict__ block_hist,
             uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ ctrl /*[0]=heavy count*/) {
+    // segments hold <= MSM_SEG << seg_shift entries; lengths are binned in units of 2^seg_shift
+    const uint32_t seg_log = MSM_SEG_LOG2 + seg_shift, unit_round = (1u << seg_shift) - 1u;
     __shared__ uint32_t lh[MSM_SEG + 1];
     __shared__ uint32_t heavy_n, heavy_base;
     if (threadIdx.x <= MSM_SEG) lh[threadIdx.x] = 0;
@@ -281,11 +310,11 @@ k_msm_plan1(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nbloc
     __syncthreads();
     uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = ci < nslots ? counts[ci] : 0;
-    uint32_t full = cnt / MSM_SEG, rem = cnt % MSM_SEG;
+    uint32_t full = cnt >> seg_log, rem = cnt & ((1u << seg_log) - 1u);
     uint32_t ns = full + (rem ? 1u : 0u);
     if (ci < nslots) nseg[ci] = ns;
     if (full) atomicAdd(&lh[MSM_SEG], full);
-    if (rem) atomicAdd(&lh[rem], 1u);
+    if (rem) atomicAdd(&lh[(rem + unit_round) >> seg_shift], 1u);
     uint32_t my_heavy = 0;
     if (ns > 1) my_heavy = atomicAdd(&heavy_n, 1u);
     __syncthreads();
@@ -299,18 +328,20 @@ k_msm_plan1(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nbloc
 
 // plan, pass 2: write the task table (bucket slot, segment index), grouped by length
 __global__ void __launch_bounds__(MSM_BLOCK)
-k_msm_plan2(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nblocks,
+k_msm_plan2(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nblocks, int seg_shift,
             const uint32_t *__restrict__ block_base, uint2 *__restrict__ tasks) {
+    const uint32_t seg_log = MSM_SEG_LOG2 + seg_shift, unit_round = (1u << seg_shift) - 1u;
     __shared__ uint32_t cur[MSM_SEG + 1];
     if (threadIdx.x <= MSM_SEG) cur[threadIdx.x] = 0;
     __syncthreads();
     uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= nslots) return;
     uint32_t cnt = counts[ci];
-    uint32_t full = cnt / MSM_SEG, rem = cnt % MSM_SEG;
+    uint32_t full = cnt >> seg_log, rem = cnt & ((1u << seg_log) - 1u);
     if (rem) {
-        uint32_t r = atomicAdd(&cur[rem], 1u);
-        tasks[block_base[(size_t)(MSM_SEG - rem) * nblocks + blockIdx.x] + r] = make_uint2(ci, full);
+        uint32_t bin = (rem + unit_round) >> seg_shift;
+        uint32_t r = atomicAdd(&cur[bin], 1u);
+        tasks[block_base[(size_t)(MSM_SEG - bin) * nblocks + blockIdx.x] + r] = make_uint2(ci, full);
     }
     if (full) {
         uint32_t r = atomicAdd(&cur[MSM_SEG], full);
@@ -328,20 +359,23 @@ __device__ __forceinline__ ge_niels niels_ld(const uint32_t *niels, uint32_t e) 
 }
 
 // one lane = one segment of <= MSM_SEG sorted entries
-__global__ void __launch_bounds__(MSM_BLOCK)
+#ifndef MSM_BUCKET_WAVES
+#define MSM_BUCKET_WAVES 4
+#endif
+__global__ void __launch_bounds__(MSM_BLOCK, MSM_BUCKET_WAVES)
 k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ sorted,
              const uint32_t *__restrict__ starts, const uint32_t *__restrict__ counts,
              const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
-             const uint2 *__restrict__ tasks, const uint32_t *__restrict__ n_tasks, int nb1,
+             const uint2 *__restrict__ tasks, const uint32_t *__restrict__ n_tasks, int nb1, int seg,
              uint32_t *__restrict__ buckets, uint32_t *__restrict__ partial) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= *n_tasks) return;
     uint2 tk = tasks[t];
     uint32_t ci = tk.x, sidx = tk.y;
     uint32_t cnt = counts[ci];
-    uint32_t lo = starts[ci] + sidx * MSM_SEG;
-    uint32_t len = cnt - sidx * MSM_SEG;
-    if (len > MSM_SEG) len = MSM_SEG;
+    uint32_t lo = starts[ci] + sidx * seg;
+    uint32_t len = cnt - sidx * seg;
+    if (len > (uint32_t)seg) len = seg;
     ge_ext acc = ge_ext_identity();
     uint32_t e = sorted[lo];
     ge_niels q = niels_ld(niels, e);
@@ -416,6 +450,7 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_REDUCE_WAVES)
 k_msm_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ counts, int nb,
              int chunks, int chunk_len, int log2_chunk_len, int red_blocks,
              uint32_t *__restrict__ partials) {
+    __builtin_amdgcn_s_setprio(3);   // latency chain: win issue arbitration against co-resident bucket waves
     __shared__ uint32_t lds[MSM_BLOCK * EXT_WORDS];
     const int w = blockIdx.y;
     const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
@@ -507,6 +542,7 @@ __device__ __forceinline__ void quad_add_cached(ge_ext &p, const ge_cached &r, i
 __global__ void __launch_bounds__(64)
 k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
             uint32_t *__restrict__ out_ext, uint32_t *__restrict__ out_aff) {
+    __builtin_amdgcn_s_setprio(3);   // latency chain: win issue arbitration against co-resident bucket waves
     __shared__ uint32_t lds[64 * EXT_WORDS];
     // phase 1: window sums.  lpw lanes share a window (strided partials), then a short tree.
     int lpw = 1;
@@ -683,13 +719,36 @@ void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits
     }
     p.nb = 1 << (p.c - 1);
     p.nb1 = p.nb + 1;
-    // enough (window, slice) workgroups to cover the chip twice, slices of >= 4096 terms
-    int S = (2 * ctx->cu_count + p.W - 1) / p.W;
+    // sort workgroups = (slice, bucket range, window).  Two things make the scatter's 4-byte
+    // stores combine into whole lines before they leave L2 (each XCD has its own):
+    //  * XCD affinity - workgroups are dealt round-robin to the 8 XCDs in linear block order, and
+    //    the range index is the fastest-varying part of blockIdx.x with R a multiple of 8 (R = 8
+    //    for c = 16), so every store into a given bucket range goes through the SAME L2, from
+    //    whichever slice it comes (range-major order, which spreads a range over all XCDs: 228 us
+    //    instead of 149 us at n = 2^20);
+    //  * temporal locality - windows are dispatched one after the other, and with >= 128
+    //    workgroups per window only ~4 windows' runs are being filled at any time (32 per
+    //    window = 8 windows in flight: 222 us).
+    // Ranges of <= 4096 buckets (16 KiB of LDS); slices of <= 65536 terms but at least 128/R of
+    // them, >= 4096 terms each, at most 256 (the per-slice histogram is W*S*nb1 words).
+    p.n_pad = (p.n_total + 7) & ~(size_t)7;
+    p.range_len = p.nb < ctx->sort_range ? p.nb : ctx->sort_range;
+    p.R = (p.nb + p.range_len - 1) / p.range_len;
+    size_t want = (p.n_total + 65535) >> 16;
+    size_t S_min = (size_t)(128 + p.R - 1) / p.R;
+    if (want < S_min) want = S_min;
+    if (want > 256) want = 256;
     size_t max_s = (p.n_total + 4095) / 4096;
-    if ((size_t)S > max_s) S = (int)max_s;
-    if (S < 1) S = 1;
+    if (want > max_s) want = max_s;
+    int S = want < 1 ? 1 : (int)want;
+    if (ctx->sort_slices) S = ctx->sort_slices;
     p.S = S;
-    p.slice_len = (p.n_total + S - 1) / S;
+    p.slice_len = (((p.n_pad + S - 1) / S) + 7) & ~(size_t)7;
+    // segment length: 64 entries up to an average bucket load of 32 (n = 2^20 at c = 16), doubled
+    // while the average load exceeds half of it - otherwise every bucket of a 2^22-term MSM is
+    // split in three and the finish stage (one more gather of 160-byte partial sums) costs 14 %
+    p.seg_shift = 0;
+    while (p.seg_shift < 4 && ((size_t)MSM_SEG << p.seg_shift) < 2 * (p.n_total / (size_t)p.nb)) p.seg_shift++;
     // reduce: chunk-lanes per window (chunk length a power of two): the per-lane work is a
     // dependency chain, so shorter chunks on more lanes cut the latency
     int chunks = p.nb < MSM_REDUCE_CHUNKS ? p.nb : MSM_REDUCE_CHUNKS;
@@ -707,7 +766,7 @@ void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, si
     };
     size_t nbk = (size_t)p.W * p.nb1;
     w.entries = (uint32_t *)take(p.n_total * entry_bytes);
-    w.digits = (int16_t *)take((size_t)p.W * p.n_total * 2);
+    w.digits = (int16_t *)take((size_t)p.W * p.n_pad * 2);
     w.hist = (uint32_t *)take((size_t)p.W * p.S * p.nb1 * 4);
     w.counts = (uint32_t *)take(nbk * 4);
     w.starts = (uint32_t *)take(nbk * 4);
@@ -717,7 +776,7 @@ void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, si
     // segment planning: at most M/SEG full segments plus one remainder per non-empty bucket
     size_t m_max = (size_t)p.W * p.n_total;
     size_t nonempty_max = m_max < (size_t)p.W * p.nb ? m_max : (size_t)p.W * p.nb;
-    w.t_max = m_max / MSM_SEG + nonempty_max;
+    w.t_max = m_max / ((size_t)MSM_SEG << p.seg_shift) + nonempty_max;
     w.plan_blocks = (uint32_t)((nbk + MSM_BLOCK - 1) / MSM_BLOCK);
     size_t hist_n = (size_t)MSM_SEG * w.plan_blocks;
     w.nseg = (uint32_t *)take(nbk * 4);
@@ -737,8 +796,8 @@ int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scal
                    const void *extra_scalars, const msm_modulus &modulus) {
     hipStream_t st = ctx->stream;
     const size_t n_total = p.n_total;
-    const unsigned gb = (unsigned)((n_total + MSM_BLOCK - 1) / MSM_BLOCK);
-    const size_t lds_bytes = (size_t)p.nb1 * 4;
+    const unsigned gb = (unsigned)((p.n_pad + MSM_BLOCK - 1) / MSM_BLOCK);
+    const size_t lds_bytes = (size_t)p.range_len * 4;
     if (lds_bytes > 48 * 1024) {
         VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_hist,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -748,14 +807,14 @@ int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scal
     {
         vmpc_stage_scope s(ctx, "msm_recode");
         k_msm_recode<<<gb, MSM_BLOCK, 0, st>>>((const uint32_t *)scalars, n,
-                                              (const uint32_t *)extra_scalars, n_total, w.digits, p.c,
+                                              (const uint32_t *)extra_scalars, n_total, p.n_pad, w.digits, p.c,
                                               p.W, modulus, ctx->d_status);
         VMPC_KERNEL_CHECK();
     }
     {
         vmpc_stage_scope s(ctx, "msm_hist");
-        k_msm_hist<<<dim3(p.S, p.W), MSM_SORT_BLOCK, lds_bytes, st>>>(w.digits, n_total, p.slice_len,
-                                                                     p.nb1, p.S, w.hist);
+        k_msm_hist<<<dim3(p.S * p.R, p.W), MSM_SORT_BLOCK, lds_bytes, st>>>(
+            w.digits, p.n_pad, p.slice_len, p.nb1, p.S, p.R, p.range_len, w.hist);
         VMPC_KERNEL_CHECK();
     }
     size_t nbk = (size_t)p.W * p.nb1;
@@ -769,14 +828,14 @@ int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scal
     }
     {
         vmpc_stage_scope s(ctx, "msm_scatter");
-        k_msm_scatter<<<dim3(p.S, p.W), MSM_SORT_BLOCK, lds_bytes, st>>>(
-            w.digits, n_total, p.slice_len, p.nb1, p.S, w.hist, w.starts, w.sorted);
+        k_msm_scatter<<<dim3(p.S * p.R, p.W), MSM_SORT_BLOCK, lds_bytes, st>>>(
+            w.digits, p.n_pad, p.slice_len, p.nb1, p.S, p.R, p.range_len, w.hist, w.starts, w.sorted);
         VMPC_KERNEL_CHECK();
     }
     {
         vmpc_stage_scope s(ctx, "msm_plan");
         VMPC_HIP_CHECK(hipMemsetAsync(w.ctrl, 0, 64, st));
-        k_msm_plan1<<<w.plan_blocks, MSM_BLOCK, 0, st>>>(w.counts, (uint32_t)nbk, w.plan_blocks, w.nseg,
+        k_msm_plan1<<<w.plan_blocks, MSM_BLOCK, 0, st>>>(w.counts, (uint32_t)nbk, w.plan_blocks, p.seg_shift, w.nseg,
                                                         w.block_hist, w.heavy_list, w.ctrl);
         VMPC_KERNEL_CHECK();
         size_t hist_n = (size_t)MSM_SEG * w.plan_blocks;
@@ -784,7 +843,7 @@ int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scal
                                                             w.scan_ws, w.ctrl + 1)));   // ctrl[1] = #tasks
         VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint32_t>(st, w.nseg, w.seg_starts, nbk, w.scan_ws,
                                                             (uint32_t *)nullptr)));
-        k_msm_plan2<<<w.plan_blocks, MSM_BLOCK, 0, st>>>(w.counts, (uint32_t)nbk, w.plan_blocks,
+        k_msm_plan2<<<w.plan_blocks, MSM_BLOCK, 0, st>>>(w.counts, (uint32_t)nbk, w.plan_blocks, p.seg_shift,
                                                         w.block_base, w.tasks);
         VMPC_KERNEL_CHECK();
     }
@@ -830,7 +889,7 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
         vmpc_stage_scope s(ctx, "msm_bucket");
         k_msm_bucket<<<(unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
             w.entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
-            w.buckets, w.seg_partial);
+            MSM_SEG << p.seg_shift, w.buckets, w.seg_partial);
         VMPC_KERNEL_CHECK();
     }
     {

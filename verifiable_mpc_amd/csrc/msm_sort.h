@@ -9,7 +9,8 @@
 #define MSM_MAX_C 16
 #define MSM_BLOCK 256
 #define MSM_SORT_BLOCK 1024
-#define MSM_SEG 64
+#define MSM_SEG 64          // length bins of the task table; a segment holds MSM_SEG << seg_shift entries
+#define MSM_SEG_LOG2 6
 #define MSM_FINISH_SERIAL 32
 #ifndef MSM_REDUCE_CHUNKS
 #define MSM_REDUCE_CHUNKS 4096
@@ -20,7 +21,11 @@ struct msm_plan {
     int scalar_bits;    // scalars are < 2^scalar_bits
     int c, W, nb, nb1;  // nb = 2^(c-1) buckets per window, nb1 = nb + 1 (bucket 0 unused)
     int S;              // slices per window in the sort kernels
-    size_t slice_len;
+    size_t slice_len;   // multiple of 8
+    int seg_shift;      // segments of MSM_SEG << seg_shift entries
+    int R;              // bucket ranges per window in the sort kernels
+    int range_len;      // buckets per range (the LDS array of one sort workgroup)
+    size_t n_pad;       // digit row stride: n_total rounded up to 8 (rows are 16-byte aligned, zero padded)
     int chunks;         // chunk-threads per window in the reduce kernel
     int chunk_len;      // buckets per chunk (power of two)
     int red_blocks;     // blocks per window in the reduce kernel
