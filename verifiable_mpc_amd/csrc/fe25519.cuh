@@ -394,7 +394,6 @@ VMPC_HD fe fe_const_d2() {
              0x19ce331u, 0x1c56dffu, 0x0901b67u}};
     return r;
 }
-
 // ---- shared helper of the Montgomery fields (sw256.cuh): 96-bit multiply-accumulate ----------------
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(VMPC_NO_DEVICE_ASM)
 #define VMPC_DEVICE_ASM 1

@@ -351,11 +351,7 @@ k_msm_plan2(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nbloc
 }
 
 __device__ __forceinline__ ge_niels niels_ld(const uint32_t *niels, uint32_t e) {
-#ifdef MSM_GATHER_MASK   // experiment: cache-resident gather (wrong results) to expose the ALU time
-    return niels_ld_line(niels + NIELS_WORDS * (size_t)(e & MSM_GATHER_MASK));
-#else
     return niels_ld_line(niels + NIELS_WORDS * (size_t)(e & 0x7fffffffu));
-#endif
 }
 
 // one lane = one segment of <= MSM_SEG sorted entries
@@ -380,7 +376,9 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
     uint32_t e = sorted[lo];
     ge_niels q = niels_ld(niels, e);
     for (uint32_t j = 0; j < len; j++) {
-        // fetch the next term before the 7 multiplications of this one
+        // fetch the next term before the 7 multiplications of this one.  (Initialising the
+        // accumulator from the first term - ge_ext_from_niels, 1M instead of 7M - was tried: the
+        // compiler then waits for each gather right after issuing it and the kernel runs 2x slower.)
         uint32_t jn = j + 1 < len ? j + 1 : j;
         uint32_t en = sorted[lo + jn];
         ge_niels qn = niels_ld(niels, en);
