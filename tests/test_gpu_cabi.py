@@ -186,6 +186,65 @@ def test_msm_edge_cases(nat, ctx):
     ctx.sync()  # status word was cleared
 
 
+@pytest.mark.parametrize("n,n_extra", [(1, 0), (5, 1), (64, 2), (301, 2)])
+def test_fixed_base_table_matches_oracle(nat, ctx, n, n_extra):
+    """vmpc_msm_table_dev over (g, extras) == pivot.vector_commitment restated, for the whole
+    vector, a prefix, the empty prefix, and with / without the extra (h ** gamma) terms."""
+    rng = random.Random(700 + n)
+    _, pts = make_points(rng, n + n_extra)
+    g, extras = pts[:n], pts[n:]
+    x = [rng.randrange(ELL) for _ in range(n)]
+    for i, v in enumerate([0, 1, ELL - 1, 2, ELL // 2, ELL // 2 + 1, (1 << 252) + 5]):
+        if i < n:
+            x[i] = v
+    gam = [rng.randrange(ELL) for _ in range(n_extra)]
+    dp = ctx.upload(aff_bytes(g))
+    de = ctx.upload(aff_bytes(extras)) if n_extra else None
+    table = ctx.msm_table_build(dp.ptr, n, de.ptr if de else None, n_extra)
+    ds = ctx.upload(sc_bytes(nat, x))
+    dg = ctx.upload(sc_bytes(nat, gam)) if n_extra else None
+    out, out_ext = ctx.alloc(64), ctx.alloc(128)
+    for m in sorted({n, n // 2, 1, 0}):
+        for use_extra in ([True, False] if n_extra else [False]):
+            acc = ed.IDENTITY
+            for xi, gi in zip(x[:m], g[:m]):
+                acc = ed.pt_add(acc, ed.pt_repeat(gi, xi))
+            if use_extra:
+                for si, ei in zip(gam, extras):
+                    acc = ed.pt_add(acc, ed.pt_repeat(ei, si))
+            ctx.msm_table(table.ptr, n, n_extra, ds.ptr, m, dg.ptr if use_extra else None, out_ext.ptr, out.ptr)
+            ctx.sync()
+            assert dl_aff(ctx, out.ptr)[0][:2] == ed.pt_affine(acc), (m, use_extra)
+            raw = ctx.download(out_ext.ptr, 128).tobytes()
+            X, Y, Z, T = (int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(4))
+            assert ed.pt_affine((X, Y, Z)) == ed.pt_affine(acc) and (X * Y - T * Z) % P == 0
+    # a non-canonical scalar is reported at the sync point, as for vmpc_msm_dev
+    bad = np.frombuffer(ELL.to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32)
+    dsb = ctx.upload(bad)
+    ctx.msm_table(table.ptr, n, n_extra, dsb.ptr, 1, None, None, out.ptr)
+    with pytest.raises(nat.VmpcError) as ei:
+        ctx.sync()
+    assert ei.value.code == nat.E_NONCANON
+    ctx.sync()
+
+
+def test_fixed_base_table_skewed_scalars(nat, ctx):
+    """all terms in one bucket / a handful of buckets: the split + finish path of the single
+    shared bucket set"""
+    rng = random.Random(77)
+    n = 5000
+    exps = [rng.randrange(1, ELL) for _ in range(n)]
+    pts = gpu_points(nat, ctx, exps)
+    table = ctx.msm_table_build(pts.ptr, n, None, 0)
+    out = ctx.alloc(64)
+    for x in ([1] * n, [(1 << 16) + 1] * n, [ELL - 1] * n, [i % 3 for i in range(n)]):
+        ds = ctx.upload(sc_bytes(nat, x))
+        ctx.msm_table(table.ptr, n, 0, ds.ptr, n, None, None, out.ptr)
+        ctx.sync()
+        want = ed.pt_affine(ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(x, exps)) % ELL))
+        assert dl_aff(ctx, out.ptr)[0][:2] == want
+
+
 def test_repeat_replays_reference_sequence(nat, ctx):
     """`g ** n` gives the oracle's exact projective representative (Z included)."""
     rng = random.Random(11)

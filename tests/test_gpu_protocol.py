@@ -219,6 +219,42 @@ def test_compact_transcript_matches_oracle(vm, monkeypatch, n):
                                                    transcript="compact") is False
 
 
+def test_precomputed_generators_give_identical_proofs(vm):
+    """PointVector.precompute (fixed-base tables) changes how commitments are computed, not what
+    they are: commitments and whole Protocol-5 proofs are identical with and without it."""
+    rng = random.Random(808)
+    n = 63
+    exps = [rng.randrange(1, ELL) for _ in range(n)]
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    h, k = group.generator, vm.Ed25519Point.repeat(group.generator, rng.randrange(1, ELL))
+    x = [rng.randrange(ELL) for _ in range(n)]
+    coeffs = [rng.randrange(ELL) for _ in range(n)]
+    gamma, rho = rng.randrange(1, ELL), rng.randrange(ELL)
+    r = [rng.randrange(ELL) for _ in range(n)]
+    results = []
+    for pre in (False, True):
+        g = vm.PointVector.fixed_base(h, exps, keep_proj=True)
+        if pre:
+            g.precompute([h, k])
+            assert g[:10]._table is g._table and g[1:]._table is None
+        gens = {"g": g, "h": h, "k": k}
+        xs, Lf = vm.ScalarVector.from_ints(x), vm.pivot.LinearForm(vm.ScalarVector.from_ints(coeffs))
+        P = vm.pivot.vector_commitment(xs, gamma, g, h)
+        Pk = vm.pivot.vector_commitment(xs[:20], gamma, g, k)          # prefix, other base point
+        y = gf(Lf(xs))
+        proofs = {}
+        for mode in ("compact", "reference"):
+            proof = vm.compressed_pivot.protocol_5_prover(gens, P, Lf, y, xs, gamma, gf, transcript=mode,
+                                                          r=list(r), rho=rho)
+            assert vm.compressed_pivot.protocol_5_verifier(gens, P, Lf, y, proof, gf, transcript=mode) is True
+            proofs[mode] = {key: (tuple(v.normalize().coords) if hasattr(v, "normalize") else
+                                  [int(e) for e in v] if isinstance(v, list) else int(v))
+                            for key, v in proof.items()}
+        results.append((tuple(P.normalize().coords), tuple(Pk.normalize().coords), proofs))
+    assert results[0] == results[1]
+
+
 def test_basic_pivot_fixture(vm, golden_small, monkeypatch, record_hashes):
     """Pi_s (pivot.py:156-205)."""
     case = golden_small["pis"][0]

@@ -29,7 +29,7 @@ SYMBOLS = [
     "vmpc_memcpy_d2h", "vmpc_memcpy_d2d", "vmpc_ctx_profile", "vmpc_ctx_profile_read",
     "vmpc_ctx_set_window", "vmpc_ed25519_msm_plan", "vmpc_ed25519_madd_rate", "vmpc_ed25519_msm", "vmpc_ed25519_fold",
     "vmpc_ed25519_fixed_base_batch", "vmpc_fr_axpy", "vmpc_fr_dot", "vmpc_points_validate_dev",
-    "vmpc_msm_dev", "vmpc_points_sum_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
+    "vmpc_msm_dev", "vmpc_msm_table_bytes", "vmpc_msm_table_build_dev", "vmpc_msm_table_dev", "vmpc_points_sum_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
     "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
     "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
@@ -85,6 +85,9 @@ def load_library():
         "vmpc_fr_dot": (i32, [vp, vp, sz, vp]),
         "vmpc_points_validate_dev": (i32, [vp, vp, sz, u64p]),
         "vmpc_msm_dev": (i32, [vp, vp, vp, sz, vp, vp, sz, vp, vp]),
+        "vmpc_msm_table_bytes": (i32, [sz, sz, vp]),
+        "vmpc_msm_table_build_dev": (i32, [vp, vp, sz, vp, sz, vp]),
+        "vmpc_msm_table_dev": (i32, [vp, vp, sz, sz, vp, sz, vp, vp, vp]),
         "vmpc_points_sum_dev": (i32, [vp, vp, sz, vp, vp]),
         "vmpc_repeat_dev": (i32, [vp, vp, sz, i32, vp, sz, i32, vp, vp]),
         "vmpc_fold_dev": (i32, [vp, vp, vp, i32, vp, sz, vp, vp]),
@@ -410,6 +413,24 @@ class Context:
                                      ctypes.c_void_p(extra_points_ptr), n_extra,
                                      ctypes.c_void_p(out_ext_ptr), ctypes.c_void_p(out_affine_ptr)),
                "vmpc_msm_dev")
+
+    def msm_table_build(self, points_ptr, n, extra_points_ptr=None, n_extra=0):
+        """Fixed-base table (DeviceBuffer) over n points followed by n_extra extra points."""
+        nbytes = ctypes.c_size_t(0)
+        _check(self.lib.vmpc_msm_table_bytes(n, n_extra, ctypes.byref(nbytes)), "vmpc_msm_table_bytes")
+        table = self.alloc(nbytes.value)
+        _check(self.lib.vmpc_msm_table_build_dev(self.handle, ctypes.c_void_p(points_ptr), n,
+                                                 ctypes.c_void_p(extra_points_ptr), n_extra,
+                                                 ctypes.c_void_p(table.ptr)), "vmpc_msm_table_build_dev")
+        return table
+
+    def msm_table(self, table_ptr, table_n, table_extra, scalars_ptr, m, extra_scalars_ptr=None,
+                  out_ext_ptr=None, out_affine_ptr=None):
+        _check(self.lib.vmpc_msm_table_dev(self.handle, ctypes.c_void_p(table_ptr), table_n, table_extra,
+                                           ctypes.c_void_p(scalars_ptr), m,
+                                           ctypes.c_void_p(extra_scalars_ptr),
+                                           ctypes.c_void_p(out_ext_ptr), ctypes.c_void_p(out_affine_ptr)),
+               "vmpc_msm_table_dev")
 
     def points_sum(self, ext_ptr, m, out_ext_ptr=None, out_affine_ptr=None):
         _check(self.lib.vmpc_points_sum_dev(self.handle, ctypes.c_void_p(ext_ptr), m,

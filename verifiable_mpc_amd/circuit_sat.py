@@ -32,6 +32,12 @@ def _our_point(obj):
     return Ed25519Point((int(obj[0]), int(obj[1]), int(obj[2])))
 
 
+# Generators are a CRS: up to this many get a fixed-base table at creation (2 KiB each, so 256 MiB -
+# the size that still sits in the Infinity Cache; beyond it the table gather runs at HBM speed and the
+# gain over the variable-base MSM shrinks to ~10 %: PointVector.precompute stays available).
+PRECOMPUTE_MAX = 1 << 17
+
+
 def create_generators(g_length, pivot_choice, group=None, progress_bar=False):
     """Create generators g, h, k with g_i = h ** r_i on the GPU (one lane per generator,
     csrc/exact.hip k_repeat).  Exponents are drawn from `prng` in the reference's order:
@@ -46,8 +52,12 @@ def create_generators(g_length, pivot_choice, group=None, progress_bar=False):
         print("Generating keys: on device", end="\r")
     g = PointVector.fixed_base(h, random_exponents)
     if pivot_choice == PivotChoice.pivot:
+        if g_length <= PRECOMPUTE_MAX:
+            g.precompute([h])
         return {"g": g, "h": h}
     k = Ed25519Point.repeat(h, prng.randrange(1, group.order))
+    if g_length <= PRECOMPUTE_MAX:
+        g.precompute([h, k])
     return {"g": g, "h": h, "k": k}
 
 

@@ -157,17 +157,21 @@ k_msm_prep(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__re
 }
 
 // ---- recode: scalar -> signed digits ----------------------------------------------------
+// Row w of `digits` holds window w of every term: main terms at [0, n_main), extra terms at
+// [extra_pos, extra_pos + n_extra), zeros (= no entry) everywhere else up to the row stride n_pad.
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__restrict__ sc_extra,
-             size_t n_total, size_t n_pad, int16_t *__restrict__ digits, int c, int W, msm_modulus mod,
-             uint32_t *__restrict__ status) {
+             size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *__restrict__ digits, int c, int W,
+             msm_modulus mod, uint32_t *__restrict__ status) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) {
-        if (i < n_pad)                       // zero digits = no entry: the sort kernels read whole 16-byte vectors
-            for (int w = 0; w < W; w++) digits[(size_t)w * n_pad + i] = 0;
+    if (i >= n_pad) return;
+    const uint32_t *src = nullptr;
+    if (i < n_main) src = sc + 8 * i;
+    else if (sc_extra && i >= extra_pos && i < extra_pos + n_extra) src = sc_extra + 8 * (i - extra_pos);
+    if (!src) {                              // the sort kernels read whole 16-byte vectors of a row
+        for (int w = 0; w < W; w++) digits[(size_t)w * n_pad + i] = 0;
         return;
     }
-    const uint32_t *src = (i < n_main) ? sc + 8 * i : sc_extra + 8 * (i - n_main);
     uint32_t s[8];
     load_u32x8(s, src);
     {   // canonical residue? (s < modulus); the caller is told at the next sync point
@@ -715,6 +719,11 @@ void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits
         p.c++;
         p.W = (scalar_bits + 2 + p.c - 1) / p.c;
     }
+    msm_plan_geometry(ctx, p);
+}
+
+// everything that follows from (n_total, c, W): sort decomposition, segment length, reduce shape
+void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
     p.nb = 1 << (p.c - 1);
     p.nb1 = p.nb + 1;
     // sort workgroups = (slice, bucket range, window).  Two things make the scatter's 4-byte
@@ -742,11 +751,12 @@ void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits
     if (ctx->sort_slices) S = ctx->sort_slices;
     p.S = S;
     p.slice_len = (((p.n_pad + S - 1) / S) + 7) & ~(size_t)7;
-    // segment length: 64 entries up to an average bucket load of 32 (n = 2^20 at c = 16), doubled
-    // while the average load exceeds half of it - otherwise every bucket of a 2^22-term MSM is
-    // split in three and the finish stage (one more gather of 160-byte partial sums) costs 14 %
+    // segment length: the bucket stage wants ~4 tasks per lane of the chip (2^18) of equal length.
+    // 64 entries up to W * n = 2^24 (n = 2^20 at c = 16), doubled from there - otherwise every
+    // bucket of a 2^22-term MSM is split in three and the finish stage (one more gather of
+    // 160-byte partial sums) costs 14 %
     p.seg_shift = 0;
-    while (p.seg_shift < 4 && ((size_t)MSM_SEG << p.seg_shift) < 2 * (p.n_total / (size_t)p.nb)) p.seg_shift++;
+    while (p.seg_shift < 4 && (((size_t)MSM_SEG << p.seg_shift) << 18) < (size_t)p.W * p.n_total) p.seg_shift++;
     // reduce: chunk-lanes per window (chunk length a power of two): the per-lane work is a
     // dependency chain, so shorter chunks on more lanes cut the latency
     int chunks = p.nb < MSM_REDUCE_CHUNKS ? p.nb : MSM_REDUCE_CHUNKS;
@@ -795,19 +805,25 @@ int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scal
     hipStream_t st = ctx->stream;
     const size_t n_total = p.n_total;
     const unsigned gb = (unsigned)((p.n_pad + MSM_BLOCK - 1) / MSM_BLOCK);
+    {
+        vmpc_stage_scope s(ctx, "msm_recode");
+        k_msm_recode<<<gb, MSM_BLOCK, 0, st>>>((const uint32_t *)scalars, n,
+                                              (const uint32_t *)extra_scalars, n, n_total - n, p.n_pad, w.digits, p.c,
+                                              p.W, modulus, ctx->d_status);
+        VMPC_KERNEL_CHECK();
+    }
+    return msm_sort_digits(ctx, p, w);
+}
+
+// hist -> counts/scan -> scatter -> plan over digits already in w.digits
+int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
+    hipStream_t st = ctx->stream;
     const size_t lds_bytes = (size_t)p.range_len * 4;
     if (lds_bytes > 48 * 1024) {
         VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_hist,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_scatter,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    }
-    {
-        vmpc_stage_scope s(ctx, "msm_recode");
-        k_msm_recode<<<gb, MSM_BLOCK, 0, st>>>((const uint32_t *)scalars, n,
-                                              (const uint32_t *)extra_scalars, n_total, p.n_pad, w.digits, p.c,
-                                              p.W, modulus, ctx->d_status);
-        VMPC_KERNEL_CHECK();
     }
     {
         vmpc_stage_scope s(ctx, "msm_hist");
@@ -850,6 +866,44 @@ int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scal
 
 static const msm_modulus ED25519_L = {VMPC_FR_L};
 
+// bucket accumulation -> finish -> reduce -> recombination over a sorted task table; `entries` is
+// the niels array the sorted indices refer to (the call's own prepared points, or a fixed-base table)
+static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uint32_t *entries, void *out_ext,
+                          void *out_affine) {
+    hipStream_t st = ctx->stream;
+    {
+        vmpc_stage_scope s(ctx, "msm_bucket");
+        k_msm_bucket<<<(unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
+            entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
+            MSM_SEG << p.seg_shift, w.buckets, w.seg_partial);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_bucket_finish");
+        k_msm_bucket_finish_light<<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(
+            w.heavy_list, w.ctrl, w.nseg, w.seg_starts, w.seg_partial, p.nb1, w.buckets);
+        VMPC_KERNEL_CHECK();
+        k_msm_bucket_finish<<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg,
+                                                                    w.seg_starts, w.seg_partial, p.nb1,
+                                                                    w.buckets);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_reduce");
+        k_msm_reduce<<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, st>>>(
+            w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, msm_ilog2(p.chunk_len), p.red_blocks, w.partials);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_final");
+        k_msm_final<<<1, 64, 0, st>>>(w.partials, p.W, p.red_blocks, p.c, (uint32_t *)out_ext,
+                                      (uint32_t *)out_affine);
+        VMPC_KERNEL_CHECK();
+    }
+    return VMPC_OK;
+}
+
+
 extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affine_points, size_t n,
                             const void *extra_scalars, const void *extra_affine_points,
                             size_t n_extra, void *out_ext, void *out_affine) {
@@ -883,36 +937,98 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
         VMPC_KERNEL_CHECK();
     }
     VMPC_CHECK(msm_sort_stage(ctx, p, w, scalars, n, extra_scalars, ED25519_L));
-    {
-        vmpc_stage_scope s(ctx, "msm_bucket");
-        k_msm_bucket<<<(unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
-            w.entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
-            MSM_SEG << p.seg_shift, w.buckets, w.seg_partial);
-        VMPC_KERNEL_CHECK();
+    return msm_accumulate(ctx, p, w, w.entries, out_ext, out_affine);
+}
+
+// ---- fixed-base tables -----------------------------------------------------------------------
+// A generator vector that serves many commitments (the CRS of pivot.py:139-145: g, h, k never
+// change between proofs) is expanded once into  T[w][i] = 2^(16 w) * P_i,  w = 0..15, in niels form.
+// Term (i, window w) of any later MSM then adds T[w][i] into bucket |digit| of ONE shared bucket
+// set: the flattened digit array [w][i] is sorted as a single window of 16*stride entries whose
+// indices ARE table positions.  No window recombination remains (the 240-doubling Horner chain
+// and 15/16 of the bucket reduction disappear), and no per-call point preparation.
+#define MSM_TABLE_C 16
+#define MSM_TABLE_W 16
+
+static size_t msm_table_stride(size_t n_points) { return (n_points + 7) & ~(size_t)7; }
+
+__global__ void __launch_bounds__(MSM_BLOCK, 2)
+k_msm_table_build(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__restrict__ aff_extra,
+                  size_t n_total, size_t stride, uint32_t *__restrict__ table) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= stride) return;
+    if (i >= n_total) {     // padding rows are never referenced (their digits are zero); keep them defined
+        ge_niels z;
+        z.ymx = fe_one();
+        z.ypx = fe_one();
+        z.t2d = fe_zero();
+        for (int w = 0; w < MSM_TABLE_W; w++) niels_st_line(table + NIELS_WORDS * ((size_t)w * stride + i), z);
+        return;
     }
-    {
-        vmpc_stage_scope s(ctx, "msm_bucket_finish");
-        k_msm_bucket_finish_light<<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(
-            w.heavy_list, w.ctrl, w.nseg, w.seg_starts, w.seg_partial, p.nb1, w.buckets);
-        VMPC_KERNEL_CHECK();
-        k_msm_bucket_finish<<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg,
-                                                                    w.seg_starts, w.seg_partial, p.nb1,
-                                                                    w.buckets);
-        VMPC_KERNEL_CHECK();
+    const uint32_t *src = (i < n_main) ? aff + 16 * i : aff_extra + 16 * (i - n_main);
+    ge_aff a;
+    a.x = fe_ld8(src);
+    a.y = fe_ld8(src + 8);
+    niels_st_line(table + NIELS_WORDS * i, ge_niels_from_affine(a));
+    ge_ext q = ge_ext_from_affine(a);
+    for (int w = 1; w < MSM_TABLE_W; w++) {
+        for (int k = 0; k < MSM_TABLE_C; k++) q = ge_dbl(q);
+        ge_aff b = ge_ext_to_affine(q);
+        niels_st_line(table + NIELS_WORDS * ((size_t)w * stride + i), ge_niels_from_affine(b));
     }
-    {
-        vmpc_stage_scope s(ctx, "msm_reduce");
-        k_msm_reduce<<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, st>>>(
-            w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, msm_ilog2(p.chunk_len), p.red_blocks, w.partials);
-        VMPC_KERNEL_CHECK();
-    }
-    {
-        vmpc_stage_scope s(ctx, "msm_final");
-        k_msm_final<<<1, 64, 0, st>>>(w.partials, p.W, p.red_blocks, p.c, (uint32_t *)out_ext,
-                                      (uint32_t *)out_affine);
-        VMPC_KERNEL_CHECK();
-    }
+}
+
+extern "C" int vmpc_msm_table_bytes(size_t n, size_t n_extra, size_t *bytes) {
+    if (!bytes || n + n_extra == 0 || n + n_extra > ((size_t)1 << 26)) return VMPC_E_INVAL;
+    *bytes = (size_t)MSM_TABLE_W * msm_table_stride(n + n_extra) * NIELS_WORDS * 4;
     return VMPC_OK;
+}
+
+extern "C" int vmpc_msm_table_build_dev(vmpc_ctx *ctx, const void *affine_points, size_t n,
+                                        const void *extra_affine_points, size_t n_extra, void *table) {
+    if (!ctx || !table || (n && !affine_points) || (n_extra && !extra_affine_points) || n + n_extra == 0 ||
+        n + n_extra > ((size_t)1 << 26))
+        return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t stride = msm_table_stride(n + n_extra);
+    vmpc_stage_scope s(ctx, "msm_table_build");
+    k_msm_table_build<<<(unsigned)((stride + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
+        (const uint32_t *)affine_points, n, (const uint32_t *)extra_affine_points, n + n_extra, stride,
+        (uint32_t *)table);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra,
+                                  const void *scalars, size_t m, const void *extra_scalars, void *out_ext,
+                                  void *out_affine) {
+    if (!ctx || !table || m > table_n || (m && !scalars) || table_n + table_extra == 0 ||
+        table_n + table_extra > ((size_t)1 << 26) || (!out_ext && !out_affine))
+        return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t stride = msm_table_stride(table_n + table_extra);
+    // the whole digit array is ONE window of 16 * stride entries
+    msm_plan p;
+    p.n_main = p.n_total = (size_t)MSM_TABLE_W * stride;
+    p.n_extra = 0;
+    p.scalar_bits = 253;
+    p.c = MSM_TABLE_C;
+    p.W = 1;
+    msm_plan_geometry(ctx, p);
+    msm_ws w;
+    msm_layout(p, w, nullptr, 0, EXT_WORDS * 4);
+    VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
+    msm_layout(p, w, (char *)ctx->ws, 0, EXT_WORDS * 4);
+    {
+        vmpc_stage_scope s(ctx, "msm_recode");
+        k_msm_recode<<<(unsigned)((stride + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
+            (const uint32_t *)scalars, m, (const uint32_t *)extra_scalars, table_n, table_extra, stride, w.digits,
+            MSM_TABLE_C, MSM_TABLE_W, ED25519_L, ctx->d_status);
+        VMPC_KERNEL_CHECK();
+    }
+    VMPC_CHECK(msm_sort_digits(ctx, p, w));
+    return msm_accumulate(ctx, p, w, (const uint32_t *)table, out_ext, out_affine);
 }
 
 extern "C" int vmpc_points_sum_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, void *out_ext,

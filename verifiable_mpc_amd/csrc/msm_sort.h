@@ -51,11 +51,13 @@ struct msm_modulus {
 };
 
 void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits, msm_plan &p);
+void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p);   // from (n_total, c, W) already set
 void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, size_t acc_bytes);
 // recode -> hist -> counts/scan -> scatter -> plan: fills digits, sorted, starts, counts, nseg,
 // seg_starts, heavy_list, tasks, ctrl[0] = #split buckets, ctrl[1] = #tasks
 int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scalars, size_t n,
                    const void *extra_scalars, const msm_modulus &modulus);
+int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w);   // the same minus the recoding
 
 static inline int msm_ilog2(int v) {
     int r = 0;

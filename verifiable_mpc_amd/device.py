@@ -172,6 +172,24 @@ class ScalarVector:
         return "[" + body[:-2] + "]"
 
 
+class FixedBaseTable:
+    """Device table 2^(16 w) * P_i over a generator vector followed by a few extra base points."""
+
+    def __init__(self, buf, n, extra_bytes):
+        self.buf, self.n, self.extra_bytes = buf, n, extra_bytes
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    def extra_index(self, point):
+        """position of `point` among the extras, or None"""
+        try:
+            return self.extra_bytes.index(point.to_affine_bytes())
+        except ValueError:
+            return None
+
+
 class PointVector:
     """n Ed25519 points on the device, affine always, projective representatives when the
     reference transcript needs them (`keep_proj`)."""
@@ -181,6 +199,7 @@ class PointVector:
         self.a = affine_view
         self.p = proj_view
         self._digest = None
+        self._table = None       # FixedBaseTable over this vector (precompute)
 
     # ---- construction ----------------------------------------------------------------------
     @classmethod
@@ -244,8 +263,11 @@ class PointVector:
     def __getitem__(self, key):
         if isinstance(key, slice):
             a, b = _slice_bounds(key, self.a.n)
-            return PointVector(self.a.sub(a, b), self.p.sub(a, b) if self.p is not None else None,
-                               self.ctx)
+            sub = PointVector(self.a.sub(a, b), self.p.sub(a, b) if self.p is not None else None,
+                              self.ctx)
+            if a == 0:
+                sub._table = self._table       # a prefix addresses the same table rows
+            return sub
         if key < 0:
             key += self.a.n
         if self.p is not None:
@@ -289,6 +311,19 @@ class PointVector:
         return NotImplemented
 
     # ---- kernels -------------------------------------------------------------------------------
+    def precompute(self, extras=()):
+        """Build the fixed-base table (include/vmpc.h: vmpc_msm_table_build_dev) for this vector and
+        the `extras` (the commitment bases h, k of the CRS).  Commitments over this vector or a
+        prefix of it, with one of `extras` as base point, then run as a single bucket pass with no
+        window recombination (2x shorter below ~2^17 generators; 2 KiB of HBM per generator)."""
+        extras = list(extras)
+        raw = b"".join(p.to_affine_bytes() for p in extras)
+        eb = self.ctx.upload(np.frombuffer(raw, np.uint8)) if extras else None
+        buf = self.ctx.msm_table_build(self.a.ptr, len(self), eb.ptr if eb else None, len(extras))
+        self.ctx.sync()
+        self._table = FixedBaseTable(buf, len(self), [raw[64 * i:64 * i + 64] for i in range(len(extras))])
+        return self
+
     def fold(self, other, c, keep_proj=None):
         """[(self[i] ** c) * other[i]] (compressed_pivot.py:64/:178), csrc/exact.hip k_fold."""
         assert len(self) == len(other)
