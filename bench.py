@@ -86,21 +86,30 @@ def prove_timing(vm, ctx, n_pow, rng):
     ctx.sync()
     out["create_generators_ms"] = (time.perf_counter() - t0) * 1e3
     gens = {"g": g, "h": group.generator, "k": vm.Ed25519Point.repeat(group.generator, 0x1234567)}
+    t0 = time.perf_counter()
+    g.precompute([gens["h"], gens["k"]])     # CRS setup, as circuit_sat.create_generators does
+    ctx.sync()
+    out["crs_table_ms"] = (time.perf_counter() - t0) * 1e3
     x = vm.ScalarVector.from_array(rand_scalars(rng, n))
     L = vm.pivot.LinearForm(vm.ScalarVector.from_array(rand_scalars(rng, n)))
     gamma = 0x7654321
     y = gf(L(x))
     P = vm.pivot.vector_commitment(x, gamma, g, gens["h"])
     for mode in ("compact", "reference"):
-        r = vm.ScalarVector.from_array(rand_scalars(rng, n))
         if mode == "compact":
             vm.compressed_pivot.generators_digest(gens)      # CRS digest is setup, cached
-        ctx.sync()
-        t0 = time.perf_counter()
-        proof = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, gamma, gf, transcript=mode,
-                                                      r=r, rho=0x1111)
-        ctx.sync()
-        out[f"prove_ms_{mode}"] = (time.perf_counter() - t0) * 1e3
+        for attempt in ("first_call", "steady"):             # first call grows the stream workspaces
+            r = vm.ScalarVector.from_array(rand_scalars(rng, n))
+            ctx.sync()
+            t0 = time.perf_counter()
+            proof = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, gamma, gf, transcript=mode,
+                                                          r=r, rho=0x1111)
+            ctx.sync()
+            dt = (time.perf_counter() - t0) * 1e3
+            if attempt == "first_call":
+                out[f"prove_ms_{mode}_first_call"] = dt
+            else:
+                out[f"prove_ms_{mode}"] = dt
         t0 = time.perf_counter()
         ok = vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, proof, gf, transcript=mode)
         out[f"verify_ms_{mode}"] = (time.perf_counter() - t0) * 1e3

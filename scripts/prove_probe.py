@@ -28,6 +28,8 @@ def main():
     gf = vm.GF(group.order)
     g = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(rand_scalars(rng, n)))
     gens = {"g": g, "h": group.generator, "k": vm.Ed25519Point.repeat(group.generator, 12345)}
+    if os.environ.get("PRECOMPUTE", "1") == "1":
+        g.precompute([gens["h"], gens["k"]])
     x = vm.ScalarVector.from_array(rand_scalars(rng, n))
     L = vm.pivot.LinearForm(vm.ScalarVector.from_array(rand_scalars(rng, n)))
     y = gf(L(x))

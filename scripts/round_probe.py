@@ -16,6 +16,7 @@ ctx = vm.get_context(); rng = np.random.default_rng(3); n = (1 << k) - 1
 group = vm.EllipticCurve("Ed25519", "projective"); gf = vm.GF(group.order)
 g = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(rand_scalars(rng, n)), keep_proj=(mode == "reference"))
 gens = {"g": g, "h": group.generator, "k": vm.Ed25519Point.repeat(group.generator, 12345)}
+if os.environ.get("PRECOMPUTE", "1") == "1": g.precompute([gens["h"], gens["k"]])
 x = vm.ScalarVector.from_array(rand_scalars(rng, n)); L = pivot.LinearForm(vm.ScalarVector.from_array(rand_scalars(rng, n)))
 y = gf(L(x)); P = pivot.vector_commitment(x, 777, g, gens["h"])
 stamps = []

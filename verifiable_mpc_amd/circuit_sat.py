@@ -32,10 +32,10 @@ def _our_point(obj):
     return Ed25519Point((int(obj[0]), int(obj[1]), int(obj[2])))
 
 
-# Generators are a CRS: up to this many get a fixed-base table at creation (2 KiB each, so 256 MiB -
-# the size that still sits in the Infinity Cache; beyond it the table gather runs at HBM speed and the
-# gain over the variable-base MSM shrinks to ~10 %: PointVector.precompute stays available).
-PRECOMPUTE_MAX = 1 << 17
+# Generators are a CRS: up to this many get a fixed-base table at creation (2 KiB each: 2 GiB of the
+# 288 GB for 2^20).  Besides shortening every commitment over g, the table lets the compact-transcript
+# prover skip the generator folds altogether (compressed_pivot._tabulated).
+PRECOMPUTE_MAX = 1 << 20
 
 
 def create_generators(g_length, pivot_choice, group=None, progress_bar=False):

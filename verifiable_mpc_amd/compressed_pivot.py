@@ -151,6 +151,16 @@ class _Transcript:
 
 # ---- Protocol 4 --------------------------------------------------------------------------------------
 
+def _tabulated(g_hat, k):
+    """g_hat and k live in one fixed-base table: commitments over the UNFOLDED g_hat are then cheaper
+    than folding it (a 2^19-element fold costs as much as eight 2^20-term table commitments)"""
+    t = getattr(g_hat, "_table", None)
+    if t is None:
+        return False
+    slot = t.extra_index(k)
+    return slot is not None and slot >= g_hat._table_tail
+
+
 def _round_prover_scalars(L_tilde, z_hat, half, gf):
     """Exponents of k in A_i, B_i and the split witness (compressed_pivot.py:35-42)."""
     if _on_device(L_tilde.coeffs, z_hat):
@@ -259,7 +269,7 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
         z_l, z_r, gamma_a, gamma_b = _round_prover_scalars(L_tilde, z_hat, half, gf)
         logger_cp.debug("Calculate A_i, B_i.")
         if tail_cs is None and transcript.mode == "compact" and isinstance(z_l, ScalarVector) \
-                and len(g_hat) <= TAIL_BASE and len(g_hat) == m and m >= 4:
+                and len(g_hat) == m and m >= 4 and (len(g_hat) <= TAIL_BASE or _tabulated(g_hat, k)):
             tail_cs = []
         if tail_cs is not None:
             ctx = g_hat.ctx

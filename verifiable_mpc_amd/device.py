@@ -200,6 +200,7 @@ class PointVector:
         self.p = proj_view
         self._digest = None
         self._table = None       # FixedBaseTable over this vector (precompute)
+        self._table_tail = 0     # trailing elements that are the table's extras 0.._table_tail-1
 
     # ---- construction ----------------------------------------------------------------------
     @classmethod
@@ -265,8 +266,9 @@ class PointVector:
             a, b = _slice_bounds(key, self.a.n)
             sub = PointVector(self.a.sub(a, b), self.p.sub(a, b) if self.p is not None else None,
                               self.ctx)
-            if a == 0:
+            if a == 0 and self._table is not None:
                 sub._table = self._table       # a prefix addresses the same table rows
+                sub._table_tail = max(0, b - (len(self) - self._table_tail))
             return sub
         if key < 0:
             key += self.a.n
@@ -303,7 +305,12 @@ class PointVector:
             self.ctx.upload_into(pbuf.ptr + 96 * n,
                                  np.frombuffer(b"".join(p.to_proj_bytes() for p in points), np.uint8))
             pv = _View(pbuf, 0, n + m, 96)
-        return PointVector(_View(abuf, 0, n + m, 64), pv, self.ctx)
+        out = PointVector(_View(abuf, 0, n + m, 64), pv, self.ctx)
+        t = self._table
+        if t is not None and self._table_tail == 0 and n == t.n and \
+                [p.to_affine_bytes() for p in points] == t.extra_bytes[:m]:
+            out._table, out._table_tail = t, m      # g + [h]: h is extra 0 of g's table
+        return out
 
     def __add__(self, other):
         if isinstance(other, (list, tuple)):

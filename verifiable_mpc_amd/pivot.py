@@ -286,14 +286,22 @@ def _commit_launch(xs, gamma, gv, h, ctx):
     n = len(xs)
     out = ctx.alloc(128)
     table = getattr(gv, "_table", None)
-    slot = table.extra_index(h) if table is not None and n <= table.n else None
-    if slot is not None:
-        # fixed-base path: the vector (or the vector this one is a prefix of) and h are in a table
-        esc = bytearray(32 * len(table.extra_bytes))
-        esc[32 * slot:32 * slot + 32] = reduce_scalar(_int(gamma)).to_bytes(32, "little")
-        gam = ctx.upload(np.frombuffer(bytes(esc), np.uint8))
-        ctx.msm_table(table.ptr, table.n, len(table.extra_bytes), xs.ptr, n, gam.ptr, out.ptr, None)
-        return _PendingCommitment(ctx, out, (gam, xs, gv, table))
+    if table is not None:
+        # fixed-base path: gv is (a prefix of) a tabulated vector, possibly followed by the first
+        # `tail` extras of the table (g + [h]), and h is one of the remaining extras
+        tail = gv._table_tail
+        n_main = len(gv) - tail
+        slot = table.extra_index(h)
+        used_tail = max(0, n - n_main)
+        if slot is not None and slot >= used_tail:
+            esc = bytearray(32 * len(table.extra_bytes))
+            esc[32 * slot:32 * slot + 32] = reduce_scalar(_int(gamma)).to_bytes(32, "little")
+            gam = ctx.upload(np.frombuffer(bytes(esc), np.uint8))
+            if used_tail:
+                ctx.copy(gam.ptr, xs.ptr + 32 * n_main, 32 * used_tail)
+            ctx.msm_table(table.ptr, table.n, len(table.extra_bytes), xs.ptr, min(n, n_main), gam.ptr,
+                          out.ptr, None)
+            return _PendingCommitment(ctx, out, (gam, xs, gv, table))
     gam = ctx.upload(np.frombuffer(reduce_scalar(_int(gamma)).to_bytes(32, "little"), np.uint8))
     hb = ctx.upload(np.frombuffer(h.to_affine_bytes(), np.uint8))
     ctx.msm(xs.ptr, gv.affine_ptr, n, gam.ptr, hb.ptr, 1, out.ptr, None)
