@@ -204,6 +204,13 @@ int vmpc_bn256_g2_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points
                           void *out_affine);
 /* group = 1 (G1) or 2 (G2): canonical encodings and curve equation; *n_bad = offenders (sync) */
 int vmpc_bn256_validate_dev(vmpc_ctx *ctx, int group, const void *points, size_t n, uint64_t *n_bad);
+/* Fixed-base tables over an evaluation-key vector (fixed per circuit; pynocchio.py:228-246 reads the
+ * same evalkey entries for every proof): 17 rows 2^(16 w) * P_i.  vmpc_bn256_table_msm_dev computes
+ * sum_{i<m} scalars[i] * P_i, equal to vmpc_bn256_g{1,2}_msm_dev on the first m points. */
+int vmpc_bn256_table_bytes(int group, size_t n, size_t *bytes);
+int vmpc_bn256_table_build_dev(vmpc_ctx *ctx, int group, const void *points, size_t n, void *table);
+int vmpc_bn256_table_msm_dev(vmpc_ctx *ctx, int group, const void *table, size_t table_n,
+                             const void *scalars, size_t m, void *out_affine);
 
 /* SHA-256 of every `chunk_bytes`-sized piece of a device buffer (last piece may be short):
  * out_digests[i] = SHA256(data[i*chunk : (i+1)*chunk]), 32 bytes each.  Leaves of the compact

@@ -30,3 +30,19 @@ for group, gen, width in ((1, G1, 64), (2, G2, 128)):
         prof = ctx.profile_read(True); ctx.profile(False)
         print(f"G{group} n=2^{lg}: {dt*1e3:.2f} ms -> {n/dt/1e6:.1f} M sm/s  " +
               " ".join(f"{k}={ms/max(c,1)*1e3:.0f}us" for k, (ms, c) in prof.items() if k.startswith("bn_")))
+        want = ctx.download(out.ptr, width).tobytes()
+        t0 = time.perf_counter()
+        table = ctx.bn256_table_build(group, dp.ptr, n); ctx.sync()
+        t_build = time.perf_counter() - t0
+        out2 = ctx.alloc(width)
+        ctx.bn256_table_msm(group, table.ptr, n, ds.ptr, n, out2.ptr); ctx.sync()
+        same = ctx.download(out2.ptr, width).tobytes() == want
+        ctx.profile(True); ctx.profile_read(True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.bn256_table_msm(group, table.ptr, n, ds.ptr, n, out2.ptr)
+        ctx.sync(); dt = (time.perf_counter() - t0) / 3
+        prof = ctx.profile_read(True); ctx.profile(False)
+        print(f"   table: {dt*1e3:.2f} ms -> {n/dt/1e6:.1f} M sm/s same={same} build {t_build*1e3:.0f} ms {table.nbytes>>20} MiB  " +
+              " ".join(f"{k}={ms/max(c,1)*1e3:.0f}us" for k, (ms, c) in prof.items() if k.startswith("bn_")))
+        del table

@@ -105,6 +105,46 @@ def test_msm_exceptional_cases(vm, gi):
     assert ei.value.code == _native.E_NONCANON
 
 
+@pytest.mark.parametrize("gi", [0, 1])
+def test_table_msm_matches_variable_base_and_oracle(vm, gi):
+    """vmpc_bn256_table_msm_dev == the exponent identity and the variable-base MSM, for the whole
+    vector, prefixes and the empty prefix; exceptional cases (repeated points, P - P, infinity as an
+    input point) go through the single shared bucket set."""
+    from verifiable_mpc_amd import _native
+    ctx = vm.get_context()
+    grp, E, G, to_b, from_b, width = groups()[gi]
+    rng = random.Random(4000 + grp)
+    n = 257 if grp == 1 else 130
+    exps, pts = walk_points(E, G, rng, n)
+    pts[5], exps[5] = None, 0                                   # infinity among the key points
+    pts[7], exps[7] = pts[6], exps[6]                           # a repeated point
+    pts[9], exps[9] = E.neg(pts[8]), (bn.N - exps[8]) % bn.N     # and a negated one
+    sc = [rng.randrange(bn.N) for _ in range(n)]
+    for i, v in enumerate([0, 1, bn.N - 1, 2, 2**255, bn.N - 2]):
+        sc[i] = v
+    sc[7] = sc[6]                                               # same point, same scalar -> doubling in a bucket
+    sc[9] = sc[8]                                               # P and -P with the same scalar -> cancels
+    arr = np.frombuffer(b"".join(to_b(p) for p in pts), np.uint8).reshape(n, width)
+    dp, ds, out = ctx.upload(arr), ctx.upload(_native.ints_to_array(sc, 32)), ctx.alloc(width)
+    table = ctx.bn256_table_build(grp, dp.ptr, n)
+    for m in (n, n // 2, 10, 1, 0):
+        ctx.bn256_table_msm(grp, table.ptr, n, ds.ptr, m, out.ptr)
+        ctx.sync()
+        got = from_b(ctx.download(out.ptr, width).tobytes())
+        assert got == E.mul(sum(a * b for a, b in zip(sc[:m], exps[:m])) % bn.N, G), m
+        if m:
+            ctx.bn256_msm(grp, ds.ptr, dp.ptr, m, out.ptr)
+            ctx.sync()
+            assert from_b(ctx.download(out.ptr, width).tobytes()) == got
+    # non-canonical scalar reported at the sync point
+    bad = ctx.upload(np.frombuffer(bn.N.to_bytes(32, "little"), np.uint8).reshape(1, 32))
+    ctx.bn256_table_msm(grp, table.ptr, n, bad.ptr, 1, out.ptr)
+    with pytest.raises(_native.VmpcError) as ei:
+        ctx.sync()
+    assert ei.value.code == _native.E_NONCANON
+    ctx.sync()
+
+
 def test_compute_proof_matches_reference_fixture(vm):
     """pynocchio.compute_proof (pynocchio.py:228-273) - eight elements, zero-knowledge terms
     included - equals what the reference's own code produced."""
@@ -134,3 +174,7 @@ def test_compute_proof_matches_reference_fixture(vm):
     # without the zero-knowledge terms the elements differ (the deltas are really used)
     plain = pn.compute_proof(Q, [h2i(v) for v in case["c"]], H(), evalkey, None)
     assert plain["r_v*v_mid*g1"] != proof["r_v*v_mid*g1"]
+    # the prepared (device-resident, tabulated) key gives the same proofs
+    key = pn.PreparedKey(Q, evalkey)
+    assert pn.compute_proof(Q, [h2i(v) for v in case["c"]], H(), key, D) == proof
+    assert pn.compute_proof(Q, [h2i(v) for v in case["c"]], H(), key, None) == plain

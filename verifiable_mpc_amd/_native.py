@@ -35,7 +35,7 @@ SYMBOLS = [
     "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
-    "vmpc_bn256_validate_dev",
+    "vmpc_bn256_validate_dev", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
 ]
 
 
@@ -111,6 +111,9 @@ def load_library():
         "vmpc_bn256_g1_msm_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_bn256_g2_msm_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_bn256_validate_dev": (i32, [vp, i32, vp, sz, u64p]),
+        "vmpc_bn256_table_bytes": (i32, [i32, sz, vp]),
+        "vmpc_bn256_table_build_dev": (i32, [vp, i32, vp, sz, vp]),
+        "vmpc_bn256_table_msm_dev": (i32, [vp, i32, vp, sz, vp, sz, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the export is missing
@@ -511,6 +514,19 @@ class Context:
         fn = self.lib.vmpc_bn256_g1_msm_dev if group == 1 else self.lib.vmpc_bn256_g2_msm_dev
         _check(fn(self.handle, ctypes.c_void_p(scalars_ptr), ctypes.c_void_p(points_ptr), n,
                   ctypes.c_void_p(out_ptr)), f"vmpc_bn256_g{group}_msm_dev")
+
+    def bn256_table_build(self, group, points_ptr, n):
+        nbytes = ctypes.c_size_t(0)
+        _check(self.lib.vmpc_bn256_table_bytes(group, n, ctypes.byref(nbytes)), "vmpc_bn256_table_bytes")
+        table = self.alloc(nbytes.value)
+        _check(self.lib.vmpc_bn256_table_build_dev(self.handle, group, ctypes.c_void_p(points_ptr), n,
+                                                   ctypes.c_void_p(table.ptr)), "vmpc_bn256_table_build_dev")
+        return table
+
+    def bn256_table_msm(self, group, table_ptr, table_n, scalars_ptr, m, out_ptr):
+        _check(self.lib.vmpc_bn256_table_msm_dev(self.handle, group, ctypes.c_void_p(table_ptr), table_n,
+                                                 ctypes.c_void_p(scalars_ptr), m, ctypes.c_void_p(out_ptr)),
+               "vmpc_bn256_table_msm_dev")
 
     def bn256_validate(self, group, points_ptr, n):
         bad = ctypes.c_uint64()

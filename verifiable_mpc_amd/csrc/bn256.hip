@@ -238,6 +238,40 @@ gk_validate(const uint32_t *__restrict__ pts, size_t n, typename F::elem b,
     if (!ok) atomicAdd(bad, 1ull);
 }
 
+// bucket accumulation -> finish -> reduce -> recombination; `entries` = the call's prepared points or
+// a fixed-base table
+template <class C, class F>
+static int bn_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uint32_t *entries, void *out_affine) {
+    hipStream_t st = ctx->stream;
+    {
+        vmpc_stage_scope s(ctx, "bn_bucket");
+        gk_bucket<C><<<(unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
+            entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
+            MSM_SEG << p.seg_shift, w.buckets, w.seg_partial);
+        VMPC_KERNEL_CHECK();
+        gk_finish_light<C, F><<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg,
+                                                                      w.seg_starts, w.seg_partial, p.nb1,
+                                                                      w.buckets);
+        VMPC_KERNEL_CHECK();
+        gk_finish<C, F><<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg, w.seg_starts,
+                                                                w.seg_partial, p.nb1, w.buckets);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "bn_reduce");
+        gk_reduce<C, F><<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, st>>>(
+            w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, msm_ilog2(p.chunk_len), p.red_blocks,
+            w.partials);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "bn_final");
+        gk_final<C, F><<<1, 64, 0, st>>>(w.partials, p.W, p.red_blocks, p.c, (uint32_t *)out_affine);
+        VMPC_KERNEL_CHECK();
+    }
+    return VMPC_OK;
+}
+
 template <class C, class F>
 static int bn_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, size_t n, void *out_affine,
                       const char *tag) {
@@ -262,34 +296,8 @@ static int bn_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, si
         VMPC_KERNEL_CHECK();
     }
     VMPC_CHECK(msm_sort_stage(ctx, p, w, scalars, n, nullptr, BN_ORDER));
-    {
-        vmpc_stage_scope s(ctx, "bn_bucket");
-        gk_bucket<C><<<(unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
-            w.entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
-            MSM_SEG << p.seg_shift, w.buckets, w.seg_partial);
-        VMPC_KERNEL_CHECK();
-        gk_finish_light<C, F><<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg,
-                                                                      w.seg_starts, w.seg_partial, p.nb1,
-                                                                      w.buckets);
-        VMPC_KERNEL_CHECK();
-        gk_finish<C, F><<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg, w.seg_starts,
-                                                                w.seg_partial, p.nb1, w.buckets);
-        VMPC_KERNEL_CHECK();
-    }
-    {
-        vmpc_stage_scope s(ctx, "bn_reduce");
-        gk_reduce<C, F><<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, st>>>(
-            w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, msm_ilog2(p.chunk_len), p.red_blocks,
-            w.partials);
-        VMPC_KERNEL_CHECK();
-    }
-    {
-        vmpc_stage_scope s(ctx, "bn_final");
-        gk_final<C, F><<<1, 64, 0, st>>>(w.partials, p.W, p.red_blocks, p.c, (uint32_t *)out_affine);
-        VMPC_KERNEL_CHECK();
-    }
     (void)tag;
-    return VMPC_OK;
+    return bn_accumulate<C, F>(ctx, p, w, w.entries, out_affine);
 }
 
 extern "C" int vmpc_bn256_g1_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, size_t n,
@@ -300,6 +308,95 @@ extern "C" int vmpc_bn256_g1_msm_dev(vmpc_ctx *ctx, const void *scalars, const v
 extern "C" int vmpc_bn256_g2_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, size_t n,
                                      void *out_affine) {
     return bn_msm_dev<G2, Fp2Ops>(ctx, scalars, points, n, out_affine, "g2");
+}
+
+// ---- fixed-base tables (the evaluation key of a circuit is fixed: pynocchio.py:228-246 reads the
+// same evalkey vectors for every proof) ---------------------------------------------------------------
+// T[w][i] = 2^(16 w) * P_i for w = 0..16 as Montgomery-form affine entries; a later MSM sorts the
+// flattened digit array [w][i] as ONE window whose indices are table positions, so neither the
+// 256-doubling recombination (single lane: 2.6 ms for G1, 6.5 ms for the twist) nor 16/17 of the
+// bucket reduction remain.  Same scheme as the Ed25519 tables in msm.hip.
+#define BN_TABLE_C 16
+#define BN_TABLE_W 17
+
+static size_t bn_table_stride(size_t n) { return (n + 7) & ~(size_t)7; }
+
+template <class C, class F>
+__global__ void __launch_bounds__(MSM_BLOCK)
+gk_table_build(const uint32_t *__restrict__ pts, size_t n, size_t stride, uint32_t *__restrict__ table) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= stride) return;
+    aff<F> a;
+    if (i < n) {
+        a = aff_load<F>(pts + (size_t)C::AFF_WORDS * i);
+    } else {                 // padding columns: never referenced (zero digits); stored as infinity
+        a.inf = true;
+        a.x = F::zero();
+        a.y = F::zero();
+    }
+    C::entry_st(table + (size_t)C::ENTRY_WORDS * i, a);
+    jac<F> q = jac_identity<F>();
+    q = jac_madd<F>(q, a);
+    for (int w = 1; w < BN_TABLE_W; w++) {
+        for (int k = 0; k < BN_TABLE_C; k++) q = jac_dbl<F>(q);
+        C::entry_st(table + (size_t)C::ENTRY_WORDS * ((size_t)w * stride + i), jac_to_affine<F>(q));
+    }
+}
+
+template <class C, class F>
+static int bn_table_build_dev(vmpc_ctx *ctx, const void *points, size_t n, void *table) {
+    if (!ctx || !points || !table || n == 0 || n > ((size_t)1 << 26)) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t stride = bn_table_stride(n);
+    vmpc_stage_scope s(ctx, "bn_table_build");
+    gk_table_build<C, F><<<(unsigned)((stride + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
+        (const uint32_t *)points, n, stride, (uint32_t *)table);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+template <class C, class F>
+static int bn_table_msm_dev(vmpc_ctx *ctx, const void *table, size_t table_n, const void *scalars, size_t m,
+                            void *out_affine) {
+    if (!ctx || !table || !out_affine || table_n == 0 || table_n > ((size_t)1 << 26) || m > table_n ||
+        (m && !scalars))
+        return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t stride = bn_table_stride(table_n);
+    msm_plan p;
+    p.n_main = p.n_total = (size_t)BN_TABLE_W * stride;
+    p.n_extra = 0;
+    p.scalar_bits = 256;
+    p.c = BN_TABLE_C;
+    p.W = 1;
+    msm_plan_geometry(ctx, p);
+    msm_ws w;
+    msm_layout(p, w, nullptr, 0, C::ACC_WORDS * 4);
+    VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
+    msm_layout(p, w, (char *)ctx->ws, 0, C::ACC_WORDS * 4);
+    VMPC_CHECK(msm_recode_rows(ctx, scalars, m, nullptr, 0, 0, stride, w.digits, BN_TABLE_C, BN_TABLE_W, BN_ORDER));
+    VMPC_CHECK(msm_sort_digits(ctx, p, w));
+    return bn_accumulate<C, F>(ctx, p, w, (const uint32_t *)table, out_affine);
+}
+
+extern "C" int vmpc_bn256_table_bytes(int group, size_t n, size_t *bytes) {
+    if (!bytes || (group != 1 && group != 2) || n == 0 || n > ((size_t)1 << 26)) return VMPC_E_INVAL;
+    *bytes = (size_t)BN_TABLE_W * bn_table_stride(n) * (group == 1 ? G1::ENTRY_WORDS : G2::ENTRY_WORDS) * 4;
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_bn256_table_build_dev(vmpc_ctx *ctx, int group, const void *points, size_t n, void *table) {
+    if (group == 1) return bn_table_build_dev<G1, Fp1Ops>(ctx, points, n, table);
+    if (group == 2) return bn_table_build_dev<G2, Fp2Ops>(ctx, points, n, table);
+    return VMPC_E_INVAL;
+}
+
+extern "C" int vmpc_bn256_table_msm_dev(vmpc_ctx *ctx, int group, const void *table, size_t table_n,
+                                        const void *scalars, size_t m, void *out_affine) {
+    if (group == 1) return bn_table_msm_dev<G1, Fp1Ops>(ctx, table, table_n, scalars, m, out_affine);
+    if (group == 2) return bn_table_msm_dev<G2, Fp2Ops>(ctx, table, table_n, scalars, m, out_affine);
+    return VMPC_E_INVAL;
 }
 
 extern "C" int vmpc_bn256_validate_dev(vmpc_ctx *ctx, int group, const void *points, size_t n,

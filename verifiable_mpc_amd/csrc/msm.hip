@@ -819,6 +819,17 @@ int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scal
     return msm_sort_digits(ctx, p, w);
 }
 
+int msm_recode_rows(vmpc_ctx *ctx, const void *scalars, size_t n_main, const void *extra_scalars,
+                    size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *digits, int c, int W,
+                    const msm_modulus &modulus) {
+    vmpc_stage_scope s(ctx, "msm_recode");
+    k_msm_recode<<<(unsigned)((n_pad + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
+        (const uint32_t *)scalars, n_main, (const uint32_t *)extra_scalars, extra_pos, n_extra, n_pad, digits, c,
+        W, modulus, ctx->d_status);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
 // hist -> counts/scan -> scatter -> plan over digits already in w.digits
 int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
     hipStream_t st = ctx->stream;

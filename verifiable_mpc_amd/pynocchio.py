@@ -105,8 +105,86 @@ def msm(scalars, points, ctx=None):
     return cls.from_bytes(ctx.download(out.ptr, width).tobytes())
 
 
+# the eight proof elements of pynocchio.py:228-273: name -> (evalkey name of term i, zero-knowledge terms
+# as (delta attribute, evalkey name))
+_ELEMENTS = {
+    "r_v*v_mid*g1": (lambda i: "r_v*v" + str(i) + "*g1", (("v", "r_v*t*g1"),)),
+    "r_w*w_mid*g2": (lambda i: "r_w*w" + str(i) + "*g2", (("w", "r_w*t*g2"),)),
+    "r_y*y_mid*g1": (lambda i: "r_y*y" + str(i) + "*g1", (("y", "r_y*t*g1"),)),
+    "r_v*alpha_v*v_mid*g1": (lambda i: f"r_v*alpha_v*v{i}*g1", (("v", "r_v*alpha_v*t*g1"),)),
+    "r_w*alpha_w*w_mid*g1": (lambda i: f"r_w*alpha_w*w{i}*g1", (("w", "r_w*alpha_w*t*g1"),)),
+    "r_y*alpha_y*y_mid*g1": (lambda i: f"r_y*alpha_y*y{i}*g1", (("y", "r_y*alpha_y*t*g1"),)),
+    "r_v*beta*v_mid+r_w*beta*w_mid+r_y*beta*y_mid*g1": (
+        lambda i: f"r_v*beta*v+r_w*beta*w+r_y*beta*y{i}_g1",
+        (("v", "r_v*beta*t*g1"), ("w", "r_w*beta*t*g1"), ("y", "r_y*beta*t*g1"))),
+}
+
+
+class _KeyVector:
+    """One evaluation-key vector on the device: points uploaded, validated and tabulated once."""
+
+    def __init__(self, ctx, points):
+        enc = [_as_bytes(p) for p in points]
+        self.group = enc[0][0]
+        assert all(g == self.group for g, _ in enc), "mixed groups in one key vector"
+        self.width = 64 if self.group == 1 else 128
+        self.n = len(points)
+        pts = np.frombuffer(b"".join(b for _, b in enc), dtype=np.uint8).reshape(-1, self.width)
+        dp = ctx.upload(pts)
+        if ctx.bn256_validate(self.group, dp.ptr, self.n):
+            raise _native.VmpcError(_native.E_NOTONCURVE, "pynocchio.PreparedKey")
+        self.table = ctx.bn256_table_build(self.group, dp.ptr, self.n)
+        ctx.sync()
+
+    def msm(self, ctx, scalars):
+        m = len(scalars)
+        assert m <= self.n
+        ds, out = ctx.upload(_native.ints_to_array([int(s) % ORDER for s in scalars], 32)), ctx.alloc(self.width)
+        ctx.bn256_table_msm(self.group, self.table.ptr, self.n, ds.ptr, m, out.ptr)
+        ctx.sync()
+        cls = BN256Point if self.group == 1 else BN256TwistPoint
+        return cls.from_bytes(ctx.download(out.ptr, self.width).tobytes())
+
+
+class PreparedKey:
+    """The evaluation key of one circuit, prepared for many proofs: the eight point vectors that
+    compute_proof reads (pynocchio.py:228-246) are converted, uploaded, checked and expanded into
+    fixed-base tables ONCE; each proof then only ships its scalars.  Pass it to compute_proof in place
+    of the evalkey dict."""
+
+    def __init__(self, qap, evalkey, ctx=None):
+        self.ctx = ctx or get_context()
+        self.mid = list(qap.indices_mid)
+        self.vectors = {}
+        for name, (key_fmt, zk) in _ELEMENTS.items():
+            points = [evalkey[key_fmt(i)] for i in self.mid]
+            self.zk_ok = all(zname in evalkey for _, zname in zk)
+            if self.zk_ok:
+                points += [evalkey[zname] for _, zname in zk]
+            self.vectors[name] = _KeyVector(self.ctx, points)
+        powers = []
+        while "s^" + str(len(powers)) + "*g1" in evalkey:
+            powers.append(evalkey["s^" + str(len(powers)) + "*g1"])
+        self.vectors["h*g1"] = _KeyVector(self.ctx, powers)
+
+
+def _compute_proof_prepared(key, c, h, deltas):
+    cm = [int(c[i]) for i in key.mid]
+    proof = {}
+    for name, (_, zk) in _ELEMENTS.items():
+        scalars = list(cm)
+        if deltas is not None:
+            scalars += [int(getattr(deltas, attr)) for attr, _ in zk]
+        proof[name] = key.vectors[name].msm(key.ctx, scalars)
+    proof["h*g1"] = key.vectors["h*g1"].msm(key.ctx, [int(h.coeffs[i]) for i in range(0, len(h))])
+    return proof
+
+
 def compute_proof(qap, c, h, evalkey, deltas=None):
-    """Pinocchio proof elements (pynocchio.py:228-273), one MSM per element."""
+    """Pinocchio proof elements (pynocchio.py:228-273), one MSM per element.  `evalkey` is the
+    reference's dict of points, or a PreparedKey made from it (device-resident, tabulated)."""
+    if isinstance(evalkey, PreparedKey):
+        return _compute_proof_prepared(evalkey, c, h, deltas)
     mid = list(qap.indices_mid)
     cm = [int(c[i]) for i in mid]
 
