@@ -111,16 +111,17 @@ int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affine_points, 
 
 /* Fixed-base tables for a generator vector that serves many commitments: the CRS of
  * pivot.py:139-145 (g, h, k are fixed between proofs: circuit_sat_r1cs.py:47-93 creates them once).
- * The table holds 2^(16 w) * P_i, w = 0..15, for the n points followed by the n_extra extra points
- * (16 * 128 bytes per point, rows padded to a multiple of 8 points: vmpc_msm_table_bytes).  A commitment over
- * a table is one bucket pass with no window recombination; its result equals vmpc_msm_dev's on the
- * same points and scalars (as a group element; compared after normalisation). */
-int vmpc_msm_table_bytes(size_t n, size_t n_extra, size_t *bytes);
+ * The table holds rows 2^(256 rho / rows) * P_i, rho = 0..rows-1, rows in {1, 2, 4, 8, 16}, for the n
+ * points followed by the n_extra extra points (rows * 128 bytes per point, rows padded to a multiple
+ * of 8 points: vmpc_msm_table_bytes).  A commitment over a table needs no point preparation and only
+ * (16/rows - 1) * 16 doublings of window recombination (none for rows = 16); its result equals
+ * vmpc_msm_dev's on the same points and scalars (as a group element; compared after normalisation). */
+int vmpc_msm_table_bytes(size_t n, size_t n_extra, int rows, size_t *bytes);
 int vmpc_msm_table_build_dev(vmpc_ctx *ctx, const void *affine_points, size_t n,
-                             const void *extra_affine_points, size_t n_extra, void *table);
+                             const void *extra_affine_points, size_t n_extra, int rows, void *table);
 /* out = sum_{i<m} scalars[i] * P_i + sum_{e<table_extra} extra_scalars[e] * E_e over the table built
  * from (P_0..P_{table_n-1}, E_0..E_{table_extra-1}); m <= table_n; extra_scalars may be NULL (zeros). */
-int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra,
+int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
                        const void *scalars, size_t m, const void *extra_scalars, void *out_ext,
                        void *out_affine);
 

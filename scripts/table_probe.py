@@ -30,36 +30,38 @@ def main():
         dpts = ctx.alloc(64 * (n + n_extra))
         ctx.repeat(dbase.ptr, 1, True, dexp.ptr, n + n_extra, False, None, dpts.ptr)
         ctx.sync()
-        t0 = time.time()
-        table = ctx.msm_table_build(dpts.ptr, n, dpts.ptr + 64 * n, n_extra)
-        ctx.sync()
-        t_build = time.time() - t0
-        out_v, out_t = ctx.alloc(64), ctx.alloc(64)
-        for m in (n, n // 2 + 1, 1, 0):
-            ctx.msm(dsc.ptr, dpts.ptr, m, dsc.ptr + 32 * n, dpts.ptr + 64 * n, n_extra, None, out_v.ptr)
-            ctx.msm_table(table.ptr, n, n_extra, dsc.ptr, m, dsc.ptr + 32 * n, None, out_t.ptr)
-            ctx.sync()
-            same = ctx.download(out_v.ptr, 64).tobytes() == ctx.download(out_t.ptr, 64).tobytes()
-            print(f"n=2^{lg}-1 m={m}: table == variable-base: {same}")
-        ctx.msm_table(table.ptr, n, n_extra, dsc.ptr, n, None, None, out_t.ptr)
-        ctx.msm(dsc.ptr, dpts.ptr, n, None, None, 0, None, out_v.ptr)
-        ctx.sync()
-        print("  no extras:", ctx.download(out_v.ptr, 64).tobytes() == ctx.download(out_t.ptr, 64).tobytes())
-        reps = 5
-        for name, fn in (("variable", lambda: ctx.msm(dsc.ptr, dpts.ptr, n, dsc.ptr + 32 * n, dpts.ptr + 64 * n, n_extra, None, out_v.ptr)),
-                         ("table", lambda: ctx.msm_table(table.ptr, n, n_extra, dsc.ptr, n, dsc.ptr + 32 * n, None, out_t.ptr))):
-            fn(); ctx.sync()
+        for rows in [int(r) for r in os.environ.get("ROWS", "16").split(",")]:
             t0 = time.time()
-            for _ in range(reps):
-                fn()
+            table = ctx.msm_table_build(dpts.ptr, n, dpts.ptr + 64 * n, n_extra, rows)
             ctx.sync()
-            dt = (time.time() - t0) / reps
-            ctx.profile(True); ctx.profile_read(reset=True)
-            fn(); ctx.sync()
-            prof = ctx.profile_read(reset=True); ctx.profile(False)
-            st = " ".join(f"{k[4:]}={ms*1e3:.0f}" for k, (ms, cnt) in prof.items())
-            print(f"  {name:9s} {dt*1e3:7.3f} ms  {st}")
-        print(f"  table build {t_build*1e3:.1f} ms, {table.nbytes/2**20:.0f} MiB")
+            t_build = time.time() - t0
+            out_v, out_t = ctx.alloc(64), ctx.alloc(64)
+            print(f"rows={rows}")
+            for m in (n, n // 2 + 1, 1, 0):
+                ctx.msm(dsc.ptr, dpts.ptr, m, dsc.ptr + 32 * n, dpts.ptr + 64 * n, n_extra, None, out_v.ptr)
+                ctx.msm_table(table.ptr, n, n_extra, dsc.ptr, m, dsc.ptr + 32 * n, None, out_t.ptr, rows)
+                ctx.sync()
+                same = ctx.download(out_v.ptr, 64).tobytes() == ctx.download(out_t.ptr, 64).tobytes()
+                print(f"n=2^{lg}-1 m={m}: table == variable-base: {same}")
+            ctx.msm_table(table.ptr, n, n_extra, dsc.ptr, n, None, None, out_t.ptr, rows)
+            ctx.msm(dsc.ptr, dpts.ptr, n, None, None, 0, None, out_v.ptr)
+            ctx.sync()
+            print("  no extras:", ctx.download(out_v.ptr, 64).tobytes() == ctx.download(out_t.ptr, 64).tobytes())
+            reps = 5
+            for name, fn in (("variable", lambda: ctx.msm(dsc.ptr, dpts.ptr, n, dsc.ptr + 32 * n, dpts.ptr + 64 * n, n_extra, None, out_v.ptr)),
+                             ("table", lambda: ctx.msm_table(table.ptr, n, n_extra, dsc.ptr, n, dsc.ptr + 32 * n, None, out_t.ptr, rows))):
+                fn(); ctx.sync()
+                t0 = time.time()
+                for _ in range(reps):
+                    fn()
+                ctx.sync()
+                dt = (time.time() - t0) / reps
+                ctx.profile(True); ctx.profile_read(reset=True)
+                fn(); ctx.sync()
+                prof = ctx.profile_read(reset=True); ctx.profile(False)
+                st = " ".join(f"{k[4:]}={ms*1e3:.0f}" for k, (ms, cnt) in prof.items())
+                print(f"  {name:9s} {dt*1e3:7.3f} ms  {st}")
+            print(f"  table build {t_build*1e3:.1f} ms, {table.nbytes/2**20:.0f} MiB")
 
 
 if __name__ == "__main__":

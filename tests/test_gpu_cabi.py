@@ -186,8 +186,8 @@ def test_msm_edge_cases(nat, ctx):
     ctx.sync()  # status word was cleared
 
 
-@pytest.mark.parametrize("n,n_extra", [(1, 0), (5, 1), (64, 2), (301, 2)])
-def test_fixed_base_table_matches_oracle(nat, ctx, n, n_extra):
+@pytest.mark.parametrize("n,n_extra,rows", [(1, 0, 16), (5, 1, 1), (64, 2, 2), (301, 2, 16), (301, 2, 4), (70, 1, 8)])
+def test_fixed_base_table_matches_oracle(nat, ctx, n, n_extra, rows):
     """vmpc_msm_table_dev over (g, extras) == pivot.vector_commitment restated, for the whole
     vector, a prefix, the empty prefix, and with / without the extra (h ** gamma) terms."""
     rng = random.Random(700 + n)
@@ -200,7 +200,7 @@ def test_fixed_base_table_matches_oracle(nat, ctx, n, n_extra):
     gam = [rng.randrange(ELL) for _ in range(n_extra)]
     dp = ctx.upload(aff_bytes(g))
     de = ctx.upload(aff_bytes(extras)) if n_extra else None
-    table = ctx.msm_table_build(dp.ptr, n, de.ptr if de else None, n_extra)
+    table = ctx.msm_table_build(dp.ptr, n, de.ptr if de else None, n_extra, rows)
     ds = ctx.upload(sc_bytes(nat, x))
     dg = ctx.upload(sc_bytes(nat, gam)) if n_extra else None
     out, out_ext = ctx.alloc(64), ctx.alloc(128)
@@ -212,7 +212,7 @@ def test_fixed_base_table_matches_oracle(nat, ctx, n, n_extra):
             if use_extra:
                 for si, ei in zip(gam, extras):
                     acc = ed.pt_add(acc, ed.pt_repeat(ei, si))
-            ctx.msm_table(table.ptr, n, n_extra, ds.ptr, m, dg.ptr if use_extra else None, out_ext.ptr, out.ptr)
+            ctx.msm_table(table.ptr, n, n_extra, ds.ptr, m, dg.ptr if use_extra else None, out_ext.ptr, out.ptr, rows)
             ctx.sync()
             assert dl_aff(ctx, out.ptr)[0][:2] == ed.pt_affine(acc), (m, use_extra)
             raw = ctx.download(out_ext.ptr, 128).tobytes()
@@ -221,7 +221,7 @@ def test_fixed_base_table_matches_oracle(nat, ctx, n, n_extra):
     # a non-canonical scalar is reported at the sync point, as for vmpc_msm_dev
     bad = np.frombuffer(ELL.to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32)
     dsb = ctx.upload(bad)
-    ctx.msm_table(table.ptr, n, n_extra, dsb.ptr, 1, None, None, out.ptr)
+    ctx.msm_table(table.ptr, n, n_extra, dsb.ptr, 1, None, None, out.ptr, rows)
     with pytest.raises(nat.VmpcError) as ei:
         ctx.sync()
     assert ei.value.code == nat.E_NONCANON
@@ -235,14 +235,15 @@ def test_fixed_base_table_skewed_scalars(nat, ctx):
     n = 5000
     exps = [rng.randrange(1, ELL) for _ in range(n)]
     pts = gpu_points(nat, ctx, exps)
-    table = ctx.msm_table_build(pts.ptr, n, None, 0)
     out = ctx.alloc(64)
-    for x in ([1] * n, [(1 << 16) + 1] * n, [ELL - 1] * n, [i % 3 for i in range(n)]):
-        ds = ctx.upload(sc_bytes(nat, x))
-        ctx.msm_table(table.ptr, n, 0, ds.ptr, n, None, None, out.ptr)
-        ctx.sync()
-        want = ed.pt_affine(ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(x, exps)) % ELL))
-        assert dl_aff(ctx, out.ptr)[0][:2] == want
+    for rows in (16, 2):
+        table = ctx.msm_table_build(pts.ptr, n, None, 0, rows)
+        for x in ([1] * n, [(1 << 16) + 1] * n, [ELL - 1] * n, [i % 3 for i in range(n)]):
+            ds = ctx.upload(sc_bytes(nat, x))
+            ctx.msm_table(table.ptr, n, 0, ds.ptr, n, None, None, out.ptr, rows)
+            ctx.sync()
+            want = ed.pt_affine(ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(x, exps)) % ELL))
+            assert dl_aff(ctx, out.ptr)[0][:2] == want, rows
 
 
 def test_repeat_replays_reference_sequence(nat, ctx):

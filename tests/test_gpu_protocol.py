@@ -233,10 +233,10 @@ def test_precomputed_generators_give_identical_proofs(vm):
     gamma, rho = rng.randrange(1, ELL), rng.randrange(ELL)
     r = [rng.randrange(ELL) for _ in range(n)]
     results = []
-    for pre in (False, True):
+    for pre in (False, 16, 2, 1):
         g = vm.PointVector.fixed_base(h, exps, keep_proj=True)
         if pre:
-            g.precompute([h, k])
+            g.precompute([h, k], rows=pre)
             assert g[:10]._table is g._table and g[1:]._table is None
         gens = {"g": g, "h": h, "k": k}
         xs, Lf = vm.ScalarVector.from_ints(x), vm.pivot.LinearForm(vm.ScalarVector.from_ints(coeffs))
@@ -252,7 +252,7 @@ def test_precomputed_generators_give_identical_proofs(vm):
                                   [int(e) for e in v] if isinstance(v, list) else int(v))
                             for key, v in proof.items()}
         results.append((tuple(P.normalize().coords), tuple(Pk.normalize().coords), proofs))
-    assert results[0] == results[1]
+    assert results[0] == results[1] == results[2] == results[3]
 
 
 def test_basic_pivot_fixture(vm, golden_small, monkeypatch, record_hashes):

@@ -85,9 +85,9 @@ def load_library():
         "vmpc_fr_dot": (i32, [vp, vp, sz, vp]),
         "vmpc_points_validate_dev": (i32, [vp, vp, sz, u64p]),
         "vmpc_msm_dev": (i32, [vp, vp, vp, sz, vp, vp, sz, vp, vp]),
-        "vmpc_msm_table_bytes": (i32, [sz, sz, vp]),
-        "vmpc_msm_table_build_dev": (i32, [vp, vp, sz, vp, sz, vp]),
-        "vmpc_msm_table_dev": (i32, [vp, vp, sz, sz, vp, sz, vp, vp, vp]),
+        "vmpc_msm_table_bytes": (i32, [sz, sz, i32, vp]),
+        "vmpc_msm_table_build_dev": (i32, [vp, vp, sz, vp, sz, i32, vp]),
+        "vmpc_msm_table_dev": (i32, [vp, vp, sz, sz, i32, vp, sz, vp, vp, vp]),
         "vmpc_points_sum_dev": (i32, [vp, vp, sz, vp, vp]),
         "vmpc_repeat_dev": (i32, [vp, vp, sz, i32, vp, sz, i32, vp, vp]),
         "vmpc_fold_dev": (i32, [vp, vp, vp, i32, vp, sz, vp, vp]),
@@ -417,19 +417,19 @@ class Context:
                                      ctypes.c_void_p(out_ext_ptr), ctypes.c_void_p(out_affine_ptr)),
                "vmpc_msm_dev")
 
-    def msm_table_build(self, points_ptr, n, extra_points_ptr=None, n_extra=0):
-        """Fixed-base table (DeviceBuffer) over n points followed by n_extra extra points."""
+    def msm_table_build(self, points_ptr, n, extra_points_ptr=None, n_extra=0, rows=16):
+        """Fixed-base table (DeviceBuffer) of `rows` rows over n points followed by n_extra extras."""
         nbytes = ctypes.c_size_t(0)
-        _check(self.lib.vmpc_msm_table_bytes(n, n_extra, ctypes.byref(nbytes)), "vmpc_msm_table_bytes")
+        _check(self.lib.vmpc_msm_table_bytes(n, n_extra, rows, ctypes.byref(nbytes)), "vmpc_msm_table_bytes")
         table = self.alloc(nbytes.value)
         _check(self.lib.vmpc_msm_table_build_dev(self.handle, ctypes.c_void_p(points_ptr), n,
-                                                 ctypes.c_void_p(extra_points_ptr), n_extra,
+                                                 ctypes.c_void_p(extra_points_ptr), n_extra, rows,
                                                  ctypes.c_void_p(table.ptr)), "vmpc_msm_table_build_dev")
         return table
 
     def msm_table(self, table_ptr, table_n, table_extra, scalars_ptr, m, extra_scalars_ptr=None,
-                  out_ext_ptr=None, out_affine_ptr=None):
-        _check(self.lib.vmpc_msm_table_dev(self.handle, ctypes.c_void_p(table_ptr), table_n, table_extra,
+                  out_ext_ptr=None, out_affine_ptr=None, rows=16):
+        _check(self.lib.vmpc_msm_table_dev(self.handle, ctypes.c_void_p(table_ptr), table_n, table_extra, rows,
                                            ctypes.c_void_p(scalars_ptr), m,
                                            ctypes.c_void_p(extra_scalars_ptr),
                                            ctypes.c_void_p(out_ext_ptr), ctypes.c_void_p(out_affine_ptr)),

@@ -32,8 +32,8 @@ def _our_point(obj):
     return Ed25519Point((int(obj[0]), int(obj[1]), int(obj[2])))
 
 
-# Generators are a CRS: up to this many get a fixed-base table at creation (2 KiB each: 2 GiB of the
-# 288 GB for 2^20).  Besides shortening every commitment over g, the table lets the compact-transcript
+# Generators are a CRS: up to this many get a fixed-base table at creation (at most 2 KiB each, capped
+# at 256 MiB per table).  Besides shortening every commitment over g, the table lets the compact-transcript
 # prover skip the generator folds altogether (compressed_pivot._tabulated).
 PRECOMPUTE_MAX = 1 << 20
 

@@ -375,7 +375,8 @@ static int bn_table_msm_dev(vmpc_ctx *ctx, const void *table, size_t table_n, co
     msm_layout(p, w, nullptr, 0, C::ACC_WORDS * 4);
     VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
     msm_layout(p, w, (char *)ctx->ws, 0, C::ACC_WORDS * 4);
-    VMPC_CHECK(msm_recode_rows(ctx, scalars, m, nullptr, 0, 0, stride, w.digits, BN_TABLE_C, BN_TABLE_W, BN_ORDER));
+    VMPC_CHECK(msm_recode_rows(ctx, scalars, m, nullptr, 0, 0, stride, w.digits, BN_TABLE_C, BN_TABLE_W, BN_TABLE_W,
+                               BN_ORDER));
     VMPC_CHECK(msm_sort_digits(ctx, p, w));
     return bn_accumulate<C, F>(ctx, p, w, (const uint32_t *)table, out_affine);
 }

@@ -162,14 +162,17 @@ k_msm_prep(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__re
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__restrict__ sc_extra,
              size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *__restrict__ digits, int c, int W,
-             msm_modulus mod, uint32_t *__restrict__ status) {
+             int wpr, size_t set_stride, msm_modulus mod, uint32_t *__restrict__ status) {
+    // digit w of term i goes to digits[(w % wpr) * set_stride + (w / wpr) * n_pad + i]: plain MSMs have
+    // wpr = W and set_stride = n_pad (row w = window w); fixed-base tables of r rows have wpr = W / r
+    // bucket sets, each a row of r * n_pad entries whose index is the table position (w / wpr, i)
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
     const uint32_t *src = nullptr;
     if (i < n_main) src = sc + 8 * i;
     else if (sc_extra && i >= extra_pos && i < extra_pos + n_extra) src = sc_extra + 8 * (i - extra_pos);
     if (!src) {                              // the sort kernels read whole 16-byte vectors of a row
-        for (int w = 0; w < W; w++) digits[(size_t)w * n_pad + i] = 0;
+        for (int w = 0; w < W; w++) digits[(size_t)(w % wpr) * set_stride + (size_t)(w / wpr) * n_pad + i] = 0;
         return;
     }
     uint32_t s[8];
@@ -198,7 +201,7 @@ k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__r
             d = (int32_t)raw;
             carry = 0;
         }
-        digits[(size_t)w * n_pad + i] = (int16_t)d;
+        digits[(size_t)(w % wpr) * set_stride + (size_t)(w / wpr) * n_pad + i] = (int16_t)d;
         // s >>= c  (c < 32; static limb indices keep s[] in registers)
 #pragma unroll
         for (int k = 0; k < 7; k++) s[k] = (s[k] >> c) | (s[k + 1] << (32 - c));
@@ -813,19 +816,20 @@ int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scal
         vmpc_stage_scope s(ctx, "msm_recode");
         k_msm_recode<<<gb, MSM_BLOCK, 0, st>>>((const uint32_t *)scalars, n,
                                               (const uint32_t *)extra_scalars, n, n_total - n, p.n_pad, w.digits, p.c,
-                                              p.W, modulus, ctx->d_status);
+                                              p.W, p.W, p.n_pad, modulus, ctx->d_status);
         VMPC_KERNEL_CHECK();
     }
     return msm_sort_digits(ctx, p, w);
 }
 
 int msm_recode_rows(vmpc_ctx *ctx, const void *scalars, size_t n_main, const void *extra_scalars,
-                    size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *digits, int c, int W,
+                    size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *digits, int c, int W, int rows,
                     const msm_modulus &modulus) {
     vmpc_stage_scope s(ctx, "msm_recode");
+    const int wpr = W / rows;
     k_msm_recode<<<(unsigned)((n_pad + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
         (const uint32_t *)scalars, n_main, (const uint32_t *)extra_scalars, extra_pos, n_extra, n_pad, digits, c,
-        W, modulus, ctx->d_status);
+        W, wpr, (size_t)rows * n_pad, modulus, ctx->d_status);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }
@@ -957,27 +961,32 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
 
 // ---- fixed-base tables -----------------------------------------------------------------------
 // A generator vector that serves many commitments (the CRS of pivot.py:139-145: g, h, k never
-// change between proofs) is expanded once into  T[w][i] = 2^(16 w) * P_i,  w = 0..15, in niels form.
-// Term (i, window w) of any later MSM then adds T[w][i] into bucket |digit| of ONE shared bucket
-// set: the flattened digit array [w][i] is sorted as a single window of 16*stride entries whose
-// indices ARE table positions.  No window recombination remains (the 240-doubling Horner chain
-// and 15/16 of the bucket reduction disappear), and no per-call point preparation.
+// change between proofs) is expanded once into r rows  T[rho][i] = 2^(256 rho / r) * P_i  in niels
+// form, r in {1, 2, 4, 8, 16}.  The 16 digits of a scalar then fall into 16 / r bucket SETS: digit w
+// adds T[w / (16/r)][i] into bucket |digit| of set w % (16/r), and each set's flattened digit row
+// [rho][i] is sorted as one window whose indices ARE table positions.  What remains of the window
+// recombination is a Horner chain over the 16 / r sets: (16/r - 1) * 16 doublings instead of 240,
+// none at all for r = 16; the bucket reduction shrinks by the same factor and no per-call point
+// preparation is left.  r trades table size (r * 128 bytes per generator) against that chain: the
+// bucket stage gathers table entries at random, so the table should stay Infinity-Cache resident
+// (256 MiB) - PointVector.precompute picks r accordingly.
 #define MSM_TABLE_C 16
 #define MSM_TABLE_W 16
 
 static size_t msm_table_stride(size_t n_points) { return (n_points + 7) & ~(size_t)7; }
+static bool msm_table_rows_ok(int rows) { return rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16; }
 
 __global__ void __launch_bounds__(MSM_BLOCK, 2)
 k_msm_table_build(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__restrict__ aff_extra,
-                  size_t n_total, size_t stride, uint32_t *__restrict__ table) {
+                  size_t n_total, size_t stride, int rows, uint32_t *__restrict__ table) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= stride) return;
-    if (i >= n_total) {     // padding rows are never referenced (their digits are zero); keep them defined
+    if (i >= n_total) {     // padding columns are never referenced (their digits are zero); keep them defined
         ge_niels z;
         z.ymx = fe_one();
         z.ypx = fe_one();
         z.t2d = fe_zero();
-        for (int w = 0; w < MSM_TABLE_W; w++) niels_st_line(table + NIELS_WORDS * ((size_t)w * stride + i), z);
+        for (int r = 0; r < rows; r++) niels_st_line(table + NIELS_WORDS * ((size_t)r * stride + i), z);
         return;
     }
     const uint32_t *src = (i < n_main) ? aff + 16 * i : aff_extra + 16 * (i - n_main);
@@ -986,62 +995,57 @@ k_msm_table_build(const uint32_t *__restrict__ aff, size_t n_main, const uint32_
     a.y = fe_ld8(src + 8);
     niels_st_line(table + NIELS_WORDS * i, ge_niels_from_affine(a));
     ge_ext q = ge_ext_from_affine(a);
-    for (int w = 1; w < MSM_TABLE_W; w++) {
-        for (int k = 0; k < MSM_TABLE_C; k++) q = ge_dbl(q);
+    const int dbl_per_row = MSM_TABLE_C * (MSM_TABLE_W / rows);
+    for (int r = 1; r < rows; r++) {
+        for (int k = 0; k < dbl_per_row; k++) q = ge_dbl(q);
         ge_aff b = ge_ext_to_affine(q);
-        niels_st_line(table + NIELS_WORDS * ((size_t)w * stride + i), ge_niels_from_affine(b));
+        niels_st_line(table + NIELS_WORDS * ((size_t)r * stride + i), ge_niels_from_affine(b));
     }
 }
 
-extern "C" int vmpc_msm_table_bytes(size_t n, size_t n_extra, size_t *bytes) {
-    if (!bytes || n + n_extra == 0 || n + n_extra > ((size_t)1 << 26)) return VMPC_E_INVAL;
-    *bytes = (size_t)MSM_TABLE_W * msm_table_stride(n + n_extra) * NIELS_WORDS * 4;
+extern "C" int vmpc_msm_table_bytes(size_t n, size_t n_extra, int rows, size_t *bytes) {
+    if (!bytes || n + n_extra == 0 || n + n_extra > ((size_t)1 << 26) || !msm_table_rows_ok(rows)) return VMPC_E_INVAL;
+    *bytes = (size_t)rows * msm_table_stride(n + n_extra) * NIELS_WORDS * 4;
     return VMPC_OK;
 }
 
 extern "C" int vmpc_msm_table_build_dev(vmpc_ctx *ctx, const void *affine_points, size_t n,
-                                        const void *extra_affine_points, size_t n_extra, void *table) {
+                                        const void *extra_affine_points, size_t n_extra, int rows, void *table) {
     if (!ctx || !table || (n && !affine_points) || (n_extra && !extra_affine_points) || n + n_extra == 0 ||
-        n + n_extra > ((size_t)1 << 26))
+        n + n_extra > ((size_t)1 << 26) || !msm_table_rows_ok(rows))
         return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t stride = msm_table_stride(n + n_extra);
     vmpc_stage_scope s(ctx, "msm_table_build");
     k_msm_table_build<<<(unsigned)((stride + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
-        (const uint32_t *)affine_points, n, (const uint32_t *)extra_affine_points, n + n_extra, stride,
+        (const uint32_t *)affine_points, n, (const uint32_t *)extra_affine_points, n + n_extra, stride, rows,
         (uint32_t *)table);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }
 
-extern "C" int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra,
+extern "C" int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
                                   const void *scalars, size_t m, const void *extra_scalars, void *out_ext,
                                   void *out_affine) {
     if (!ctx || !table || m > table_n || (m && !scalars) || table_n + table_extra == 0 ||
-        table_n + table_extra > ((size_t)1 << 26) || (!out_ext && !out_affine))
+        table_n + table_extra > ((size_t)1 << 26) || !msm_table_rows_ok(rows) || (!out_ext && !out_affine))
         return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
     const size_t stride = msm_table_stride(table_n + table_extra);
-    // the whole digit array is ONE window of 16 * stride entries
+    // each of the 16 / rows bucket sets is one window of rows * stride entries
     msm_plan p;
-    p.n_main = p.n_total = (size_t)MSM_TABLE_W * stride;
+    p.n_main = p.n_total = (size_t)rows * stride;
     p.n_extra = 0;
     p.scalar_bits = 253;
     p.c = MSM_TABLE_C;
-    p.W = 1;
+    p.W = MSM_TABLE_W / rows;
     msm_plan_geometry(ctx, p);
     msm_ws w;
     msm_layout(p, w, nullptr, 0, EXT_WORDS * 4);
     VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
     msm_layout(p, w, (char *)ctx->ws, 0, EXT_WORDS * 4);
-    {
-        vmpc_stage_scope s(ctx, "msm_recode");
-        k_msm_recode<<<(unsigned)((stride + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
-            (const uint32_t *)scalars, m, (const uint32_t *)extra_scalars, table_n, table_extra, stride, w.digits,
-            MSM_TABLE_C, MSM_TABLE_W, ED25519_L, ctx->d_status);
-        VMPC_KERNEL_CHECK();
-    }
+    VMPC_CHECK(msm_recode_rows(ctx, scalars, m, extra_scalars, table_n, table_extra, stride, w.digits, MSM_TABLE_C,
+                               MSM_TABLE_W, rows, ED25519_L));
     VMPC_CHECK(msm_sort_digits(ctx, p, w));
     return msm_accumulate(ctx, p, w, (const uint32_t *)table, out_ext, out_affine);
 }

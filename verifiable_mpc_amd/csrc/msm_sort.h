@@ -58,10 +58,11 @@ void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, si
 int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scalars, size_t n,
                    const void *extra_scalars, const msm_modulus &modulus);
 int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w);   // the same minus the recoding
-// signed c-bit digits of (main || extra) scalars into rows of stride n_pad (msm.hip); `digits` row w
-// holds window w; positions outside [0, n_main) and [extra_pos, extra_pos + n_extra) are zeroed
+// signed c-bit digits of (main || extra) scalars for a fixed-base table of `rows` rows (msm.hip): digit
+// w of term i goes to digits[(w % (W/rows)) * rows * n_pad + (w / (W/rows)) * n_pad + i]; positions
+// outside [0, n_main) and [extra_pos, extra_pos + n_extra) are zeroed
 int msm_recode_rows(vmpc_ctx *ctx, const void *scalars, size_t n_main, const void *extra_scalars,
-                    size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *digits, int c, int W,
+                    size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *digits, int c, int W, int rows,
                     const msm_modulus &modulus);
 
 static inline int msm_ilog2(int v) {

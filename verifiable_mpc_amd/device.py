@@ -172,11 +172,14 @@ class ScalarVector:
         return "[" + body[:-2] + "]"
 
 
+TABLE_BUDGET_BYTES = 256 << 20      # MI355X Infinity Cache
+
+
 class FixedBaseTable:
     """Device table 2^(16 w) * P_i over a generator vector followed by a few extra base points."""
 
-    def __init__(self, buf, n, extra_bytes):
-        self.buf, self.n, self.extra_bytes = buf, n, extra_bytes
+    def __init__(self, buf, n, extra_bytes, rows):
+        self.buf, self.n, self.extra_bytes, self.rows = buf, n, extra_bytes, rows
 
     @property
     def ptr(self):
@@ -318,17 +321,25 @@ class PointVector:
         return NotImplemented
 
     # ---- kernels -------------------------------------------------------------------------------
-    def precompute(self, extras=()):
+    def precompute(self, extras=(), rows=None):
         """Build the fixed-base table (include/vmpc.h: vmpc_msm_table_build_dev) for this vector and
         the `extras` (the commitment bases h, k of the CRS).  Commitments over this vector or a
-        prefix of it, with one of `extras` as base point, then run as a single bucket pass with no
-        window recombination (2x shorter below ~2^17 generators; 2 KiB of HBM per generator)."""
+        prefix of it, with one of `extras` as base point, then need no point preparation and only
+        (16/rows - 1) * 16 doublings of window recombination.  `rows` in {1, 2, 4, 8, 16} (128 bytes
+        of HBM per generator and row); by default the largest that keeps the table within the
+        256-MiB Infinity Cache, where the bucket stage's random gathers still run at cache speed."""
         extras = list(extras)
+        if rows is None and os.environ.get("VMPC_TABLE_ROWS"):
+            rows = int(os.environ["VMPC_TABLE_ROWS"])          # tuning knob
+        if rows is None:
+            rows = 16
+            while rows > 1 and rows * 128 * (len(self) + len(extras)) > TABLE_BUDGET_BYTES:
+                rows //= 2
         raw = b"".join(p.to_affine_bytes() for p in extras)
         eb = self.ctx.upload(np.frombuffer(raw, np.uint8)) if extras else None
-        buf = self.ctx.msm_table_build(self.a.ptr, len(self), eb.ptr if eb else None, len(extras))
+        buf = self.ctx.msm_table_build(self.a.ptr, len(self), eb.ptr if eb else None, len(extras), rows)
         self.ctx.sync()
-        self._table = FixedBaseTable(buf, len(self), [raw[64 * i:64 * i + 64] for i in range(len(extras))])
+        self._table = FixedBaseTable(buf, len(self), [raw[64 * i:64 * i + 64] for i in range(len(extras))], rows)
         return self
 
     def fold(self, other, c, keep_proj=None):

@@ -300,7 +300,7 @@ def _commit_launch(xs, gamma, gv, h, ctx):
             if used_tail:
                 ctx.copy(gam.ptr, xs.ptr + 32 * n_main, 32 * used_tail)
             ctx.msm_table(table.ptr, table.n, len(table.extra_bytes), xs.ptr, min(n, n_main), gam.ptr,
-                          out.ptr, None)
+                          out.ptr, None, rows=table.rows)
             return _PendingCommitment(ctx, out, (gam, xs, gv, table))
     gam = ctx.upload(np.frombuffer(reduce_scalar(_int(gamma)).to_bytes(32, "little"), np.uint8))
     hb = ctx.upload(np.frombuffer(h.to_affine_bytes(), np.uint8))
