@@ -508,44 +508,41 @@ k_msm_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ 
 // does the q-th product of each level and the four results are exchanged with DPP quad_perm
 // broadcasts (VALU, no LDS).  Per point operation the critical path is 2 field
 // multiplications instead of 8-9.
-// second level shared by doubling and addition: X3 = E*F, Y3 = G*H, Z3 = F*G, T3 = E*H
-__device__ __forceinline__ void quad_level2(ge_ext &p, const fe &E, const fe &F, const fe &G,
-                                            const fe &H, int q) {
-    fe u = fe_pick4(E, G, F, E, q);
-    fe v = fe_pick4(F, H, G, H, q);
-    fe prod = fe_mul(u, v);
-    p.X = quad_bcast(prod, 0);
-    p.Y = quad_bcast(prod, 1);
-    p.Z = quad_bcast(prod, 2);
-    p.T = quad_bcast(prod, 3);
+// The accumulator stays LANE-DISTRIBUTED (quad.cuh): lane q of every quad holds coordinate q of
+// (X, Y, Z, T).  Second level of both operations: lane 0: E*F = X3, lane 1: G*H = Y3, lane 2: G*F = Z3,
+// lane 3: E*H = T3 - two-way operand selections, and the products land where the next operation reads
+// them.  Sums stay lazy as in ge25519.cuh (only F is carried).  448 instructions per doubling instead
+// of 733 for the replicated form with four-way picks and carried sums.
+__device__ __forceinline__ fe quadD_level2(const fe &E, const fe &F, const fe &G, const fe &H, int q) {
+    fe u = quad_sel(G, E, q == 0 || q == 3);
+    fe v = quad_sel(H, F, (q & 1) == 0);
+    return fe_mul(u, v);
 }
 
-__device__ __forceinline__ void quad_dbl(ge_ext &p, int q) {
-    fe in = fe_pick4(p.X, p.Y, p.Z, fe_add(p.X, p.Y), q);
+__device__ __forceinline__ fe quadD_dbl(const fe &P, int q) {
+    fe x = quad_perm<0x00>(P), y = quad_perm<0x55>(P);
+    fe in = quad_sel(P, fe_add_lazy(x, y), q == 3);          // X, Y, Z, X+Y
     fe sq = fe_sqr(in);
-    sq = fe_select(sq, fe_dbl(sq), q == 2);           // lane 2 holds C = 2 Z^2
-    fe A = quad_bcast(sq, 0), B = quad_bcast(sq, 1), C = quad_bcast(sq, 2), S = quad_bcast(sq, 3);
-    fe H = fe_add(A, B);
-    fe E = fe_sub(H, S);
-    fe G = fe_sub(A, B);
-    fe F = fe_add(C, G);
-    quad_level2(p, E, F, G, H, q);
+    fe A = quad_perm<0x00>(sq), B = quad_perm<0x55>(sq), C = quad_perm<0xaa>(sq), S = quad_perm<0xff>(sq);
+    fe H = fe_add_lazy(A, B);
+    fe E = fe_sub_lazy(H, S);
+    fe G = fe_sub_lazy(A, B);
+    fe F = fe_add(fe_add_lazy(C, C), G);                      // carried
+    return quadD_level2(E, F, G, H, q);
 }
 
-// p += r where r is given in cached form (Y+X, Y-X, 2d*T, 2*Z)
-struct ge_cached {
-    fe ypx, ymx, t2d, z2;
-};
-__device__ __forceinline__ void quad_add_cached(ge_ext &p, const ge_cached &r, int q) {
-    fe u = fe_pick4(fe_sub(p.Y, p.X), fe_add(p.Y, p.X), p.T, p.Z, q);
-    fe v = fe_pick4(r.ymx, r.ypx, r.t2d, r.z2, q);
-    fe prod = fe_mul(u, v);
-    fe A = quad_bcast(prod, 0), B = quad_bcast(prod, 1), C = quad_bcast(prod, 2), D = quad_bcast(prod, 3);
-    fe E = fe_sub(B, A);
-    fe F = fe_sub(D, C);
-    fe G = fe_add(D, C);
-    fe H = fe_add(B, A);
-    quad_level2(p, E, F, G, H, q);
+// P += r, lane q given its own first-level partner v_q of r = (Y-X, Y+X, 2d*T, 2*Z) (all reduced)
+__device__ __forceinline__ fe quadD_add_cached(const fe &P, const fe &vq, int q) {
+    fe x = quad_perm<0x00>(P);
+    fe t = quad_perm<0xb5>(P);                                // lanes: Y, Y, T, Z
+    fe u = quad_sel(quad_sel(t, fe_add_lazy(t, x), q == 1), fe_sub_lazy(t, x), q == 0);
+    fe prod = fe_mul(u, vq);                                  // A, B, C, D
+    fe A = quad_perm<0x00>(prod), B = quad_perm<0x55>(prod), C = quad_perm<0xaa>(prod), D = quad_perm<0xff>(prod);
+    fe E = fe_sub_lazy(B, A);
+    fe H = fe_add_lazy(B, A);
+    fe F = fe_sub(D, C);                                      // carried
+    fe G = fe_add_lazy(D, C);
+    return quadD_level2(E, F, G, H, q);
 }
 
 __global__ void __launch_bounds__(64)
@@ -574,26 +571,26 @@ k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
         __syncthreads();
         // window w's sum, in cached form for the cooperative additions, at slot w
         if (w < W && sub == 0) {
-            fe_st(lds + EXT_WORDS * w, fe_add(tot.Y, tot.X));
-            fe_st(lds + EXT_WORDS * w + FE_LIMBS, fe_sub(tot.Y, tot.X));
-            fe_st(lds + EXT_WORDS * w + 2 * FE_LIMBS, fe_mul(tot.T, fe_const_d2()));
-            fe_st(lds + EXT_WORDS * w + 3 * FE_LIMBS, fe_dbl(tot.Z));
+            fe_st(lds + EXT_WORDS * w, fe_sub(tot.Y, tot.X));                       // lane 0's partner
+            fe_st(lds + EXT_WORDS * w + FE_LIMBS, fe_add(tot.Y, tot.X));            // lane 1's
+            fe_st(lds + EXT_WORDS * w + 2 * FE_LIMBS, fe_mul(tot.T, fe_const_d2()));  // lane 2's
+            fe_st(lds + EXT_WORDS * w + 3 * FE_LIMBS, fe_dbl(tot.Z));               // lane 3's
         }
     }
     __syncthreads();
     // every quad of the wave runs the same chain redundantly (keeps EXEC full for DPP)
     const int q = threadIdx.x & 3;
-    ge_ext acc = ge_ext_identity();
+    fe P = (q == 1 || q == 2) ? fe_one() : fe_zero();          // identity (0 : 1 : 1 : 0), distributed
     for (int k = W - 1; k >= 0; k--) {
         if (k != W - 1)
-            for (int j = 0; j < c; j++) quad_dbl(acc, q);
-        ge_cached r;
-        r.ypx = fe_ld(lds + EXT_WORDS * k);
-        r.ymx = fe_ld(lds + EXT_WORDS * k + FE_LIMBS);
-        r.t2d = fe_ld(lds + EXT_WORDS * k + 2 * FE_LIMBS);
-        r.z2 = fe_ld(lds + EXT_WORDS * k + 3 * FE_LIMBS);
-        quad_add_cached(acc, r, q);
+            for (int j = 0; j < c; j++) P = quadD_dbl(P, q);
+        P = quadD_add_cached(P, fe_ld(lds + EXT_WORDS * k + FE_LIMBS * q), q);
     }
+    ge_ext acc;
+    acc.X = quad_perm<0x00>(P);
+    acc.Y = quad_perm<0x55>(P);
+    acc.Z = quad_perm<0xaa>(P);
+    acc.T = quad_perm<0xff>(P);
     if (threadIdx.x == 0) {
         if (out_ext) ext_st8(out_ext, acc);        // public: packed 128-byte X||Y||Z||T
         if (out_aff) {

@@ -35,3 +35,21 @@ __device__ __forceinline__ fe fe_pick4(const fe &a0, const fe &a1, const fe &a2,
     return r;
 }
 
+
+// ---- lane-distributed form: lane q of a quad HOLDS coordinate q (X, Y, Z, T) ---------------------
+// A point operation in this form never gathers all four coordinates into every lane: the second-level
+// products leave X3, Y3, Z3, T3 in lanes 0..3, which is exactly where the next operation wants them.
+template <int CTRL>
+__device__ __forceinline__ fe quad_perm(const fe &a) {      // DPP quad_perm, CTRL = p0 | p1<<2 | p2<<4 | p3<<6
+    fe r;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++)
+        r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], CTRL, 0xf, 0xf, true);
+    return r;
+}
+__device__ __forceinline__ fe quad_sel(const fe &a, const fe &b, bool pick_b) {   // v_cndmask per limb
+    fe r;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) r.v[i] = pick_b ? b.v[i] : a.v[i];
+    return r;
+}
