@@ -89,7 +89,15 @@ class ShardedMsm:
         self.world, self.rank, self.dist = world, rank, dist
         self.backend = backend if backend is not None else HipBackend(ctx, torch)
         self.collective = world > 1 or force_collective
-        self.sync_device = torch.cuda.synchronize if (torch is not None and backend is None) else None
+        # wait for the collective only: RCCL runs on torch's current stream; a device-wide
+        # synchronize here would also drain the other commitments in flight on their own streams
+        self.sync_device = None
+        if torch is not None and backend is None:
+            def _wait_collective():
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                ev.synchronize()
+            self.sync_device = _wait_collective
         self.gathered = self.backend.new_gather_buffer(world) if self.collective else None
 
     @property
@@ -107,7 +115,7 @@ class ShardedMsm:
         # the single curve-point exchange: G x 128 B
         self.dist.all_gather_into_tensor(self.gathered.view(-1), self.backend.partial_tensor(slot))
         if self.sync_device:
-            self.sync_device()                      # RCCL runs on torch's stream, the combine on ours
+            self.sync_device()                      # RCCL ran on torch's stream, the combine runs on ours
         return self.backend.combine(self.gathered, self.world, slot)
 
     def commit(self, scalars, points):
