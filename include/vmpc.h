@@ -171,6 +171,8 @@ int vmpc_fr_tail_scalars_dev(vmpc_ctx *ctx, const uint8_t *challenges, int t, in
                              const void *z, void *out_a, void *out_b);
 /* synchronous: result copied to host */
 int vmpc_fr_dot_dev(vmpc_ctx *ctx, const void *a, const void *b, size_t n, uint8_t out[32]);
+/* the same, result left in device memory (32 bytes at out_dev, asynchronous) */
+int vmpc_fr_dot_to_dev(vmpc_ctx *ctx, const void *a, const void *b, size_t n, void *out_dev);
 
 /* Text of the Fiat-Shamir pre-image (pivot.py:134 str(input_list)) produced on device:
  * "item0, item1, ..., item{n-1}, " (every item followed by ", ").  Synchronous; *len gets

@@ -31,7 +31,7 @@ SYMBOLS = [
     "vmpc_ed25519_fixed_base_batch", "vmpc_fr_axpy", "vmpc_fr_dot", "vmpc_points_validate_dev",
     "vmpc_msm_dev", "vmpc_msm_table_bytes", "vmpc_msm_table_build_dev", "vmpc_msm_table_dev", "vmpc_points_sum_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
-    "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
+    "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_fr_dot_to_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
     "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
@@ -97,6 +97,7 @@ def load_library():
         "vmpc_fr_axpy_dev": (i32, [vp, vp, vp, vp, sz, vp]),
         "vmpc_fr_scale_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_fr_dot_dev": (i32, [vp, vp, vp, sz, vp]),
+        "vmpc_fr_dot_to_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_format_points_dev": (i32, [vp, vp, sz, vp, sz, u64p]),
         "vmpc_format_scalars_dev": (i32, [vp, vp, sz, i32, vp, sz, u64p]),
         "vmpc_format_points_async_dev": (i32, [vp, vp, sz, vp, sz, vp, vp]),
@@ -499,6 +500,13 @@ class Context:
         _check(self.lib.vmpc_fr_dot_dev(self.handle, ctypes.c_void_p(a_ptr), ctypes.c_void_p(b_ptr),
                                         n, out), "vmpc_fr_dot_dev")
         return int.from_bytes(out.raw, "little")
+
+    def fr_dot_to_dev(self, a_ptr, b_ptr, n):
+        """inner product left on the device: a 32-byte DeviceBuffer, no synchronisation"""
+        out = self.alloc(32)
+        _check(self.lib.vmpc_fr_dot_to_dev(self.handle, ctypes.c_void_p(a_ptr), ctypes.c_void_p(b_ptr), n,
+                                           ctypes.c_void_p(out.ptr)), "vmpc_fr_dot_to_dev")
+        return out
 
     def _format(self, fn, name, src_ptr, n, per_item_cap, *extra):
         cap = n * per_item_cap + 16

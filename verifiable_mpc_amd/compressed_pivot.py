@@ -166,8 +166,9 @@ def _round_prover_scalars(L_tilde, z_hat, half, gf):
     if _on_device(L_tilde.coeffs, z_hat):
         Lc, z = _coeffs_dev(L_tilde), pivot._as_device(z_hat)
         z_l, z_r = z[:half], z[half:]
-        gamma_a = Lc[half:].dot(z_l)           # L~(0 || z_l)
-        gamma_b = Lc[:half].dot(z_r)           # L~(z_r || 0)
+        # the two inner products stay on the device: they are only ever exponents of k in A_i, B_i
+        gamma_a = Lc[half:].dot_dev(z_l)       # L~(0 || z_l)
+        gamma_b = Lc[:half].dot_dev(z_r)       # L~(z_r || 0)
         return z_l, z_r, gamma_a, gamma_b
     z_l, z_r = z_hat[:half], z_hat[half:]
     gamma_a = int(L_tilde([0] * half + z_l))

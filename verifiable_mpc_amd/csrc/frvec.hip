@@ -197,6 +197,27 @@ extern "C" int vmpc_fr_dot_dev(vmpc_ctx *ctx, const void *a, const void *b, size
     return VMPC_OK;
 }
 
+// the same inner product left on the device (no host round trip): out_dev receives 32 bytes when the
+// stream reaches it - the exponent of k in A_i / B_i (compressed_pivot.py:41-42) goes straight into the
+// commitment's extra-scalar buffer
+extern "C" int vmpc_fr_dot_to_dev(vmpc_ctx *ctx, const void *a, const void *b, size_t n, void *out_dev) {
+    if (!ctx || !out_dev || (n && (!a || !b))) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    if (n == 0) {
+        VMPC_HIP_CHECK(hipMemsetAsync(out_dev, 0, 32, ctx->stream));
+        return VMPC_OK;
+    }
+    unsigned g = fr_grid(n);
+    VMPC_CHECK(vmpc_ws_reserve(ctx, vmpc_align((size_t)g * 32) + 256));
+    uint32_t *partials = (uint32_t *)vmpc_ws_take(ctx, (size_t)g * 32);
+    vmpc_stage_scope s(ctx, "fr_dot");
+    k_fr_dot<<<g, FR_BLOCK, 0, ctx->stream>>>((const uint32_t *)a, (const uint32_t *)b, n, partials);
+    VMPC_KERNEL_CHECK();
+    k_fr_sum<<<1, FR_BLOCK, 0, ctx->stream>>>(partials, g, (uint32_t *)out_dev);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
 extern "C" int vmpc_fr_challenge_products_dev(vmpc_ctx *ctx, const uint8_t *challenges, int rounds,
                                               int low_bits, const void *z, size_t n, void *out) {
     if (!ctx || rounds < 0 || rounds > 20 || low_bits < 0 || low_bits > 40 || (rounds && !challenges) ||

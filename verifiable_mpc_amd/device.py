@@ -78,6 +78,20 @@ def _slice_bounds(key, n):
     return a, max(a, b)
 
 
+class DeviceScalar:
+    """One residue mod l in device memory (e.g. an inner product nobody on the host needs to see)."""
+
+    def __init__(self, buf, ctx):
+        self.buf, self.ctx = buf, ctx
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    def __int__(self):
+        return int.from_bytes(self.ctx.download(self.buf.ptr, 32).tobytes(), "little")
+
+
 class ScalarVector:
     """n scalars mod l on the device."""
 
@@ -151,6 +165,11 @@ class ScalarVector:
     def dot(self, other):
         assert len(other) == len(self)
         return self.ctx.fr_dot(self.ptr, other.ptr, len(self))
+
+    def dot_dev(self, other):
+        """<self, other> mod l as a DeviceScalar: stays on the device, nothing waits for it"""
+        assert len(other) == len(self)
+        return DeviceScalar(self.ctx.fr_dot_to_dev(self.ptr, other.ptr, len(self)), self.ctx)
 
     def text_begin(self, is_signed=True):
         """start producing the transcript text on the side stream (no host wait): formatting and

@@ -79,7 +79,7 @@ _FIELD = GF(P, is_signed=False)
 class Ed25519Point(EllipticCurvePoint):
     """Projective (X:Y:Z) point; the representative is part of the value (it is what
     repr() prints and what the reference's Fiat-Shamir pre-image contains)."""
-    __slots__ = ("coords",)
+    __slots__ = ("coords", "_affine_bytes")
     field = _FIELD
     order = ORDER
     is_additive = True          # MPyC's default; the AC20 demo flips both flags
@@ -101,6 +101,7 @@ class Ed25519Point(EllipticCurvePoint):
             if (-x * x + y * y - 1 - D * x * x % P * y * y) % P:
                 raise ValueError("point not on Ed25519")
         self.coords = tuple(vals)
+        self._affine_bytes = None        # cache: coords never change after construction
 
     @property
     def value(self):
@@ -134,6 +135,8 @@ class Ed25519Point(EllipticCurvePoint):
 
     def normalize(self):
         x, y, z = self.coords
+        if z == 1:
+            return self
         zi = pow(z, P - 2, P)
         return type(self)((x * zi % P, y * zi % P, 1))
 
@@ -185,8 +188,10 @@ class Ed25519Point(EllipticCurvePoint):
 
     # -- byte formats of include/vmpc.h -------------------------------------------------
     def to_affine_bytes(self):
-        x, y, _ = self.normalize().coords
-        return x.to_bytes(32, "little") + y.to_bytes(32, "little")
+        if self._affine_bytes is None:     # one field inversion; h and k are asked for every commitment
+            x, y, _ = self.normalize().coords
+            self._affine_bytes = x.to_bytes(32, "little") + y.to_bytes(32, "little")
+        return self._affine_bytes
 
     def to_proj_bytes(self):
         return b"".join(c.to_bytes(32, "little") for c in self.coords)

@@ -18,7 +18,7 @@ import hashlib
 import logging
 from random import SystemRandom
 
-from .device import PointVector, ScalarVector, get_context, reduce_scalar
+from .device import DeviceScalar, PointVector, ScalarVector, get_context, reduce_scalar
 from .fields import FiniteFieldElement
 from .groups import EllipticCurvePoint as EllipticCurveElement
 from .groups import Ed25519Point
@@ -295,14 +295,20 @@ def _commit_launch(xs, gamma, gv, h, ctx):
         used_tail = max(0, n - n_main)
         if slot is not None and slot >= used_tail:
             esc = bytearray(32 * len(table.extra_bytes))
-            esc[32 * slot:32 * slot + 32] = reduce_scalar(_int(gamma)).to_bytes(32, "little")
+            if not isinstance(gamma, DeviceScalar):
+                esc[32 * slot:32 * slot + 32] = reduce_scalar(_int(gamma)).to_bytes(32, "little")
             gam = ctx.upload(np.frombuffer(bytes(esc), np.uint8))
+            if isinstance(gamma, DeviceScalar):
+                ctx.copy(gam.ptr + 32 * slot, gamma.ptr, 32)
             if used_tail:
                 ctx.copy(gam.ptr, xs.ptr + 32 * n_main, 32 * used_tail)
             ctx.msm_table(table.ptr, table.n, len(table.extra_bytes), xs.ptr, min(n, n_main), gam.ptr,
                           out.ptr, None, rows=table.rows)
             return _PendingCommitment(ctx, out, (gam, xs, gv, table))
-    gam = ctx.upload(np.frombuffer(reduce_scalar(_int(gamma)).to_bytes(32, "little"), np.uint8))
+    if isinstance(gamma, DeviceScalar):
+        gam = gamma
+    else:
+        gam = ctx.upload(np.frombuffer(reduce_scalar(_int(gamma)).to_bytes(32, "little"), np.uint8))
     hb = ctx.upload(np.frombuffer(h.to_affine_bytes(), np.uint8))
     ctx.msm(xs.ptr, gv.affine_ptr, n, gam.ptr, hb.ptr, 1, out.ptr, None)
     return _PendingCommitment(ctx, out, (gam, hb, xs, gv))
