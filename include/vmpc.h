@@ -139,6 +139,13 @@ int vmpc_repeat_dev(vmpc_ctx *ctx, const void *bases, size_t n_bases, int bases_
                     const void *scalars, size_t n, int signed_scalars, void *out_proj,
                     void *out_affine);
 
+/* out_i = scalars[i] * base as AFFINE points (64 B each), for callers that need the group elements of
+ * `h ** r_i` (circuit_sat_r1cs.py:64-70,81) but not the reference's projective representatives: a
+ * comb table of the one base replaces the per-element ladder (6x less work than vmpc_repeat_dev).
+ * Scalars canonical (< l; checked on device, reported at the next sync point). */
+int vmpc_fixed_base_dev(vmpc_ctx *ctx, const void *base_affine, const void *scalars, size_t n,
+                        void *out_affine);
+
 /* g'_i = (g_l[i] ** c) * g_r[i], compressed_pivot.py:64/:178, replayed exactly.
  * in_affine != 0: inputs are 64-byte affine points (Z = 1), else 96-byte projective. */
 int vmpc_fold_dev(vmpc_ctx *ctx, const void *g_l, const void *g_r, int in_affine,

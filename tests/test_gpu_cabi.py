@@ -271,6 +271,29 @@ def test_repeat_replays_reference_sequence(nat, ctx):
     assert dl_proj(ctx, op2.ptr, 40) == ac.create_generators(exps)["g"]
 
 
+def test_fixed_base_comb_matches_oracle(nat, ctx):
+    """vmpc_fixed_base_dev: out_i = n_i * B as affine points (circuit_sat_r1cs.py:64-70 when the
+    projective representative is not needed), incl. digit-recoding edge cases."""
+    rng = random.Random(31)
+    base = ed.pt_repeat(ed.BASE, rng.randrange(1, ELL))
+    sc = [0, 1, 2, 127, 128, 129, 255, 256, 257, 0x8080, 0x7f7f7f7f, (1 << 252) - 1, 1 << 252, ELL - 1, ELL - 2,
+          int.from_bytes(bytes([0x80] * 31 + [0x0f]), "little"), int.from_bytes(bytes([0x81] * 31 + [0x0f]), "little"),
+          int.from_bytes(bytes([0xff] * 31 + [0x0f]), "little")] + [rng.randrange(ELL) for _ in range(40)]
+    db, ds = ctx.upload(aff_bytes([base])), ctx.upload(sc_bytes(nat, sc))
+    out = ctx.alloc(64 * len(sc))
+    ctx.fixed_base(db.ptr, ds.ptr, len(sc), out.ptr)
+    ctx.sync()
+    got = dl_aff(ctx, out.ptr, len(sc))
+    for v, g in zip(sc, got):
+        assert g[:2] == ed.pt_affine(ed.pt_repeat(base, v)), hex(v)
+    bad = ctx.upload(np.frombuffer(ELL.to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32))
+    ctx.fixed_base(db.ptr, bad.ptr, 1, out.ptr)
+    with pytest.raises(nat.VmpcError) as ei:
+        ctx.sync()
+    assert ei.value.code == nat.E_NONCANON
+    ctx.sync()
+
+
 def test_fold_replays_reference_sequence(nat, ctx):
     """g' = (g_l ** c) * g_r, compressed_pivot.py:64: exact (X, Y, Z) and affine."""
     rng = random.Random(12)

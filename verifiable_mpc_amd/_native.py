@@ -29,7 +29,7 @@ SYMBOLS = [
     "vmpc_memcpy_d2h", "vmpc_memcpy_d2d", "vmpc_ctx_profile", "vmpc_ctx_profile_read",
     "vmpc_ctx_set_window", "vmpc_ed25519_msm_plan", "vmpc_ed25519_madd_rate", "vmpc_ed25519_msm", "vmpc_ed25519_fold",
     "vmpc_ed25519_fixed_base_batch", "vmpc_fr_axpy", "vmpc_fr_dot", "vmpc_points_validate_dev",
-    "vmpc_msm_dev", "vmpc_msm_table_bytes", "vmpc_msm_table_build_dev", "vmpc_msm_table_dev", "vmpc_points_sum_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
+    "vmpc_msm_dev", "vmpc_msm_table_bytes", "vmpc_msm_table_build_dev", "vmpc_msm_table_dev", "vmpc_points_sum_dev", "vmpc_fixed_base_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
     "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_fr_dot_to_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
     "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
@@ -90,6 +90,7 @@ def load_library():
         "vmpc_msm_table_dev": (i32, [vp, vp, sz, sz, i32, vp, sz, vp, vp, vp]),
         "vmpc_points_sum_dev": (i32, [vp, vp, sz, vp, vp]),
         "vmpc_repeat_dev": (i32, [vp, vp, sz, i32, vp, sz, i32, vp, vp]),
+        "vmpc_fixed_base_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_fold_dev": (i32, [vp, vp, vp, i32, vp, sz, vp, vp]),
         "vmpc_tree_reduce_dev": (i32, [vp, vp, sz, i32, vp]),
         "vmpc_normalize_dev": (i32, [vp, vp, sz, vp]),
@@ -447,6 +448,11 @@ class Context:
                                         1 if bases_affine else 0, ctypes.c_void_p(scalars_ptr), n,
                                         1 if signed_scalars else 0, ctypes.c_void_p(out_proj_ptr),
                                         ctypes.c_void_p(out_affine_ptr)), "vmpc_repeat_dev")
+
+    def fixed_base(self, base_affine_ptr, scalars_ptr, n, out_affine_ptr):
+        _check(self.lib.vmpc_fixed_base_dev(self.handle, ctypes.c_void_p(base_affine_ptr),
+                                            ctypes.c_void_p(scalars_ptr), n, ctypes.c_void_p(out_affine_ptr)),
+               "vmpc_fixed_base_dev")
 
     def fold(self, gl_ptr, gr_ptr, in_affine, c, half, out_proj_ptr=None, out_affine_ptr=None):
         cb = ctypes.create_string_buffer(scalar_to_bytes(c), 32)
