@@ -219,8 +219,10 @@ int vmpc_bn256_validate_dev(vmpc_ctx *ctx, int group, const void *points, size_t
  * sum_{i<m} scalars[i] * P_i, equal to vmpc_bn256_g{1,2}_msm_dev on the first m points. */
 int vmpc_bn256_table_bytes(int group, size_t n, size_t *bytes);
 int vmpc_bn256_table_build_dev(vmpc_ctx *ctx, int group, const void *points, size_t n, void *table);
+/* out_affine (64 / 128 B) and / or out_jacobian (canonical X || Y || Z, 96 / 192 B; Z = 0 is the
+ * point at infinity) - the Jacobian form skips the inversion chain that one lane would run */
 int vmpc_bn256_table_msm_dev(vmpc_ctx *ctx, int group, const void *table, size_t table_n,
-                             const void *scalars, size_t m, void *out_affine);
+                             const void *scalars, size_t m, void *out_affine, void *out_jacobian);
 
 /* SHA-256 of every `chunk_bytes`-sized piece of a device buffer (last piece may be short):
  * out_digests[i] = SHA256(data[i*chunk : (i+1)*chunk]), 32 bytes each.  Leaves of the compact

@@ -35,12 +35,12 @@ for group, gen, width in ((1, G1, 64), (2, G2, 128)):
         table = ctx.bn256_table_build(group, dp.ptr, n); ctx.sync()
         t_build = time.perf_counter() - t0
         out2 = ctx.alloc(width)
-        ctx.bn256_table_msm(group, table.ptr, n, ds.ptr, n, out2.ptr); ctx.sync()
+        ctx.bn256_table_msm(group, table.ptr, n, ds.ptr, n, out2.ptr, None); ctx.sync()
         same = ctx.download(out2.ptr, width).tobytes() == want
         ctx.profile(True); ctx.profile_read(True)
         t0 = time.perf_counter()
         for _ in range(3):
-            ctx.bn256_table_msm(group, table.ptr, n, ds.ptr, n, out2.ptr)
+            ctx.bn256_table_msm(group, table.ptr, n, ds.ptr, n, out2.ptr, None)
         ctx.sync(); dt = (time.perf_counter() - t0) / 3
         prof = ctx.profile_read(True); ctx.profile(False)
         print(f"   table: {dt*1e3:.2f} ms -> {n/dt/1e6:.1f} M sm/s same={same} build {t_build*1e3:.0f} ms {table.nbytes>>20} MiB  " +

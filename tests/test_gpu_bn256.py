@@ -128,10 +128,15 @@ def test_table_msm_matches_variable_base_and_oracle(vm, gi):
     dp, ds, out = ctx.upload(arr), ctx.upload(_native.ints_to_array(sc, 32)), ctx.alloc(width)
     table = ctx.bn256_table_build(grp, dp.ptr, n)
     for m in (n, n // 2, 10, 1, 0):
-        ctx.bn256_table_msm(grp, table.ptr, n, ds.ptr, m, out.ptr)
+        jac = ctx.alloc(3 * width // 2)
+        ctx.bn256_table_msm(grp, table.ptr, n, ds.ptr, m, out.ptr, jac.ptr)
         ctx.sync()
         got = from_b(ctx.download(out.ptr, width).tobytes())
         assert got == E.mul(sum(a * b for a, b in zip(sc[:m], exps[:m])) % bn.N, G), m
+        # Jacobian output + host normalisation (what pynocchio.PreparedKey uses) is the same point
+        from verifiable_mpc_amd import pynocchio as pn
+        pj = pn._from_jacobian(grp, ctx.download(jac.ptr, 3 * width // 2).tobytes())
+        assert pj.to_bytes() == to_b(got), m
         if m:
             ctx.bn256_msm(grp, ds.ptr, dp.ptr, m, out.ptr)
             ctx.sync()

@@ -115,7 +115,7 @@ def load_library():
         "vmpc_bn256_validate_dev": (i32, [vp, i32, vp, sz, u64p]),
         "vmpc_bn256_table_bytes": (i32, [i32, sz, vp]),
         "vmpc_bn256_table_build_dev": (i32, [vp, i32, vp, sz, vp]),
-        "vmpc_bn256_table_msm_dev": (i32, [vp, i32, vp, sz, vp, sz, vp]),
+        "vmpc_bn256_table_msm_dev": (i32, [vp, i32, vp, sz, vp, sz, vp, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the export is missing
@@ -537,9 +537,10 @@ class Context:
                                                    ctypes.c_void_p(table.ptr)), "vmpc_bn256_table_build_dev")
         return table
 
-    def bn256_table_msm(self, group, table_ptr, table_n, scalars_ptr, m, out_ptr):
+    def bn256_table_msm(self, group, table_ptr, table_n, scalars_ptr, m, out_ptr=None, out_jac_ptr=None):
         _check(self.lib.vmpc_bn256_table_msm_dev(self.handle, group, ctypes.c_void_p(table_ptr), table_n,
-                                                 ctypes.c_void_p(scalars_ptr), m, ctypes.c_void_p(out_ptr)),
+                                                 ctypes.c_void_p(scalars_ptr), m, ctypes.c_void_p(out_ptr),
+                                                 ctypes.c_void_p(out_jac_ptr)),
                "vmpc_bn256_table_msm_dev")
 
     def bn256_validate(self, group, points_ptr, n):

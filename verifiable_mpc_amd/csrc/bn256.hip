@@ -197,26 +197,44 @@ gk_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ cou
 }
 
 // ---- final: window sums, Horner over windows, normalise ----------------------------------------
+// out_jac != NULL: leave the sum in Jacobian coordinates (canonical residues X || Y || Z) - the caller
+// normalises with one host inversion instead of a ~450-multiplication chain on one lane.
 template <class C, class F>
 __global__ void __launch_bounds__(64)
 gk_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
-         uint32_t *__restrict__ out_aff) {
+         uint32_t *__restrict__ out_aff, uint32_t *__restrict__ out_jac) {
     __shared__ uint32_t lds[64 * C::ACC_WORDS];
-    const int w = threadIdx.x;
-    if (w < W) {
-        typename C::acc_t r = C::acc_ld(partials + (size_t)C::ACC_WORDS * ((size_t)w * red_blocks));
-        for (int j = 1; j < red_blocks; j++)
-            r = jac_add<F>(r, C::acc_ld(partials + (size_t)C::ACC_WORDS * ((size_t)w * red_blocks + j)));
-        C::acc_st(lds + C::ACC_WORDS * w, r);
+    // window sums: lpw lanes share a window (strided partial sums), then a short LDS tree
+    int lpw = 1;
+    while (lpw * 2 * W <= 64 && lpw * 2 <= red_blocks) lpw *= 2;
+    const int w = threadIdx.x / lpw, sub = threadIdx.x % lpw;
+    {
+        typename C::acc_t r = jac_identity<F>();
+        if (w < W)
+            for (int j = sub; j < red_blocks; j += lpw)
+                r = jac_add<F>(r, C::acc_ld(partials + (size_t)C::ACC_WORDS * ((size_t)w * red_blocks + j)));
+        C::acc_st(lds + C::ACC_WORDS * threadIdx.x, r);
     }
     __syncthreads();
+    for (int stride = lpw / 2; stride >= 1; stride >>= 1) {
+        if (w < W && sub < stride)
+            C::acc_st(lds + C::ACC_WORDS * threadIdx.x,
+                      jac_add<F>(C::acc_ld(lds + C::ACC_WORDS * threadIdx.x),
+                                 C::acc_ld(lds + C::ACC_WORDS * (threadIdx.x + stride))));
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        typename C::acc_t acc = C::acc_ld(lds + C::ACC_WORDS * (W - 1));
+        typename C::acc_t acc = C::acc_ld(lds + C::ACC_WORDS * ((W - 1) * lpw));
         for (int k = W - 2; k >= 0; k--) {
             for (int j = 0; j < c; j++) acc = jac_dbl<F>(acc);
-            acc = jac_add<F>(acc, C::acc_ld(lds + C::ACC_WORDS * k));
+            acc = jac_add<F>(acc, C::acc_ld(lds + C::ACC_WORDS * (k * lpw)));
         }
-        aff_store<F>(out_aff, jac_to_affine<F>(acc));
+        if (out_aff) aff_store<F>(out_aff, jac_to_affine<F>(acc));
+        if (out_jac) {
+            F::store(out_jac, acc.X);
+            F::store(out_jac + F::WORDS, acc.Y);
+            F::store(out_jac + 2 * F::WORDS, acc.Z);
+        }
     }
 }
 
@@ -241,7 +259,8 @@ gk_validate(const uint32_t *__restrict__ pts, size_t n, typename F::elem b,
 // bucket accumulation -> finish -> reduce -> recombination; `entries` = the call's prepared points or
 // a fixed-base table
 template <class C, class F>
-static int bn_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uint32_t *entries, void *out_affine) {
+static int bn_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uint32_t *entries, void *out_affine,
+                         void *out_jac = nullptr) {
     hipStream_t st = ctx->stream;
     {
         vmpc_stage_scope s(ctx, "bn_bucket");
@@ -266,7 +285,8 @@ static int bn_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uint
     }
     {
         vmpc_stage_scope s(ctx, "bn_final");
-        gk_final<C, F><<<1, 64, 0, st>>>(w.partials, p.W, p.red_blocks, p.c, (uint32_t *)out_affine);
+        gk_final<C, F><<<1, 64, 0, st>>>(w.partials, p.W, p.red_blocks, p.c, (uint32_t *)out_affine,
+                                         (uint32_t *)out_jac);
         VMPC_KERNEL_CHECK();
     }
     return VMPC_OK;
@@ -357,8 +377,8 @@ static int bn_table_build_dev(vmpc_ctx *ctx, const void *points, size_t n, void 
 
 template <class C, class F>
 static int bn_table_msm_dev(vmpc_ctx *ctx, const void *table, size_t table_n, const void *scalars, size_t m,
-                            void *out_affine) {
-    if (!ctx || !table || !out_affine || table_n == 0 || table_n > ((size_t)1 << 26) || m > table_n ||
+                            void *out_affine, void *out_jac) {
+    if (!ctx || !table || (!out_affine && !out_jac) || table_n == 0 || table_n > ((size_t)1 << 26) || m > table_n ||
         (m && !scalars))
         return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
@@ -378,7 +398,7 @@ static int bn_table_msm_dev(vmpc_ctx *ctx, const void *table, size_t table_n, co
     VMPC_CHECK(msm_recode_rows(ctx, scalars, m, nullptr, 0, 0, stride, w.digits, BN_TABLE_C, BN_TABLE_W, BN_TABLE_W,
                                BN_ORDER));
     VMPC_CHECK(msm_sort_digits(ctx, p, w));
-    return bn_accumulate<C, F>(ctx, p, w, (const uint32_t *)table, out_affine);
+    return bn_accumulate<C, F>(ctx, p, w, (const uint32_t *)table, out_affine, out_jac);
 }
 
 extern "C" int vmpc_bn256_table_bytes(int group, size_t n, size_t *bytes) {
@@ -394,9 +414,9 @@ extern "C" int vmpc_bn256_table_build_dev(vmpc_ctx *ctx, int group, const void *
 }
 
 extern "C" int vmpc_bn256_table_msm_dev(vmpc_ctx *ctx, int group, const void *table, size_t table_n,
-                                        const void *scalars, size_t m, void *out_affine) {
-    if (group == 1) return bn_table_msm_dev<G1, Fp1Ops>(ctx, table, table_n, scalars, m, out_affine);
-    if (group == 2) return bn_table_msm_dev<G2, Fp2Ops>(ctx, table, table_n, scalars, m, out_affine);
+                                        const void *scalars, size_t m, void *out_affine, void *out_jacobian) {
+    if (group == 1) return bn_table_msm_dev<G1, Fp1Ops>(ctx, table, table_n, scalars, m, out_affine, out_jacobian);
+    if (group == 2) return bn_table_msm_dev<G2, Fp2Ops>(ctx, table, table_n, scalars, m, out_affine, out_jacobian);
     return VMPC_E_INVAL;
 }
 

@@ -120,6 +120,26 @@ _ELEMENTS = {
 }
 
 
+def _from_jacobian(group, raw):
+    """(X : Y : Z) canonical residues -> affine BN256Point / BN256TwistPoint (x = X/Z^2, y = Y/Z^3)"""
+    v = [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(len(raw) // 32)]
+    if group == 1:
+        X, Y, Z = v
+        if Z == 0:
+            return BN256Point(None)
+        zi = pow(Z, P - 2, P)
+        return BN256Point((X * zi * zi % P, Y * zi * zi % P * zi % P))
+    mul = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+    X, Y, Z = (v[0], v[1]), (v[2], v[3]), (v[4], v[5])
+    if Z == (0, 0):
+        return BN256TwistPoint(None)
+    d = pow(Z[0] * Z[0] + Z[1] * Z[1], P - 2, P)
+    zi = (Z[0] * d % P, (-Z[1] * d) % P)
+    zi2 = mul(zi, zi)
+    x, y = mul(X, zi2), mul(mul(Y, zi2), zi)
+    return BN256TwistPoint((x[0], x[1], y[0], y[1]))
+
+
 class _KeyVector:
     """One evaluation-key vector on the device: points uploaded, validated and tabulated once."""
 
@@ -139,11 +159,12 @@ class _KeyVector:
     def msm(self, ctx, scalars):
         m = len(scalars)
         assert m <= self.n
-        ds, out = ctx.upload(_native.ints_to_array([int(s) % ORDER for s in scalars], 32)), ctx.alloc(self.width)
-        ctx.bn256_table_msm(self.group, self.table.ptr, self.n, ds.ptr, m, out.ptr)
+        jw = 3 * self.width // 2
+        ds, out = ctx.upload(_native.ints_to_array([int(s) % ORDER for s in scalars], 32)), ctx.alloc(jw)
+        ctx.bn256_table_msm(self.group, self.table.ptr, self.n, ds.ptr, m, None, out.ptr)
         ctx.sync()
-        cls = BN256Point if self.group == 1 else BN256TwistPoint
-        return cls.from_bytes(ctx.download(out.ptr, self.width).tobytes())
+        # the sum comes back in Jacobian coordinates; the one inversion is O(1) host glue
+        return _from_jacobian(self.group, ctx.download(out.ptr, jw).tobytes())
 
 
 class PreparedKey:
