@@ -763,7 +763,10 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
     while (p.seg_shift < 4 && (((size_t)MSM_SEG << p.seg_shift) << 18) < (size_t)p.W * p.n_total) p.seg_shift++;
     // reduce: chunk-lanes per window (chunk length a power of two): the per-lane work is a
     // dependency chain, so shorter chunks on more lanes cut the latency
-    int chunks = p.nb < MSM_REDUCE_CHUNKS ? p.nb : MSM_REDUCE_CHUNKS;
+    // (with few windows - fixed-base tables - more chunk-lanes per window keep the same ~64 K lanes busy)
+    int chunks = MSM_REDUCE_CHUNKS;
+    while (chunks * 2 * p.W <= MSM_REDUCE_CHUNKS * 16 && chunks * 2 <= 32768) chunks *= 2;
+    if (chunks > p.nb) chunks = p.nb;
     p.chunks = chunks;
     p.chunk_len = p.nb / chunks;
     p.red_blocks = (chunks + MSM_BLOCK - 1) / MSM_BLOCK;
