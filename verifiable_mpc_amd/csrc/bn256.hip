@@ -382,7 +382,6 @@ static int bn_table_msm_dev(vmpc_ctx *ctx, const void *table, size_t table_n, co
         (m && !scalars))
         return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
     const size_t stride = bn_table_stride(table_n);
     msm_plan p;
     p.n_main = p.n_total = (size_t)BN_TABLE_W * stride;
