@@ -106,3 +106,59 @@ def test_config3_protocol5_2_20_round_trip(vm, mode):
     bad = dict(proof)
     bad[f"B{rounds // 2}"] = proof["A0"]
     assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, bad, gf, transcript=mode) is False
+
+
+def test_config3_tabulated_crs_2_20(vm):
+    """fixed-base tables at full size: a commitment over the tabulated CRS equals the variable-base one
+    (every row count), and the fold-free compact prover produces the very proof of the folding prover."""
+    N = 1 << 20
+    n = N - 1
+    rng = np.random.default_rng(77)
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    h, k = group.generator, vm.Ed25519Point.repeat(group.generator, 424242)
+    g = vm.PointVector.fixed_base(h, vm.ScalarVector.from_array(rand_scalars(rng, n)), keep_proj=False)
+    gens = {"g": g, "h": h, "k": k}
+    x = vm.ScalarVector.from_array(rand_scalars(rng, n))
+    L = vm.pivot.LinearForm(vm.ScalarVector.from_array(rand_scalars(rng, n)))
+    y, gamma = gf(L(x)), 271828
+    P = vm.pivot.vector_commitment(x, gamma, g, h)                       # variable base
+    r = rand_scalars(rng, n)
+    plain = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, gamma, gf, transcript="compact",
+                                                  r=vm.ScalarVector.from_array(r), rho=7)
+
+    def flat(proof):
+        return {key: (v.to_affine_bytes() if hasattr(v, "to_affine_bytes") else [int(e) for e in v]
+                      if isinstance(v, list) else int(v)) for key, v in proof.items()}
+    for rows in (None, 16, 1):
+        g.precompute([h, k], rows=rows)
+        assert vm.pivot.vector_commitment(x, gamma, g, h) == P
+        assert vm.pivot.vector_commitment(x[:12345], 5, g, k) == vm.pivot.vector_commitment(
+            x[:12345], 5, vm.PointVector(g.a, None, g.ctx), k)
+        if rows != 16:
+            tab = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, gamma, gf, transcript="compact",
+                                                        r=vm.ScalarVector.from_array(r), rho=7)
+            assert flat(tab) == flat(plain)
+            assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, tab, gf, transcript="compact") is True
+
+
+def test_config4_shard_size_msm_2_21_properties(vm):
+    """n = 2^21 is one GPU's share of BASELINE config 4 (2^24 terms over 8 GPUs): longer segments, more
+    sort slices.  Exponent identity and window-width independence."""
+    n = 1 << 21
+    rng = np.random.default_rng(221)
+    group = vm.EllipticCurve("Ed25519", "projective")
+    exps = rand_scalars(rng, n)
+    g = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(exps), keep_proj=False)
+    s1 = rand_scalars(rng, n)
+    x1 = vm.ScalarVector.from_array(s1)
+    ident = vm.Ed25519Point.identity
+    c1 = vm.pivot.vector_commitment(x1, 0, g, ident)
+    tot = sum(a * b for a, b in zip(vm._native.array_to_ints(s1), vm._native.array_to_ints(exps))) % ELL
+    assert c1 == vm.Ed25519Point.repeat(group.generator, tot)
+    ctx = vm.get_context()
+    ctx.set_window(14)
+    try:
+        assert vm.pivot.vector_commitment(x1, 0, g, ident) == c1
+    finally:
+        ctx.set_window(0)
