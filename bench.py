@@ -282,7 +282,7 @@ def main():
             "metric": "Ed25519 MSM scalar-mults/sec", "value": world * n * args.steps / elapsed,
             "unit": "scalar-mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32x8 (255-bit modular integers)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32 (255-bit modular integers as 10 limbs of 25.5 bits, 32x32->64 multiply-adds)", "data": "synthetic",
             "config": {"workload": f"Pedersen vector-commitment MSM, n=2^{args.log2n} Ed25519 "
                                    f"generators per GPU, uniform 252-bit scalars",
                        "terms_per_gpu": n, "total_terms": world * n, "commitments_in_flight": depth,
