@@ -176,6 +176,11 @@ int vmpc_fr_challenge_products_dev(vmpc_ctx *ctx, const uint8_t *challenges, int
  * applied; z is the current witness of 2^(log2_m0 - t) scalars.  out_a / out_b: 2^log2_m0 scalars. */
 int vmpc_fr_tail_scalars_dev(vmpc_ctx *ctx, const uint8_t *challenges, int t, int log2_m0,
                              const void *z, void *out_a, void *out_b);
+/* The same scalars round by round: `products` (2^log2_m0 scalars) carries the challenge products from
+ * the call with t - 1 to the call with t (t = 0 initialises it) and only the newest challenge
+ * c_{t-1} is passed: two products per element and round instead of up to t + 1. */
+int vmpc_fr_tail_scalars_inc_dev(vmpc_ctx *ctx, const uint8_t newest_challenge[32], int t, int log2_m0,
+                                 const void *z, void *products, void *out_a, void *out_b);
 /* synchronous: result copied to host */
 int vmpc_fr_dot_dev(vmpc_ctx *ctx, const void *a, const void *b, size_t n, uint8_t out[32]);
 /* the same, result left in device memory (32 bytes at out_dev, asynchronous) */

@@ -272,10 +272,12 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
         if tail_cs is None and transcript.mode == "compact" and isinstance(z_l, ScalarVector) \
                 and len(g_hat) == m and m >= 4 and (len(g_hat) <= TAIL_BASE or _tabulated(g_hat, k)):
             tail_cs = []
+            tail_products = ScalarVector.empty(len(g_hat), g_hat.ctx)     # challenge products per generator
         if tail_cs is not None:
             ctx = g_hat.ctx
             v_a, v_b = ScalarVector.empty(len(g_hat), ctx), ScalarVector.empty(len(g_hat), ctx)
-            ctx.fr_tail_scalars(tail_cs, len(g_hat).bit_length() - 1, z_hat.ptr, v_a.ptr, v_b.ptr)
+            ctx.fr_tail_scalars_inc(tail_cs[-1] if tail_cs else 0, len(tail_cs), len(g_hat).bit_length() - 1,
+                                    z_hat.ptr, tail_products.ptr, v_a.ptr, v_b.ptr)
             A, B = pivot.vector_commitment_pair(v_a, gamma_a, g_hat, v_b, gamma_b, g_hat, k)
         else:
             g_l, g_r = g_hat[:half], g_hat[half:]

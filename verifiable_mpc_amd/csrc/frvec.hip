@@ -144,6 +144,35 @@ k_fr_tail_scalars(fr_chal_arg ch, int t, int log2_m0, const uint32_t *__restrict
     }
 }
 
+// incremental form: `prod` holds s[j] for the first t-1 challenges (all ones for t = 0) and is updated
+// in place with the newest one, so a round costs two products per element instead of up to t + 1
+__global__ void __launch_bounds__(FR_BLOCK)
+k_fr_tail_scalars_inc(fr_arg c_new, int t, int log2_m0, const uint32_t *__restrict__ z,
+                      uint32_t *__restrict__ prod, uint32_t *__restrict__ out_a, uint32_t *__restrict__ out_b) {
+    const size_t m0 = (size_t)1 << log2_m0;
+    const size_t m = m0 >> t, h = m >> 1;
+    fr c;
+#pragma unroll
+    for (int k = 0; k < 8; k++) c.v[k] = c_new.v[k];
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m0;
+         j += (size_t)gridDim.x * blockDim.x) {
+        fr s;
+        if (t == 0) {
+            s = fr_zero();
+            s.v[0] = 1;
+        } else {
+            s = frv_ld(prod + 8 * j);
+            if (((j >> (log2_m0 - t)) & 1) == 0) s = fr_mul(s, c);
+        }
+        frv_st(prod + 8 * j, s);
+        size_t u = j & (m - 1);
+        bool right = u >= h;
+        fr acc = fr_mul(frv_ld(z + 8 * (right ? u - h : u + h)), s);
+        frv_st(out_a + 8 * j, right ? acc : fr_zero());
+        frv_st(out_b + 8 * j, right ? fr_zero() : acc);
+    }
+}
+
 static inline unsigned fr_grid(size_t n) {
     size_t g = (n + FR_BLOCK - 1) / FR_BLOCK;
     return (unsigned)(g > FR_MAX_GRID ? FR_MAX_GRID : (g ? g : 1));
@@ -254,6 +283,22 @@ extern "C" int vmpc_fr_tail_scalars_dev(vmpc_ctx *ctx, const uint8_t *challenges
     vmpc_stage_scope s(ctx, "fr_tail_scalars");
     k_fr_tail_scalars<<<fr_grid((size_t)1 << log2_m0), FR_BLOCK, 0, ctx->stream>>>(
         a, t, log2_m0, (const uint32_t *)z, (uint32_t *)out_a, (uint32_t *)out_b);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_fr_tail_scalars_inc_dev(vmpc_ctx *ctx, const uint8_t newest_challenge[32], int t, int log2_m0,
+                                            const void *z, void *products, void *out_a, void *out_b) {
+    if (!ctx || t < 0 || t > 40 || log2_m0 < 1 || log2_m0 > 40 || t >= log2_m0 || (t && !newest_challenge) ||
+        !z || !products || !out_a || !out_b)
+        return VMPC_E_INVAL;
+    fr_arg a;
+    memset(&a, 0, sizeof a);
+    if (t) VMPC_CHECK(fr_arg_from(newest_challenge, a));
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    vmpc_stage_scope s(ctx, "fr_tail_scalars");
+    k_fr_tail_scalars_inc<<<fr_grid((size_t)1 << log2_m0), FR_BLOCK, 0, ctx->stream>>>(
+        a, t, log2_m0, (const uint32_t *)z, (uint32_t *)products, (uint32_t *)out_a, (uint32_t *)out_b);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }

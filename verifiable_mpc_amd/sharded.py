@@ -189,11 +189,13 @@ def protocol_5_prover(crs, P, L, y, x, gamma, gf, r, rho):
 
     log2_n = crs.N.bit_length() - 1
     challenges, round_i = [], 0
+    products = ScalarVector.empty(crs.N, ctx)                   # challenge products per generator
     while True:
         half = len(z_hat) // 2
         z_l, z_r, gamma_a, gamma_b = cp._round_prover_scalars(L_tilde, z_hat, half, gf)
         v_a, v_b = ScalarVector.empty(crs.N, ctx), ScalarVector.empty(crs.N, ctx)
-        ctx.fr_tail_scalars(challenges, log2_n, z_hat.ptr, v_a.ptr, v_b.ptr)
+        ctx.fr_tail_scalars_inc(challenges[-1] if challenges else 0, len(challenges), log2_n, z_hat.ptr,
+                                products.ptr, v_a.ptr, v_b.ptr)
         A_i, B_i = crs.commit([(v_a, gamma_a), (v_b, gamma_b)])
         proof["A" + str(round_i)], proof["B" + str(round_i)] = A_i, B_i
         c = transcript.round_challenge(round_i, A_i, B_i, None, crs.k, None, None)
