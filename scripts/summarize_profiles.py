@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def counter_avgs(dirname, counter):
     rows = {}
-    for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+    paths = sorted(glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True),
+                   key=os.path.getmtime)
+    for path in paths[-1:]:          # a tag profiled twice leaves two files: the newest wins
         with open(path) as f:
             for r in csv.DictReader(f):
                 if r.get("Counter_Name") != counter:
@@ -32,9 +34,10 @@ def main():
     out = os.path.join(ROOT, "gpurun_out")
     prof = os.path.join(ROOT, "profiles")
     shutil.copy(os.path.join(out, f"bench_{tag}.json"), os.path.join(prof, f"{tag}_bench.json"))
-    stats = glob.glob(os.path.join(out, f"prof_{tag}", "**", "*kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(os.path.join(out, f"prof_{tag}", "**", "*kernel_stats.csv"), recursive=True),
+                   key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[0], os.path.join(prof, f"{tag}_msm_n2^20_kernel_stats.csv"))
+        shutil.copy(stats[-1], os.path.join(prof, f"{tag}_msm_n2^20_kernel_stats.csv"))
     fetch = counter_avgs(os.path.join(out, f"pmc_fetch_{tag}"), "FETCH_SIZE")
     write = counter_avgs(os.path.join(out, f"pmc_write_{tag}"), "WRITE_SIZE")
     kernels = {}
