@@ -370,6 +370,39 @@ def test_fr_vector_ops(nat, ctx, n):
     assert nat.array_to_ints(ctx.download(dx.ptr, 32 * n, (n, 32))) == [(c * b + a) % ELL for a, b in zip(x, y)]
 
 
+def test_tail_scalars_incremental_equals_direct(nat, ctx):
+    """k_fr_tail_scalars (all pending challenges at once) and its round-by-round form
+    (products carried in device memory) give the same A_i / B_i scalars, and both match the
+    definition: s[j] = prod_{r<t} (c_r if bit (log2_m0-1-r) of j is 0)."""
+    rng = random.Random(55)
+    log2_m0 = 6
+    m0 = 1 << log2_m0
+    prod = ctx.alloc(32 * m0)
+    cs = []
+    for t in range(log2_m0 - 1):
+        m = m0 >> t
+        h = m // 2
+        z = [rng.randrange(ELL) for _ in range(m)]
+        dz = ctx.upload(sc_bytes(nat, z))
+        a1, b1, a2, b2 = (ctx.alloc(32 * m0) for _ in range(4))
+        ctx.fr_tail_scalars(cs, log2_m0, dz.ptr, a1.ptr, b1.ptr)
+        ctx.fr_tail_scalars_inc(cs[-1] if cs else 0, t, log2_m0, dz.ptr, prod.ptr, a2.ptr, b2.ptr)
+        ctx.sync()
+        A1, B1 = (nat.array_to_ints(ctx.download(x.ptr, 32 * m0, (m0, 32))) for x in (a1, b1))
+        A2, B2 = (nat.array_to_ints(ctx.download(x.ptr, 32 * m0, (m0, 32))) for x in (a2, b2))
+        assert A1 == A2 and B1 == B2, t
+        for j in range(m0):
+            s = 1
+            for r, c in enumerate(cs):
+                if ((j >> (log2_m0 - 1 - r)) & 1) == 0:
+                    s = s * c % ELL
+            u = j & (m - 1)
+            wa = z[u - h] * s % ELL if u >= h else 0
+            wb = z[u + h] * s % ELL if u < h else 0
+            assert (A1[j], B1[j]) == (wa, wb), (t, j)
+        cs.append(rng.randrange(ELL))
+
+
 def test_transcript_text(nat, ctx):
     """device-formatted text == the oracle's str() restatement (pivot.py:134)."""
     rng = random.Random(16)
