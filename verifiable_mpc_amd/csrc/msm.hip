@@ -388,8 +388,9 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
         // "prefetch".  A hand-scheduled version (inline-asm loads + manual s_waitcnt after the 7
         // multiplications, 140 VGPRs, 3 waves) measured the same 0.61 ms for this kernel and 0.76
         // instead of 0.85 ms on the 2 GiB fixed-base table: not worth carrying loads the compiler
-        // cannot see.  Initialising the accumulator from the first term (1M instead of 7M) lost to
-        // register pressure.
+        // cannot see.  Staging the gather through LDS with LDS-DMA (global_load_lds_dwordx4 into a
+        // [piece][lane] stage, no VGPR cost) measured 1.07 ms.  Initialising the accumulator from the
+        // first term (1M instead of 7M) lost to register pressure.
         uint32_t jn = j + 1 < len ? j + 1 : j;
         uint32_t en = sorted[lo + jn];
         ge_niels qn = niels_ld(niels, en);
