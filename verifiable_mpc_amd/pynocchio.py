@@ -145,26 +145,50 @@ class _KeyVector:
 
     def __init__(self, ctx, points):
         enc = [_as_bytes(p) for p in points]
-        self.group = enc[0][0]
-        assert all(g == self.group for g, _ in enc), "mixed groups in one key vector"
-        self.width = 64 if self.group == 1 else 128
-        self.n = len(points)
-        pts = np.frombuffer(b"".join(b for _, b in enc), dtype=np.uint8).reshape(-1, self.width)
-        dp = ctx.upload(pts)
-        if ctx.bn256_validate(self.group, dp.ptr, self.n):
+        group = enc[0][0]
+        assert all(g == group for g, _ in enc), "mixed groups in one key vector"
+        width = 64 if group == 1 else 128
+        pts = np.frombuffer(b"".join(b for _, b in enc), dtype=np.uint8).reshape(-1, width)
+        self._init_device(ctx, group, ctx.upload(pts), len(points))
+
+    @classmethod
+    def from_device(cls, ctx, group, points_buf, n):
+        """from n affine points already in device memory (64 / 128 bytes each)"""
+        self = cls.__new__(cls)
+        self._init_device(ctx, group, points_buf, n)
+        return self
+
+    def _init_device(self, ctx, group, dp, n):
+        self.group, self.n = group, n
+        self.width = 64 if group == 1 else 128
+        if ctx.bn256_validate(group, dp.ptr, n):
             raise _native.VmpcError(_native.E_NOTONCURVE, "pynocchio.PreparedKey")
-        self.table = ctx.bn256_table_build(self.group, dp.ptr, self.n)
+        self.table = ctx.bn256_table_build(group, dp.ptr, n)
         ctx.sync()
 
-    def msm(self, ctx, scalars):
-        m = len(scalars)
+    def launch(self, ctx, head, head_n, tail=()):
+        """enqueue sum over the first head_n + len(tail) points: `head` is a device buffer of head_n
+        scalars shared by several sums, `tail` a few host ints that follow them.  -> pending handle"""
+        m = head_n + len(tail)
         assert m <= self.n
         jw = 3 * self.width // 2
-        ds, out = ctx.upload(_native.ints_to_array([int(s) % ORDER for s in scalars], 32)), ctx.alloc(jw)
+        ds, out = ctx.alloc(max(32, 32 * m)), ctx.alloc(jw)
+        if head_n:
+            ctx.copy(ds.ptr, head.ptr, 32 * head_n)
+        if tail:
+            ctx.upload_into(ds.ptr + 32 * head_n, _native.ints_to_array([int(s) % ORDER for s in tail], 32))
         ctx.bn256_table_msm(self.group, self.table.ptr, self.n, ds.ptr, m, None, out.ptr)
+        return ctx, out, jw, ds
+
+    def result(self, pending):
+        ctx, out, jw, _ = pending
         ctx.sync()
         # the sum comes back in Jacobian coordinates; the one inversion is O(1) host glue
         return _from_jacobian(self.group, ctx.download(out.ptr, jw).tobytes())
+
+    def msm(self, ctx, scalars):
+        head = ctx.upload(_native.ints_to_array([int(s) % ORDER for s in scalars], 32)) if scalars else None
+        return self.result(self.launch(ctx, head, len(scalars)))
 
 
 class PreparedKey:
@@ -190,15 +214,26 @@ class PreparedKey:
 
 
 def _compute_proof_prepared(key, c, h, deltas):
-    cm = [int(c[i]) for i in key.mid]
-    proof = {}
-    for name, (_, zk) in _ELEMENTS.items():
-        scalars = list(cm)
-        if deltas is not None:
-            scalars += [int(getattr(deltas, attr)) for attr, _ in zk]
-        proof[name] = key.vectors[name].msm(key.ctx, scalars)
-    proof["h*g1"] = key.vectors["h*g1"].msm(key.ctx, [int(h.coeffs[i]) for i in range(0, len(h))])
-    return proof
+    """The eight sums over a prepared key: the shared `c_mid` scalars are converted and uploaded once,
+    the sums run on three streams (their bucket reductions and recombinations are latency chains that
+    overlap the next sum's bucket pass)."""
+    from .device import get_aux_context
+    ctx = key.ctx
+    n_mid = len(key.mid)
+    head = ctx.upload(_native.ints_to_array([int(c[i]) % ORDER for i in key.mid], 32)) if n_mid else None
+    streams = [ctx, get_aux_context(20), get_aux_context(21)]
+    pending = {}
+    for idx, (name, (_, zk)) in enumerate(_ELEMENTS.items()):
+        cctx = streams[idx % len(streams)]
+        if cctx is not ctx:
+            cctx.wait_for(ctx)
+        tail = [int(getattr(deltas, attr)) for attr, _ in zk] if deltas is not None else []
+        pending[name] = key.vectors[name].launch(cctx, head, n_mid, tail)
+    hv = key.vectors["h*g1"]
+    h_scalars = [int(h.coeffs[i]) for i in range(0, len(h))]
+    h_head = ctx.upload(_native.ints_to_array([s % ORDER for s in h_scalars], 32)) if h_scalars else None
+    pending["h*g1"] = hv.launch(ctx, h_head, len(h_scalars))
+    return {name: key.vectors[name].result(p) for name, p in pending.items()}
 
 
 def compute_proof(qap, c, h, evalkey, deltas=None):
