@@ -129,6 +129,10 @@ int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t 
  * partial commitments; also A * Q^c * B^(c^2) style products once the powers are points) */
 int vmpc_points_sum_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, void *out_ext,
                         void *out_affine);
+/* k such sums at once: point i of sum j at ext_points + 128 * (i * k + j) - the layout an all-gather of
+ * k partial points per rank produces (A_i and B_i of a round: k = 2); outputs consecutive */
+int vmpc_points_sum_many_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, size_t k, void *out_ext,
+                             void *out_affine);
 
 /* element-wise `base_i ** n_i` replaying the reference's operation sequence (ge25519.cuh):
  * bases are projective (96 B) or, with bases_affine != 0, affine (64 B, Z = 1); a single

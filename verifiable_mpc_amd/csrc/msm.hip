@@ -603,17 +603,20 @@ k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
 }
 
 // ---- sum of m extended points in order (multi-GPU combine) --------------------------------
+// k independent sums in one launch (block j = sum j): point i of sum j sits at pts + 32 * (i * k + j),
+// i.e. the layout an all-gather of k points per rank produces
 __global__ void __launch_bounds__(64)
-k_points_sum(const uint32_t *__restrict__ pts, size_t m, uint32_t *__restrict__ out_ext,
+k_points_sum(const uint32_t *__restrict__ pts, size_t m, size_t k, uint32_t *__restrict__ out_ext,
              uint32_t *__restrict__ out_aff) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    const size_t j = blockIdx.x;
     ge_ext acc = ge_ext_identity();
-    for (size_t i = 0; i < m; i++) acc = ge_add(acc, ext_ld8(pts + 32 * i));   // packed inputs
-    if (out_ext) ext_st8(out_ext, acc);
+    for (size_t i = 0; i < m; i++) acc = ge_add(acc, ext_ld8(pts + 32 * (i * k + j)));   // packed inputs
+    if (out_ext) ext_st8(out_ext + 32 * j, acc);
     if (out_aff) {
         ge_aff a = ge_ext_to_affine(acc);
-        fe_st8(out_aff, a.x);
-        fe_st8(out_aff + 8, a.y);
+        fe_st8(out_aff + 16 * j, a.x);
+        fe_st8(out_aff + 16 * j + 8, a.y);
     }
 }
 
@@ -1156,8 +1159,19 @@ extern "C" int vmpc_points_sum_dev(vmpc_ctx *ctx, const void *ext_points, size_t
     if (!ctx || (m && !ext_points) || (!out_ext && !out_affine)) return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     vmpc_stage_scope s(ctx, "points_sum");
-    k_points_sum<<<1, 64, 0, ctx->stream>>>((const uint32_t *)ext_points, m, (uint32_t *)out_ext,
+    k_points_sum<<<1, 64, 0, ctx->stream>>>((const uint32_t *)ext_points, m, 1, (uint32_t *)out_ext,
                                            (uint32_t *)out_affine);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_points_sum_many_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, size_t k, void *out_ext,
+                                        void *out_affine) {
+    if (!ctx || k == 0 || k > 65535 || (m && !ext_points) || (!out_ext && !out_affine)) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    vmpc_stage_scope s(ctx, "points_sum");
+    k_points_sum<<<(unsigned)k, 64, 0, ctx->stream>>>((const uint32_t *)ext_points, m, k, (uint32_t *)out_ext,
+                                                     (uint32_t *)out_affine);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }

@@ -113,10 +113,19 @@ class ShardedCrs:
     # -- commitments ------------------------------------------------------------------------------------
     def commit(self, items):
         """items: [(v, gamma)] with v a ScalarVector of length N over g_hat and gamma the exponent of k
-        (None = no k term).  Returns the commitments, identical on every rank."""
+        (None = no k term).  Returns the commitments, identical on every rank.  One exchange for all of
+        them: every rank contributes len(items) partial points (128 bytes each)."""
         from .device import get_aux_context
-        ctx, W = self.ctx, self.world
-        keep, bufs, used = [], [], [ctx]
+        ctx, W, K = self.ctx, self.world, len(items)
+        # partial points, laid out [rank][item] as the all-gather will produce them
+        if self.loopback:
+            gathered, gptr, mine = ctx.alloc(128 * W * K), None, None
+            gptr = gathered.ptr
+        else:
+            mine = self.torch.zeros(128 * K, dtype=self.torch.uint8, device="cuda")
+            gathered = self.torch.zeros(128 * K * W, dtype=self.torch.uint8, device="cuda")
+            gptr = gathered.data_ptr()
+        keep, used = [], [ctx]
         for j, (v, gamma) in enumerate(items):
             assert len(v) == self.N
             cctx = ctx
@@ -124,41 +133,22 @@ class ShardedCrs:
                 cctx = get_aux_context()
                 cctx.wait_for(ctx)
                 used.append(cctx)
-            if self.loopback:
-                buf = ctx.alloc(128 * W)
-                for s in self.shards:
-                    keep.append(s.partial(cctx, v, gamma if s.index == 0 else None, buf.ptr + 128 * s.index))
-                bufs.append((buf, buf.ptr))
-            else:
-                s = self.shards[0]
-                part = self.torch.zeros(128, dtype=self.torch.uint8, device="cuda")
-                keep.append(s.partial(cctx, v, gamma if s.index == 0 else None, part.data_ptr()))
-                bufs.append((part, None))
-        for c in used[1:]:
-            c.sync()
-        out = []
+            for s in self.shards:
+                dst = (gptr + 128 * (s.index * K + j)) if self.loopback else (mine.data_ptr() + 128 * j)
+                keep.append(s.partial(cctx, v, gamma if s.index == 0 else None, dst))
+        for c in used:
+            c.sync()                                              # partial points are complete
         if not self.loopback:
-            ctx.sync()                                           # partial points are complete
-            gathered = []
-            for part, _ in bufs:
-                g = self.torch.zeros((W, 128), dtype=self.torch.uint8, device="cuda")
-                self.dist.all_gather_into_tensor(g.view(-1), part)      # the exchange: W x 128 bytes
-                gathered.append(g)
+            self.dist.all_gather_into_tensor(gathered, mine)      # the exchange: W x K x 128 bytes
             ev = self.torch.cuda.Event()
             ev.record(self.torch.cuda.current_stream())
             ev.synchronize()
-            bufs = [(g, g.data_ptr()) for g in gathered]
-        if self.loopback:
-            ctx.sync()
-        res = ctx.alloc(128 * len(bufs))
-        for j, (_, ptr) in enumerate(bufs):
-            ctx.points_sum(ptr, W, res.ptr + 128 * j, None)         # rank order: same bits everywhere
+        res = ctx.alloc(128 * K)
+        ctx.points_sum_many(gptr, W, K, res.ptr, None)            # rank order: same bits everywhere
         ctx.sync()
-        raw = ctx.download(res.ptr, 128 * len(bufs)).tobytes()
-        for j in range(len(bufs)):
-            out.append(Ed25519Point.from_proj_bytes(raw[128 * j:128 * j + 96]).normalize())
+        raw = ctx.download(res.ptr, 128 * K).tobytes()
         del keep
-        return out
+        return [Ed25519Point.from_proj_bytes(raw[128 * j:128 * j + 96]).normalize() for j in range(K)]
 
 
 def protocol_5_prover(crs, P, L, y, x, gamma, gf, r, rho):
