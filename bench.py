@@ -119,7 +119,7 @@ def prove_timing(vm, ctx, n_pow, rng):
 
 def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch):
     """AC20 Protocol 5 (compact transcript) with g_hat in `world` blocks, one per rank
-    (verifiable_mpc_amd/sharded.py): two all-gathers of 128-byte points per round."""
+    (verifiable_mpc_amd/sharded.py): one all-gather of two 128-byte points per rank and round."""
     from verifiable_mpc_amd import sharded
     N = 1 << n_pow
     n = N - 1

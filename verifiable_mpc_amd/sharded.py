@@ -5,7 +5,7 @@ one per rank (one process per GPU); every rank keeps the scalar vectors whole - 
 32 bytes per entry and their folds are O(N) - and computes, for every commitment of the proof,
 the partial sum over ITS block on its own fixed-base table (include/vmpc.h vmpc_msm_table_dev).
 The only exchange is an all-gather of 128-byte extended points - one for the announcement A,
-two per round for A_i and B_i (compressed_pivot.py:110, :41-42) - after which every rank adds the
+one per round carrying A_i and B_i together (compressed_pivot.py:110, :41-42) - after which every rank adds the
 G partial points in rank order with the same device routine, so all ranks hold bit-identical
 A_i, B_i, derive the same challenges, and need no broadcast.  The generators are never folded
 (compressed_pivot._tabulated explains why that is the cheaper form even on one GPU): round i
