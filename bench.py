@@ -117,6 +117,38 @@ def prove_timing(vm, ctx, n_pow, rng):
     return out
 
 
+def bn256_timing(vm, ctx, n_pow):
+    """BASELINE config 5: BN-256 G1 / twist sums of 2^n_pow terms (the Pinocchio prover's MSMs),
+    variable-base and over a prepared (tabulated) key vector; affine outputs.  Timing inputs: the
+    generator repeated with uniform scalars (parity is tests/test_gpu_bn256.py)."""
+    n = 1 << n_pow
+    p_mod = 65000549695646603732796438742359905742825358107623003571877145026864184071783
+    g1 = (1).to_bytes(32, "little") + (p_mod - 2).to_bytes(32, "little")
+    g2 = b"".join(v.to_bytes(32, "little") for v in (
+        64746500191241794695844075326670126197795977525365406531717464316923369116492,
+        21167961636542580255011770066570541300993051739349375019639421053990175267184,
+        17778617556404439934652658462602675281523610326338642107814333856843981424549,
+        20666913350058776956210519119118544732556678129809273996262322366050359951122))
+    rng = np.random.default_rng(7)
+    out = {}
+    for group, gen, width, tag in ((1, g1, 64, "g1"), (2, g2, 128, "g2")):
+        sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        sc[:, 31] &= 0x7F
+        dp, ds, res = ctx.upload(np.tile(np.frombuffer(gen, np.uint8), (n, 1))), ctx.upload(sc), ctx.alloc(width)
+        table = ctx.bn256_table_build(group, dp.ptr, n)
+        for name, fn in (("variable_base", lambda: ctx.bn256_msm(group, ds.ptr, dp.ptr, n, res.ptr)),
+                         ("prepared_key", lambda: ctx.bn256_table_msm(group, table.ptr, n, ds.ptr, n, res.ptr, None))):
+            fn()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            ctx.sync()
+            out[f"{tag}_{name}_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+        del table
+    return out
+
+
 def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch):
     """AC20 Protocol 5 (compact transcript) with g_hat in `world` blocks, one per rank
     (verifiable_mpc_amd/sharded.py): one all-gather of two 128-byte points per rank and round."""
@@ -315,6 +347,10 @@ def main():
                                       prove_timing(vm, ctx, 20, np.random.default_rng(99)).items()}
             except Exception as e:  # the headline metric must still be reported
                 line["ac20_n2^20"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                line["bn256_n2^18"] = {k: round(v, 2) for k, v in bn256_timing(vm, ctx, 18).items()}
+            except Exception as e:
+                line["bn256_n2^18"] = {"error": f"{type(e).__name__}: {e}"}
     sharded_info = None
     if dist and args.sharded_prove:
         # every rank takes part; a failure here must not cost the headline line
