@@ -149,6 +149,31 @@ def bn256_timing(vm, ctx, n_pow):
     return out
 
 
+def other_sizes_timing(vm, ctx, pows):
+    """One variable-base commitment alone at the other BASELINE sizes: config 2 (2^16), one GPU's share
+    of config 4 (2^21 of 2^24 over 8 GPUs) and 2^24 on a single GPU."""
+    group = vm.EllipticCurve("Ed25519", "projective")
+    rng = np.random.default_rng(11)
+    out = {}
+    for lg in pows:
+        n = 1 << lg
+        pts = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(rand_scalars(rng, n)),
+                                        keep_proj=False)
+        sc = vm.ScalarVector.from_array(rand_scalars(rng, n))
+        res = ctx.alloc(128)
+        ctx.msm(sc.ptr, pts.affine_ptr, n, None, None, 0, res.ptr, None)
+        ctx.sync()
+        reps = 10 if lg <= 21 else 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.msm(sc.ptr, pts.affine_ptr, n, None, None, 0, res.ptr, None)
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        out[f"n2^{lg}"] = {"ms": round(dt * 1e3, 3), "M_scalar_mults_per_s": round(n / dt / 1e6, 1)}
+        del pts, sc
+    return out
+
+
 def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch):
     """AC20 Protocol 5 (compact transcript) with g_hat in `world` blocks, one per rank
     (verifiable_mpc_amd/sharded.py): one all-gather of two 128-byte points per rank and round."""
@@ -347,6 +372,10 @@ def main():
                                       prove_timing(vm, ctx, 20, np.random.default_rng(99)).items()}
             except Exception as e:  # the headline metric must still be reported
                 line["ac20_n2^20"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                line["msm_other_sizes"] = other_sizes_timing(vm, ctx, (16, 21, 24))
+            except Exception as e:
+                line["msm_other_sizes"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 line["bn256_n2^18"] = {k: round(v, 2) for k, v in bn256_timing(vm, ctx, 18).items()}
             except Exception as e:
