@@ -11,7 +11,7 @@
  *  - plain pointers and sizes only; no torch / Python types;
  *  - scalars: 32 bytes little-endian, canonical residue < l (l = Ed25519 group order);
  *  - affine points: 64 bytes x||y little-endian, canonical residues < p = 2^255-19;
- *  - projective points: 96 bytes X||Y||Z (representative preserved, see ge25519.cuh);
+ *  - projective points: 96 bytes X||Y||Z (representative preserved, see ge25519.h);
  *  - extended points: 128 bytes X||Y||Z||T;
  *  - every function returns 0 on success or a negative VMPC_E_* code; the library never
  *    retains host pointers past a call and never draws randomness (the reference draws
@@ -134,7 +134,7 @@ int vmpc_points_sum_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, void *o
 int vmpc_points_sum_many_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, size_t k, void *out_ext,
                              void *out_affine);
 
-/* element-wise `base_i ** n_i` replaying the reference's operation sequence (ge25519.cuh):
+/* element-wise `base_i ** n_i` replaying the reference's operation sequence (ge25519.h):
  * bases are projective (96 B) or, with bases_affine != 0, affine (64 B, Z = 1); a single
  * base is broadcast when n_bases == 1.  signed_scalars != 0 applies the reference's
  * pivot._int convention (pivot.py:119-128): residues above l/2 act as negative exponents.

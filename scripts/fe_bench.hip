@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
-#include "../verifiable_mpc_amd/csrc/ge25519.cuh"
+#include "../verifiable_mpc_amd/csrc/ge25519.h"
 
 template <int V> __device__ __forceinline__ fe mulv(const fe &a, const fe &b) {
     if (V == 0) return fe_mul(a, b);

@@ -10,11 +10,11 @@
 #include <vector>
 
 #define VMPC_HD inline
-#include "../../verifiable_mpc_amd/csrc/fe25519.cuh"
-#include "../../verifiable_mpc_amd/csrc/ge25519.cuh"
-#include "../../verifiable_mpc_amd/csrc/fr.cuh"
-#include "../../verifiable_mpc_amd/csrc/fmt.cuh"
-#include "../../verifiable_mpc_amd/csrc/sw256.cuh"
+#include "../../verifiable_mpc_amd/csrc/fe25519.h"
+#include "../../verifiable_mpc_amd/csrc/ge25519.h"
+#include "../../verifiable_mpc_amd/csrc/fr.h"
+#include "../../verifiable_mpc_amd/csrc/fmt.h"
+#include "../../verifiable_mpc_amd/csrc/sw256.h"
 
 static void parse_hex(const std::string &h, uint32_t *out, int limbs) {
     for (int i = 0; i < limbs; i++) out[i] = 0;

@@ -349,3 +349,38 @@ def test_proof_survives_the_wire(vm, golden_small, monkeypatch):
     back, mode = wire.deserialize_proof(wire.serialize_proof(proof), gf)
     assert mode == "reference"
     assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, back, gf) is True
+
+
+@pytest.mark.parametrize("mode", ["reference", "compact"])
+def test_verifier_rejects_points_outside_the_group(vm, golden_small, monkeypatch, mode):
+    """Prover-supplied points that are off the curve, or on it but outside the order-l subgroup, make
+    the verifier return False before any kernel does arithmetic on them (the niels mixed addition
+    absorbs (0, 0); exponents are reduced mod l, compressed_pivot.py:66 does not reduce c**2)."""
+    from verifiable_mpc_amd import compressed_pivot as cp
+    case = golden_small["p5"][2]
+    group, gens = build_generators(vm, case, monkeypatch, case["seed"] + 1)
+    gf = vm.GF(group.order)
+    x = [gf(h2i(v)) for v in case["x"]]
+    L = vm.pivot.LinearForm([gf(h2i(v)) for v in case["L"]])
+    gamma, y = h2i(case["gamma"]), gf(h2i(case["y"]))
+    P = vm.pivot.vector_commitment(x, gamma, gens["g"], gens["h"])
+    proof = cp.protocol_5_prover(gens, P, L, y, x, gamma, gf, transcript=mode)
+    assert cp.protocol_5_verifier(gens, P, L, y, proof, gf, transcript=mode) is True
+    t4 = vm.Ed25519Point((pow(2, (ed.P - 1) // 4, ed.P), 0, 1), check=True)       # order 4
+    t2 = vm.Ed25519Point((0, ed.P - 1, 1), check=True)                            # order 2
+    off = vm.Ed25519Point((0, 0, 1))                                             # not on the curve
+    assert cp._valid_group_elements([P, proof["A"], vm.Ed25519Point.identity]) is True
+    for bad_pt in (off, t4, t2, vm.Ed25519Point.operation(proof["A0"], t4),
+                   vm.Ed25519Point((5, 7, 0))):                                   # Z = 0
+        assert cp._valid_group_elements([proof["A"], bad_pt]) is False
+        for key in ("A0", "B1", "A"):
+            bad = dict(proof)
+            bad[key] = bad_pt
+            assert cp.protocol_5_verifier(gens, P, L, y, bad, gf, transcript=mode) is False
+        assert cp.protocol_5_verifier(gens, bad_pt, L, y, proof, gf, transcript=mode) is False
+    # Protocol 4 called on its own validates Q and the round points too
+    g_hat = gens["g"] + [gens["h"]]
+    Lt = vm.pivot.LinearForm(list(L.coeffs) + [0])
+    bad = {k_: v for k_, v in proof.items() if k_ not in ("t", "A")}
+    bad["B0"] = t4
+    assert cp.protocol_4_verifier(g_hat, gens["k"], P, Lt, gf, bad, transcript=mode) is False

@@ -1,4 +1,4 @@
-"""CPU check of the device math headers (fe25519/ge25519/fr/fmt .cuh).
+"""CPU check of the device math headers (fe25519/ge25519/fr/fmt .h).
 
 The headers are `__host__ __device__`; this test builds them with g++ into a small
 harness (tests/native/host_math_test.cpp) and compares every operation with the
@@ -21,12 +21,20 @@ P, ELL = ed.P, ed.ELL
 
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
+    # AddressSanitizer + UndefinedBehaviorSanitizer on the CPU build of the device headers (SURVEY.md
+    # section 5: sanitizers run here; GPU ASan is not available on the pool).  Unsigned wrap-around is
+    # intended arithmetic in the limb code and is not part of -fsanitize=undefined.
     exe = str(tmp_path_factory.mktemp("native") / "host_math_test")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, SRC])
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-o", exe, SRC])
 
     def run(lines):
-        out = subprocess.run([exe], input="\n".join(lines) + "\nquit\n", text=True,
-                             capture_output=True, check=True).stdout.strip().split("\n")
+        res = subprocess.run([exe], input="\n".join(lines) + "\nquit\n", text=True, capture_output=True,
+                             env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0",
+                                      UBSAN_OPTIONS="print_stacktrace=1"))
+        assert res.returncode == 0 and "runtime error" not in res.stderr and "AddressSanitizer" not in res.stderr, \
+            res.stderr[-2000:]
+        out = res.stdout.strip().split("\n")
         assert len(out) == len(lines), (len(out), len(lines))
         return out
     return run
@@ -74,7 +82,7 @@ def _limbs_value(limbs):
 def test_field_mul_operand_contract(harness):
     """fe_mul(f, g) with every even limb of f just below 2^28 and of g just below 2^27.2 (product of
     maxima 2^55.2), fe_sqr with even limbs just below 2^27.6; odd limbs one bit less: the
-    documented lazy-operand bounds of fe25519.cuh."""
+    documented lazy-operand bounds of fe25519.h."""
     rng = random.Random(11)
     fmax, gmax, smax = (1 << 28) - 1, int(2 ** 27.2), int(2 ** 27.6)
 

@@ -45,3 +45,14 @@ def test_proof_roundtrip():
     with pytest.raises(ValueError):
         wire.deserialize_proof(blob + b"\x00", gf)
     assert wire.proof_size(19) == 9 + 32 * 40 + 1 + 64      # N = 2^20: 1354 bytes
+    # a point with a torsion component is a valid ENCODING but not a proof element: the order-4 point
+    # (sqrt(-1), 0) added to A0 keeps it on the curve and takes it out of the order-l group
+    t4 = vm.Ed25519Point((pow(2, (ed.P - 1) // 4, ed.P), 0, 1), check=True)
+    assert not wire.in_prime_subgroup(t4) and wire.in_prime_subgroup(proof["A0"])
+    bad = dict(proof)
+    bad["A0"] = vm.Ed25519Point.operation(proof["A0"], t4)
+    blob = wire.serialize_proof(bad, "compact")
+    with pytest.raises(ValueError, match="subgroup"):
+        wire.deserialize_proof(blob, gf)
+    back, _ = wire.deserialize_proof(blob, gf, check_subgroup=False)     # the verifier's job then
+    assert back["A0"] == bad["A0"]

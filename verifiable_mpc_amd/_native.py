@@ -226,8 +226,11 @@ class PendingText:
     """Transcript text being formatted and copied on a context's stream (PointVector /
     ScalarVector .text_begin()); result() synchronises that stream."""
 
-    def __init__(self, ctx, pinned, dev, cap):
+    def __init__(self, ctx, pinned, dev, cap, keepalive=None):
         self.ctx, self.pinned, self.dev, self.cap = ctx, pinned, dev, cap
+        # the SOURCE vector's device block belongs to another context's block cache: hold it until this
+        # stream has been synchronised, so that it cannot be recycled under the formatter's reads
+        self.keepalive = keepalive
 
     def result(self):
         if self.dev is not None:
@@ -235,6 +238,7 @@ class PendingText:
             n = int(np.frombuffer(self.pinned.array[:8], dtype=np.uint64)[0])
             self._view = self.pinned.array[16:16 + n]
             self.dev = None
+            self.keepalive = None
         return self._view
 
     def __del__(self):
@@ -243,6 +247,7 @@ class PendingText:
             if self.pinned is not None and self.ctx is not None and self.ctx.handle:
                 self.ctx.sync()
                 self._view = None
+                self.keepalive = None
                 self.ctx._give_pinned(self.cap + 16, self.pinned)
                 self.pinned = None
         except Exception:
@@ -273,8 +278,9 @@ class Context:
         # until the NEXT text_begin of the same size class on this context
         self._pinned.setdefault(_size_class(nbytes), []).append(buf)
 
-    def format_begin(self, kind, src_ptr, n, is_signed=True):
-        """enqueue formatting + D2H of a vector's transcript text; returns a PendingText"""
+    def format_begin(self, kind, src_ptr, n, is_signed=True, keepalive=None):
+        """enqueue formatting + D2H of a vector's transcript text; returns a PendingText.
+        `keepalive`: the owner of `src_ptr` when it lives in another context's block cache"""
         per = (3 * 78 + 8) if kind == "points" else (78 + 3)
         cap = n * per + 16
         pinned = self._take_pinned(cap + 16)
@@ -289,7 +295,7 @@ class Context:
                                                         1 if is_signed else 0, ctypes.c_void_p(dev.ptr),
                                                         cap, host_text, host_len)
         _check(rc, "vmpc_format_async")
-        return PendingText(self, pinned, dev, cap)
+        return PendingText(self, pinned, dev, cap, keepalive)
 
     def _take_block(self, cap):
         lst = self._cache.get(cap)

@@ -25,7 +25,7 @@ def _stale(target, sources):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "hipcc")
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".cuh")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "vmpc.h"))
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)

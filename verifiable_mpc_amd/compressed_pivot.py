@@ -67,6 +67,47 @@ def _same_residue(a, b, order):
     return (pivot._residue(a) - pivot._residue(b)) % order == 0
 
 
+def _valid_group_elements(points, ctx=None):
+    """True iff every point is a canonical element of the order-l subgroup of Ed25519.
+
+    The verifier's inputs from the prover (P, A, A_i, B_i) are untrusted.  The kernels assume curve
+    points (the niels mixed addition absorbs (0, 0)) and reduce exponents mod l, which equals the
+    reference's unreduced `B ** (c ** 2)` (compressed_pivot.py:66,180) only on the order-l subgroup -
+    so anything else is rejected up front: on-curve + canonical coordinates (vmpc_points_validate_dev),
+    then (l - 1) * X == -X for all of them in one launch of the ladder kernel (vmpc_repeat_dev)."""
+    import numpy as np
+    from .device import get_context
+    from .groups import ORDER, P as FIELD_P
+    ctx = ctx or get_context()
+    try:
+        pts = [_pt(p) for p in points]
+        raw = b"".join(p.to_affine_bytes() for p in pts)
+    except Exception:
+        return False
+    n = len(pts)
+    if n == 0:
+        return True
+    buf = ctx.upload(np.frombuffer(raw, np.uint8))
+    if ctx.validate_points(buf.ptr, n):
+        return False
+    sc = ctx.upload(np.frombuffer((ORDER - 1).to_bytes(32, "little") * n, np.uint8))
+    out = ctx.alloc(64 * n)
+    ctx.repeat(buf.ptr, n, True, sc.ptr, n, False, None, out.ptr)
+    got = ctx.download(out.ptr, 64 * n).tobytes()
+    for i in range(n):
+        x = int.from_bytes(raw[64 * i:64 * i + 32], "little")
+        want = ((FIELD_P - x) % FIELD_P).to_bytes(32, "little") + raw[64 * i + 32:64 * i + 64]
+        if got[64 * i:64 * i + 64] != want:
+            return False
+    return True
+
+
+def _proof_points(proof):
+    """A, A_0.., B_0.. of a Protocol-4/5 proof dict (whatever is present)"""
+    return [v for key, v in proof.items()
+            if key == "A" or (key[:1] in "AB" and key[1:].isdigit())]
+
+
 # ---- scalar-side strategies --------------------------------------------------------------------
 
 def _on_device(*vs):
@@ -100,15 +141,20 @@ def _sc_bytes(v):
 
 
 def generators_digest(generators):
-    """Digest of the CRS for the compact transcript; cached on the device vector."""
+    """Digest of the CRS (g, h, k) for the compact transcript.  Cached on the device vector g, keyed
+    by the h and k it was computed with: the same g under another h or k is another CRS."""
     g = generators["g"]
-    if isinstance(g, PointVector) and g._digest is not None:
-        return g._digest
+    h, k = _pt(generators["h"]), _pt(generators["k"])
+    key = (h.to_affine_bytes(), k.to_affine_bytes())
+    if isinstance(g, PointVector) and g._digest is not None and key in g._digest:
+        return g._digest[key]
     gv = pivot._points_on_device(g)
-    full = PointVector(gv.a, None, gv.ctx).concat([_pt(generators["h"]), _pt(generators["k"])])
+    full = PointVector(gv.a, None, gv.ctx).concat([h, k])
     d = _chunked_digest_dev(b"vmpc-ac20/gens/v1", full.ctx, full.affine_ptr, 64 * len(full))
     if isinstance(g, PointVector):
-        g._digest = d
+        if g._digest is None:
+            g._digest = {}
+        g._digest[key] = d
     return d
 
 
@@ -350,9 +396,13 @@ def _protocol_4_verifier_compact(g_hat, k, Q, L_tilde, gf, proof, round_i, trans
     return bool(pending.result() == Q_final)
 
 
-def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=None):
-    """Non-interactive Protocol 4, verifier (compressed_pivot.py:148-202)."""
+def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=None, _checked=False):
+    """Non-interactive Protocol 4, verifier (compressed_pivot.py:148-202).  Returns False (never
+    raises) for a proof whose points are not elements of the order-l group."""
     g_hat = pivot._points_on_device(g_hat)
+    if not _checked and not _valid_group_elements(
+            _proof_points(proof) + ([] if isinstance(Q, (_LazyQ, _LazyPoint)) else [Q]), g_hat.ctx):
+        return False
     k = _pt(k)
     Q = Q if isinstance(Q, (_LazyQ, _LazyPoint)) else _pt(Q)
     if not isinstance(transcript, _Transcript):
@@ -500,6 +550,9 @@ def protocol_5_verifier(generators, P, L, y, proof, gf, transcript=None):
     """Compressed Sigma-protocol Pi_c, verifier (compressed_pivot.py:205-239)."""
     mode = transcript or TRANSCRIPT
     g, h, k = generators["g"], _pt(generators["h"]), _pt(generators["k"])
+    if not _valid_group_elements([P] + _proof_points(proof),
+                                 g.ctx if isinstance(g, PointVector) else None):
+        return False
     P = _pt(P)
     order = gf.order
     n = len(g)
@@ -515,4 +568,4 @@ def protocol_5_verifier(generators, P, L, y, proof, gf, transcript=None):
         Q = Q.point()
     L_tilde = _extend_form(L, c1)
     return protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof,
-                               transcript=_p5_setup(generators, k, seed, mode, order))
+                               transcript=_p5_setup(generators, k, seed, mode, order), _checked=True)

@@ -2,7 +2,7 @@
 // one-shot entry points of include/vmpc.h.
 #include <stdlib.h>
 
-#include "common.cuh"
+#include "common.h"
 
 #define VMPC_IGNORE(expr) ((void)(expr))
 

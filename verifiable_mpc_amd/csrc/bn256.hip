@@ -11,9 +11,9 @@
 // explicit handling of the exceptional cases (P+P, P-P, infinity), which - unlike the complete
 // Edwards law - can occur in bucket sums.
 // Entries are affine points in Montgomery form (64 B / 128 B), accumulators Jacobian (96 B / 192 B).
-#include "common.cuh"
+#include "common.h"
 #include "msm_sort.h"
-#include "sw256.cuh"
+#include "sw256.h"
 
 #define BN_B3_MONT                                                                             \
     { 0x29d50ffdu, 0x8630a1e2u, 0x5c7373e9u, 0x583653eau, 0x1867b356u, 0xabd06066u, 0x8ace581fu,  \

@@ -1,7 +1,7 @@
 // Element-wise kernels that REPLAY the reference's group-operation sequences
 // (projective add-2008-bbjlp / dbl-2008-bbjlp, right-to-left `repeat`) so that the
 // un-normalised coordinates entering the reference's Fiat-Shamir pre-image are
-// reproduced bit for bit (see ge25519.cuh):
+// reproduced bit for bit (see ge25519.h):
 //   vmpc_fold_dev         g'_i = (g_l[i] ** c) * g_r[i]     compressed_pivot.py:64 / :178
 //   vmpc_repeat_dev       base ** r_i, g[i] ** x_i          circuit_sat_r1cs.py:64-70,81; pivot.py:143
 //   vmpc_tree_reduce_dev  pivot.list_mul                    pivot.py:26-28
@@ -10,11 +10,11 @@
 // wave-uniform scalar (no divergence); repeat predicates per lane.
 #include <stdlib.h>
 
-#include "common.cuh"
-#include "fe25519.cuh"
-#include "fr.cuh"
-#include "ge25519.cuh"
-#include "quad.cuh"
+#include "common.h"
+#include "fe25519.h"
+#include "fr.h"
+#include "ge25519.h"
+#include "quad.h"
 
 #define EX_BLOCK 256
 // vectors up to this many elements use four lanes per element (latency-bound regime)

@@ -22,7 +22,7 @@
 // max(f) * max(g) <= 2^55.2 (then the ten 64-bit column sums, each term carrying at most the
 // factors 19 * 2, stay below 2^64, and 19 * g_j fits 32 bits).  Reduced values, one lazy sum or
 // difference of reduced values (< 2^27.6), and `lazy +- reduced` against a reduced partner all
-// satisfy it; the call sites in ge25519.cuh state their bounds.  fe_sqr(f): limbs < 2^27.6.
+// satisfy it; the call sites in ge25519.h state their bounds.  fe_sqr(f): limbs < 2^27.6.
 // tests/native/host_math_test.cpp drives both at these bounds (command `rawmul`).
 //
 // Memory format (`fe8`): 32 bytes little-endian = 8 LE uint32 words, canonical residue < p on
@@ -36,7 +36,7 @@
 #include <stdint.h>
 
 #ifndef VMPC_HD
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define VMPC_HD __host__ __device__ __forceinline__
 #else
 #define VMPC_HD inline
@@ -394,7 +394,7 @@ VMPC_HD fe fe_const_d2() {
              0x19ce331u, 0x1c56dffu, 0x0901b67u}};
     return r;
 }
-// ---- shared helper of the Montgomery fields (sw256.cuh): 96-bit multiply-accumulate ----------------
+// ---- shared helper of the Montgomery fields (sw256.h): 96-bit multiply-accumulate ----------------
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(VMPC_NO_DEVICE_ASM)
 #define VMPC_DEVICE_ASM 1
 __device__ __forceinline__ void fe_mac96(uint64_t &acc, uint32_t &ovf, uint32_t a, uint32_t b) {

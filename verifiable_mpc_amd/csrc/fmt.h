@@ -9,8 +9,8 @@
 //   scalar -> signed decimal of the residue in (-l/2, l/2]
 // [mpyc-recall: formats as restated in oracle/ed25519_ref.py pt_repr / scalar_repr]
 #pragma once
-#include "fe25519.cuh"
-#include "fr.cuh"
+#include "fe25519.h"
+#include "fr.h"
 
 // v (256-bit) -> 9 base-10^9 chunks, least significant first.  Returns #decimal digits.
 VMPC_HD int u256_to_chunks(const uint32_t v[8], uint32_t chunk[9]) {

@@ -6,9 +6,9 @@
 // round 0.  Two kernels per vector: item lengths -> exclusive scan -> write at offsets.
 // Output layout: "item0, item1, ..., item{n-1}, " (each item followed by ", "); the host
 // feeds SHA-256 with the brackets and without the last separator.
-#include "common.cuh"
-#include "fmt.cuh"
-#include "scan.cuh"
+#include "common.h"
+#include "fmt.h"
+#include "scan.h"
 
 #define FMT_BLOCK 256
 

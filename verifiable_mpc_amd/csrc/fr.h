@@ -7,7 +7,7 @@
 //   L(z) = sum coeffs[i]*values[i]       verifiable_mpc/ac20/pivot.py:84-92
 #pragma once
 #include <stdint.h>
-#include "fe25519.cuh"  // VMPC_HD
+#include "fe25519.h"  // VMPC_HD
 
 struct fr {
     uint32_t v[8];

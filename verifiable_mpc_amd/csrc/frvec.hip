@@ -5,8 +5,8 @@
 //   vmpc_fr_dot_dev    sum a_i*b_i        LinearForm evaluation (pivot.py:84-92), L~(0||z_l), L~(z_r||0)
 // HBM-bound streaming kernels: 32-B elements, two 16-B accesses per lane, grid capped at
 // 2048 workgroups with a grid-stride loop.
-#include "common.cuh"
-#include "fr.cuh"
+#include "common.h"
+#include "fr.h"
 
 #define FR_BLOCK 256
 #define FR_MAX_GRID 2048

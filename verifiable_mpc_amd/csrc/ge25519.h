@@ -16,7 +16,7 @@
 //      arithmetic is exact, so replaying the same formula sequence yields the same
 //      residues.  [mpyc-recall: formulas as restated in oracle/ed25519_ref.py]
 #pragma once
-#include "fe25519.cuh"
+#include "fe25519.h"
 
 struct ge_ext {   // extended: x = X/Z, y = Y/Z, T = XY/Z
     fe X, Y, Z, T;

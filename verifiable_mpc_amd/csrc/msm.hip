@@ -22,12 +22,12 @@
 // HBM traffic is dominated by the 96-B niels gathers (W per term) and the 4-B sorted
 // indices; the algorithmic bytes of SURVEY.md 8d are 96 B per term (32 B scalar + 64 B
 // point).  Arithmetic is 32x32->64 integer multiply-add; no MFMA.
-#include "common.cuh"
-#include "fe25519.cuh"
-#include "fr.cuh"
-#include "ge25519.cuh"
-#include "scan.cuh"
-#include "quad.cuh"
+#include "common.h"
+#include "fe25519.h"
+#include "fr.h"
+#include "ge25519.h"
+#include "scan.h"
+#include "quad.h"
 #include "msm_sort.h"
 
 // niels record stride in 32-bit words: 24 = packed 96 B, 32 = one 128-B line per gather
@@ -509,10 +509,10 @@ k_msm_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ 
 // does the q-th product of each level and the four results are exchanged with DPP quad_perm
 // broadcasts (VALU, no LDS).  Per point operation the critical path is 2 field
 // multiplications instead of 8-9.
-// The accumulator stays LANE-DISTRIBUTED (quad.cuh): lane q of every quad holds coordinate q of
+// The accumulator stays LANE-DISTRIBUTED (quad.h): lane q of every quad holds coordinate q of
 // (X, Y, Z, T).  Second level of both operations: lane 0: E*F = X3, lane 1: G*H = Y3, lane 2: G*F = Z3,
 // lane 3: E*H = T3 - two-way operand selections, and the products land where the next operation reads
-// them.  Sums stay lazy as in ge25519.cuh (only F is carried).  448 instructions per doubling instead
+// them.  Sums stay lazy as in ge25519.h (only F is carried).  448 instructions per doubling instead
 // of 733 for the replicated form with four-way picks and carried sums.
 __device__ __forceinline__ fe quadD_level2(const fe &E, const fe &F, const fe &G, const fe &H, int q) {
     fe u = quad_sel(G, E, q == 0 || q == 3);

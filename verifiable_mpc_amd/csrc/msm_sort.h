@@ -4,7 +4,7 @@
 // G1/G2 MSMs (bn256.hip); the curve-specific kernels (entry preparation, bucket accumulation,
 // bucket reduction, window recombination) live with their curve.
 #pragma once
-#include "common.cuh"
+#include "common.h"
 
 #define MSM_MAX_C 16
 #define MSM_BLOCK 256

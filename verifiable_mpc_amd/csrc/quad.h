@@ -5,7 +5,7 @@
 // one point: lane q computes the q-th product of a level and the results are exchanged with
 // DPP quad_perm broadcasts (plain VALU moves, no LDS).  EXEC must be full within the quad.
 #pragma once
-#include "fe25519.cuh"
+#include "fe25519.h"
 
 __device__ __forceinline__ fe quad_bcast(const fe &a, int src /*0..3, compile-time after unroll*/) {
     fe r;

@@ -2,7 +2,7 @@
 // bucket start offsets of the Pippenger sort and for text offsets of the transcript
 // formatter.  Three-kernel reduce-then-scan; inputs of up to 2048 * 2048 * 2048 items.
 #pragma once
-#include "common.cuh"
+#include "common.h"
 
 #define VMPC_SCAN_THREADS 256
 #define VMPC_SCAN_ITEMS 8

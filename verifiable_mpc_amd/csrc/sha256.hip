@@ -5,7 +5,7 @@
 // independent, so they are computed where the data lives and only 32 bytes per leaf cross
 // PCIe.  (The reference transcript, pivot.py:131-136, is one sequential SHA-256 over the
 // whole text and cannot be split; it stays on the host's hashlib.)
-#include "common.cuh"
+#include "common.h"
 
 #define SHA_BLOCK 256
 

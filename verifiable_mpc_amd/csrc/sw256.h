@@ -10,7 +10,7 @@
 // Only affine results are defined as output (proof elements feed pairings).
 // VMPC_HD: host-testable (tests/native/host_math_test.cpp).
 #pragma once
-#include "fe25519.cuh"   // VMPC_HD, fe_mac96 (device)
+#include "fe25519.h"   // VMPC_HD, fe_mac96 (device)
 
 struct fp {
     uint32_t v[8];

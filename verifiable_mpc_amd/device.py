@@ -177,7 +177,8 @@ class ScalarVector:
         if len(self):
             side = get_aux_context(2)
             side.wait_for(self.ctx)
-            self._pending_text = (is_signed, side.format_begin("scalars", self.ptr, len(self), is_signed))
+            self._pending_text = (is_signed, side.format_begin("scalars", self.ptr, len(self), is_signed,
+                                                                    keepalive=self.v.buf))
 
     def text(self, is_signed=True):
         """b'v0, v1, ..., ' as produced on the device (uint8 array)."""
@@ -389,7 +390,7 @@ class PointVector:
         if self.p is not None and len(self):
             side = get_aux_context(2)
             side.wait_for(self.ctx)
-            self._pending_text = side.format_begin("points", self.p.ptr, len(self))
+            self._pending_text = side.format_begin("points", self.p.ptr, len(self), keepalive=self.p.buf)
 
     def text(self):
         """b'[X, Y, Z], [X, Y, Z], ..., ' (uint8 array) for the Fiat-Shamir pre-image."""

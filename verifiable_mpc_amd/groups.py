@@ -8,7 +8,7 @@ class attributes `.order .generator .identity .operation .field` and the
 
 It is O(1)-per-round glue (Q' = A * Q**c * B**(c**2), equality of the final check); all
 vector-sized group work goes to the HIP kernels.  The formulas are the same projective
-add-2008-bbjlp / dbl-2008-bbjlp / right-to-left repeat that csrc/ge25519.cuh replays, so
+add-2008-bbjlp / dbl-2008-bbjlp / right-to-left repeat that csrc/ge25519.h replays, so
 un-normalised representatives agree between host elements and device vectors.
 [mpyc-recall, see oracle/ed25519_ref.py header for the parity status]
 """

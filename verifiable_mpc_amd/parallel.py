@@ -41,8 +41,11 @@ class HipBackend:
             n_slots = int(os.environ.get("VMPC_MSM_SLOTS", "3"))
         self.torch = torch
         self.ctxs = [ctx] + [get_aux_context(10 + i) for i in range(max(0, n_slots - 1))]
+        # torch's fills run on torch's current stream, which the vmpc streams (hipStreamNonBlocking) are
+        # not ordered with: finish them before the first MSM writes into these buffers
         self.partial_bufs = [torch.zeros(128, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
         self.combine_bufs = [torch.zeros(128, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
+        torch.cuda.current_stream().synchronize()
 
     @property
     def n_slots(self):
@@ -69,7 +72,9 @@ class HipBackend:
         return self.partial_bufs[slot]
 
     def new_gather_buffer(self, world):
-        return self.torch.zeros((world, 128), dtype=self.torch.uint8, device="cuda")
+        buf = self.torch.zeros((world, 128), dtype=self.torch.uint8, device="cuda")
+        self.torch.cuda.current_stream().synchronize()
+        return buf
 
     def combine(self, gathered, world, slot=0):
         # on the slot's own (now idle) stream, into its own buffer: never queued behind or

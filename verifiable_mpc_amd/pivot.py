@@ -323,9 +323,19 @@ def vector_commitment_pair(x_a, gamma_a, g_a, x_b, gamma_b, g_b, h):
     xa, xb = _scalars_on_device(x_a), _scalars_on_device(x_b)
     main, aux = gva.ctx, get_aux_context()
     aux.wait_for(main)                 # inputs were produced on the main stream
-    pa = _commit_launch(xa, gamma_a, gva, h, main)
-    pb = _commit_launch(xb, gamma_b, gvb, h, aux)
-    return pa.result(), pb.result()
+    try:
+        pa = _commit_launch(xa, gamma_a, gva, h, main)
+        pb = _commit_launch(xb, gamma_b, gvb, h, aux)
+        return pa.result(), pb.result()
+    except BaseException:
+        # a failed result() (e.g. NONCANON) must not hand this call's buffers back to the block cache
+        # while the other stream still reads them
+        for c in (main, aux):
+            try:
+                c.sync()
+            except Exception:
+                pass
+        raise
 
 
 def affine_to_linear(L, y, n):

@@ -201,10 +201,13 @@ class PreparedKey:
         self.ctx = ctx or get_context()
         self.mid = list(qap.indices_mid)
         self.vectors = {}
+        self.zk_missing = {}      # element -> names of zero-knowledge key points the evalkey lacks
         for name, (key_fmt, zk) in _ELEMENTS.items():
             points = [evalkey[key_fmt(i)] for i in self.mid]
-            self.zk_ok = all(zname in evalkey for _, zname in zk)
-            if self.zk_ok:
+            missing = [zname for _, zname in zk if zname not in evalkey]
+            if missing:
+                self.zk_missing[name] = missing
+            else:
                 points += [evalkey[zname] for _, zname in zk]
             self.vectors[name] = _KeyVector(self.ctx, points)
         powers = []
@@ -220,6 +223,10 @@ def _compute_proof_prepared(key, c, h, deltas):
     from .device import get_aux_context
     ctx = key.ctx
     n_mid = len(key.mid)
+    if deltas is not None and key.zk_missing:
+        # the dict path fails with KeyError on the first absent name (pynocchio.py:229-246)
+        raise KeyError("zero-knowledge deltas given but the prepared key lacks "
+                       + ", ".join(sorted(n for names in key.zk_missing.values() for n in names)))
     head = ctx.upload(_native.ints_to_array([int(c[i]) % ORDER for i in key.mid], 32)) if n_mid else None
     streams = [ctx, get_aux_context(20), get_aux_context(21)]
     pending = {}

@@ -122,8 +122,10 @@ class ShardedCrs:
             gathered, gptr, mine = ctx.alloc(128 * W * K), None, None
             gptr = gathered.ptr
         else:
-            mine = self.torch.zeros(128 * K, dtype=self.torch.uint8, device="cuda")
-            gathered = self.torch.zeros(128 * K * W, dtype=self.torch.uint8, device="cuda")
+            # torch.empty: no fill kernel on torch's stream that the vmpc streams (non-blocking, unordered
+            # with it) could race with; every byte is written by the partial sums / the all-gather
+            mine = self.torch.empty(128 * K, dtype=self.torch.uint8, device="cuda")
+            gathered = self.torch.empty(128 * K * W, dtype=self.torch.uint8, device="cuda")
             gptr = gathered.data_ptr()
         keep, used = [], [ctx]
         for j, (v, gamma) in enumerate(items):

@@ -43,6 +43,14 @@ def decompress_point(b):
     return Ed25519Point((x, y, 1))
 
 
+def in_prime_subgroup(pt):
+    """l * pt == identity (host big-int ladder, ~1.5 ms per point).  decompress_point accepts every
+    curve point, including the 8-torsion and its translates; a proof's points must lie in the
+    order-l group for the verifier's reduced exponents to mean what the reference's unreduced ones
+    do (compressed_pivot.py:66)."""
+    return Ed25519Point.repeat(pt, ORDER) == Ed25519Point.identity
+
+
 def _scalar(v):
     return (int(v) % ORDER).to_bytes(32, "little")
 
@@ -59,8 +67,11 @@ def serialize_proof(proof, transcript="reference"):
     return b"".join(out)
 
 
-def deserialize_proof(data, gf):
-    """-> (proof dict with `gf` scalars and Ed25519Point points, transcript name)"""
+def deserialize_proof(data, gf, check_subgroup=True):
+    """-> (proof dict with `gf` scalars and Ed25519Point points, transcript name).  Raises ValueError
+    for anything that is not a canonical encoding of scalars < l and points of the order-l group
+    (`check_subgroup=False` leaves the group-membership test to protocol_5_verifier, which runs it
+    on the device for all points at once)."""
     if data[:6] != MAGIC or data[6] != 1:
         raise ValueError("not an AC20 Protocol-5 proof (v1)")
     transcript = "reference" if data[7] == 0 else "compact"
@@ -81,11 +92,17 @@ def deserialize_proof(data, gf):
             raise ValueError("non-canonical scalar")
         return gf(v)
 
-    proof = {"t": scalar(), "A": decompress_point(take(32))}
+    def point():
+        pt = decompress_point(take(32))
+        if check_subgroup and not in_prime_subgroup(pt):
+            raise ValueError("point outside the prime-order subgroup")
+        return pt
+
+    proof = {"t": scalar(), "A": point()}
     for i in range(rounds):
-        proof[f"A{i}"] = decompress_point(take(32))
+        proof[f"A{i}"] = point()
     for i in range(rounds):
-        proof[f"B{i}"] = decompress_point(take(32))
+        proof[f"B{i}"] = point()
     nz = take(1)[0]
     proof["z_prime"] = [scalar() for _ in range(nz)]
     if off != len(data):
