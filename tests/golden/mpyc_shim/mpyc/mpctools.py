@@ -1,10 +1,17 @@
-"""Shim of mpyc.mpctools."""
-import os, sys
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "../../../..")))
-from oracle.ed25519_ref import tree_reduce
+"""Shim of mpyc.mpctools (the shim's own statement; not oracle/ed25519_ref.py)."""
 
 _none = object()
 
 
 def reduce(f, x, initial=_none):
-    return tree_reduce(f, x, None if initial is _none else initial)
+    """[mpyc-recall] Balanced pairwise reduction with O(log n) depth; an initial value is appended
+    at the END of the sequence.  An odd leftover stays at the FRONT of the list."""
+    x = list(x)
+    if initial is not _none:
+        x.append(initial)
+    if not x:
+        raise TypeError("reduce() of empty sequence with no initial value")
+    while len(x) > 1:
+        head = x[:len(x) % 2]
+        x = head + [f(x[i], x[i + 1]) for i in range(len(head), len(x), 2)]
+    return x[0]
