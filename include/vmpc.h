@@ -136,8 +136,10 @@ int vmpc_points_sum_many_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, si
 
 /* element-wise `base_i ** n_i` replaying the reference's operation sequence (ge25519.h):
  * bases are projective (96 B) or, with bases_affine != 0, affine (64 B, Z = 1); a single
- * base is broadcast when n_bases == 1.  signed_scalars != 0 applies the reference's
- * pivot._int convention (pivot.py:119-128): residues above l/2 act as negative exponents.
+ * base is broadcast when n_bases == 1.  signed_scalars = 1 applies the reference's
+ * pivot._int convention (pivot.py:119-128): residues above l/2 act as negative exponents;
+ * signed_scalars = 2 takes exponents in sign-magnitude form (|n| < 2^255, bit 255 = sign) for
+ * callers that hold the reference's Python ints, which need not be residues (pivot.py:143).
  * Outputs: projective representatives (may be NULL) and/or affine (may be NULL). */
 int vmpc_repeat_dev(vmpc_ctx *ctx, const void *bases, size_t n_bases, int bases_affine,
                     const void *scalars, size_t n, int signed_scalars, void *out_proj,

@@ -247,15 +247,87 @@ def demo_case(seed):
         })
         return proof
 
+    # Protocol 8 level (circuit_sat_cb.py:59-166, :255-318): everything the two Protocol-8 hashes are made
+    # of, the un-normalised commitment [z] they contain (:103-111), and the proof as returned
+    p8 = {}
+    orig_p8 = cs_cb.protocol_8_excl_pivot_prover
+    orig_forms = cb.calculate_circuit_forms
+
+    def form_rec(f, order):
+        return {"coeffs": [typed(v, order) for v in f.coeffs], "constant": typed(f.constant, order),
+                "linear": isinstance(f, pivot.LinearForm)}
+
+    def spy_p8(generators, circuit, x, gf, use_koe=False):
+        order = gf.order
+        with Recorder() as rec:
+            proof, z_commitment, L, z, gamma = orig_p8(generators, circuit, x, gf, use_koe)
+        # the objects of the second hash are rebuilt exactly as :127-147 builds them (deterministic
+        # functions of the circuit, the first challenge and y1..y3)
+        c1 = int(rec.calls[0]["c"], 16)
+        lf = cb.calculate_fg_form(circuit, wire=0, challenge=c1, gf=gf)
+        lg = cb.calculate_fg_form(circuit, wire=1, challenge=c1, gf=gf)
+        lh = cb.calculate_h_form(circuit, c1, gf)
+        circuit_forms = [cb.convert_to_ac20(f, circuit) for f in orig_forms(circuit)]
+        outputs = proof["outputs"]
+        lin_forms = [form - y for form, y in zip(circuit_forms, outputs)] + \
+            [lf - proof["y1"], lg - proof["y2"], lh - proof["y3"]]
+        check = [proof["y1"], proof["y2"], proof["y3"], z_commitment, outputs, circuit_forms, lin_forms,
+                 "Second hash circuit satisfiability protocol"]
+        assert hashlib.sha256(str(check).encode()).hexdigest() == rec.calls[1]["sha256"]
+        p8.update({
+            "z_typed": [typed(v, order) for v in z], "gamma": hx(gamma),
+            "z_commitment_proj": pt_proj_hex(z_commitment),
+            "circuit_str": str(circuit),
+            "hashes": rec.calls,                                  # first, second hash (:107-111, :149-162)
+            "y_typed": [typed(proof[k], order) for k in ("y1", "y2", "y3")],
+            "outputs_typed": [typed(v, order) for v in outputs],
+            "circuit_forms": [form_rec(f, order) for f in circuit_forms],
+            "lin_forms": [form_rec(f, order) for f in lin_forms],
+            "L": form_rec(L, order),
+        })
+        return proof, z_commitment, L, z, gamma
+
+    all_hashes = Recorder()
+    captured_proof = {}
+    orig_prover = cs_cb.circuit_sat_prover
+
+    def spy_prover(generators, circuit, x, gf, pivot_choice=cs_cb.PivotChoice.compressed):
+        proof = orig_prover(generators, circuit, x, gf, pivot_choice)
+        captured_proof["proof"] = proof
+        return proof
+
     compressed_pivot.protocol_5_prover = spy
+    cs_cb.protocol_8_excl_pivot_prover = spy_p8
+    cs_cb.circuit_sat_prover = spy_prover
     try:
-        with contextlib.redirect_stdout(io.StringIO()) as buf:
+        with contextlib.redirect_stdout(io.StringIO()) as buf, all_hashes:
             verification = demo.main(cs_cb.PivotChoice.compressed, 3)
     finally:
         compressed_pivot.protocol_5_prover = orig_p5
+        cs_cb.protocol_8_excl_pivot_prover = orig_p8
+        cs_cb.circuit_sat_prover = orig_prover
     captured["verification"] = verification
     captured["stdout_head"] = [l for l in buf.getvalue().replace("\r", "\n").split("\n")
                                if l.startswith("Length of")]
+    # the full returned proof (demos/demo_zkp_ac20.py:82-84 prints it): points with their
+    # representatives, scalars with their Python type
+    order = 2**252 + 27742317777372353535851937790883648493
+    pp = captured_proof["proof"]["pivot_proof"]
+    rounds = captured["rounds"]
+    captured["protocol8"] = p8
+    captured["returned_proof"] = {
+        "keys": list(captured_proof["proof"].keys()),
+        "pivot_proof_keys": list(pp.keys()),
+        "t_typed": typed(pp["t"], order), "A_proj": pt_proj_hex(pp["A"]),
+        "A_i_proj": [pt_proj_hex(pp[f"A{i}"]) for i in range(rounds)],
+        "B_i_proj": [pt_proj_hex(pp[f"B{i}"]) for i in range(rounds)],
+        "z_prime_typed": [typed(v, order) for v in pp["z_prime"]],
+    }
+    # every Fiat-Shamir hash of the run in call order: prover (2 Protocol-8, c0, c1, one per round), then
+    # the verifier's recomputation of the same
+    captured["all_hashes"] = all_hashes.calls
+    half_n = len(all_hashes.calls) // 2
+    assert all_hashes.calls[:half_n] == all_hashes.calls[half_n:]
     return captured
 
 

@@ -186,6 +186,78 @@ def test_demo_zkp_ac20_elliptic_protocol5_call(vm, golden_demo, monkeypatch, rec
     assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, 0, proof, gf) is True
 
 
+def _typed_of(v):
+    return "i:" + str(v) if isinstance(v, int) else "f:" + hx(int(v) % ELL)
+
+
+def proj_hex(pt):
+    return [hx(c) for c in pt.coords]
+
+
+def test_demo_zkp_ac20_whole_transcript(vm, golden_demo, monkeypatch, record_hashes):
+    """BASELINE config 1 at the Protocol-8 level: every Fiat-Shamir hash of the seeded
+    `demo_zkp_ac20.py --elliptic` run - the two of circuit_sat_cb.py:107-111 / :149-162, which contain
+    the UN-normalised commitment [z], then c0, c1 and the six round challenges - and the proof dict the
+    demo prints, points with their (X:Y:Z) representatives and scalars with their Python types.
+
+    The circuit front end is out of scope and absent from the GPU box, so the objects it feeds into
+    the hashes (str(circuit), the circuit / f / g / h forms) come from the fixture as typed
+    coefficient lists and are rebuilt with THIS package's classes; everything on the hot path -
+    [z] (pivot.py:139-145 through the exact list-mode path), the hashes, L = sum lin_form_i * rho^i
+    (circuit_sat_cb.py:164), Protocol 5 - is computed here."""
+    case, p8, ret = golden_demo, golden_demo["protocol8"], golden_demo["returned_proof"]
+    group, gens = build_generators(vm, case, monkeypatch, 20200152 + 600 + 10)
+    gf = vm.GF(group.order)
+    tv = lambda s_: typed_value(gf, s_)
+
+    def form(rec):
+        cls = vm.pivot.LinearForm if rec["linear"] else vm.pivot.AffineForm
+        return cls([tv(c) for c in rec["coeffs"]], tv(rec["constant"]))
+
+    # circuit_sat_cb.py:91-104: z and its commitment (the caller passes Python lists)
+    z = [tv(v) for v in p8["z_typed"]]
+    gamma = h2i(p8["gamma"])
+    z_commitment = vm.pivot.vector_commitment(z, gamma, list(gens["g"]), gens["h"])
+    assert proj_hex(z_commitment) == p8["z_commitment_proj"]              # representative, not just the element
+    assert aff_hex(z_commitment) == case["P"]
+    # first hash (:107-111)
+    c = vm.pivot.fiat_shamir_hash(
+        [z_commitment, p8["circuit_str"], "First hash circuit satisfiability protocol"], gf.order)
+    assert hx(c) == p8["hashes"][0]["c"]
+    # second hash (:149-162)
+    y1, y2, y3 = (tv(v) for v in p8["y_typed"])
+    outputs = [tv(v) for v in p8["outputs_typed"]]
+    circuit_forms = [form(f) for f in p8["circuit_forms"]]
+    lin_forms = [form(f) for f in p8["lin_forms"]]
+    rho = vm.pivot.fiat_shamir_hash([y1, y2, y3, z_commitment, outputs, circuit_forms, lin_forms,
+                                     "Second hash circuit satisfiability protocol"], gf.order)
+    assert hx(rho) == p8["hashes"][1]["c"]
+    # L (:164): the same expression over this package's form classes
+    L = sum((linform_i) * (rho ** i) for i, linform_i in enumerate(lin_forms))
+    assert [_typed_of(v) for v in L.coeffs] == p8["L"]["coeffs"] == case["L_typed"]
+    assert _typed_of(L.constant) == p8["L"]["constant"]
+    # circuit_sat_cb.py:263-266
+    monkeypatch.setattr(vm.compressed_pivot, "prng", random.Random(20200152 + 600 + 12))
+    proof = vm.compressed_pivot.protocol_5_prover(gens, z_commitment, L, L(z), z, gamma, gf)
+    assert [hx(v) for v in record_hashes] == [h["c"] for h in case["all_hashes"][:10]]
+    assert list(proof.keys()) == ret["pivot_proof_keys"]
+    assert _typed_of(proof["t"]) == ret["t_typed"]
+    assert proj_hex(proof["A"]) == ret["A_proj"]
+    for i in range(case["rounds"]):
+        assert proj_hex(proof[f"A{i}"]) == ret["A_i_proj"][i], f"A{i}"
+        assert proj_hex(proof[f"B{i}"]) == ret["B_i_proj"][i], f"B{i}"
+    assert [_typed_of(v) for v in proof["z_prime"]] == ret["z_prime_typed"]
+    # verifier (:285-318): recomputes the same ten hashes; y = 0 and the un-shifted form
+    del record_hashes[:]
+    cv = vm.pivot.fiat_shamir_hash(
+        [z_commitment, p8["circuit_str"], "First hash circuit satisfiability protocol"], gf.order)
+    rv = vm.pivot.fiat_shamir_hash([y1, y2, y3, z_commitment, outputs, circuit_forms, lin_forms,
+                                    "Second hash circuit satisfiability protocol"], gf.order)
+    assert (cv, rv) == (c, rho)
+    assert vm.compressed_pivot.protocol_5_verifier(gens, z_commitment, L, 0, proof, gf) is True
+    assert [hx(v) for v in record_hashes] == [h["c"] for h in case["all_hashes"][10:]]
+
+
 @pytest.mark.parametrize("n", [3, 31])
 def test_compact_transcript_matches_oracle(vm, monkeypatch, n):
     rng = random.Random(500 + n)
@@ -332,7 +404,7 @@ def test_mpc_local_commitment_shares(vm):
              for p in range(parties)]
     want = vm.pivot.vector_commitment(x, gamma, g, h)
     assert mpc_ac20.combine_commitment_shares(parts) == want
-    assert want.coords[:2] == ed.pt_affine(ac.vector_commitment(
+    assert want.normalize().coords[:2] == ed.pt_affine(ac.vector_commitment(
         x, gamma, [p.coords for p in g.to_points()], h.coords))
 
 

@@ -89,3 +89,20 @@ def test_field_repr_conventions_match(shim_group):
         sys.modules.update(saved)
     p = ed.pt_repeat(ed.BASE, 5)
     assert repr(shim_group.repeat(shim_group.generator, 5)) == ed.pt_repr(p)
+
+
+def test_reduce_tree_shape_matches():
+    """mpctools.reduce (pivot.list_mul's tree, pivot.py:26-28): the shim's and the oracle's statements
+    build the same tree - checked with a non-associative operation that spells the tree out"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("shim_mpctools", os.path.join(SHIM, "mpyc", "mpctools.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    f = lambda a, b: f"({a}{b})"
+    for n in range(1, 40):
+        xs = [chr(65 + i % 26) for i in range(n)]
+        assert mod.reduce(f, xs) == ed.tree_reduce(f, xs)
+        assert mod.reduce(f, xs, "!") == ed.tree_reduce(f, xs, "!")
+    assert mod.reduce(f, [], "!") == "!"
+    with pytest.raises(TypeError):
+        mod.reduce(f, [])

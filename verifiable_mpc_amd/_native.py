@@ -459,7 +459,7 @@ class Context:
                out_proj_ptr=None, out_affine_ptr=None):
         _check(self.lib.vmpc_repeat_dev(self.handle, ctypes.c_void_p(bases_ptr), n_bases,
                                         1 if bases_affine else 0, ctypes.c_void_p(scalars_ptr), n,
-                                        1 if signed_scalars else 0, ctypes.c_void_p(out_proj_ptr),
+                                        int(signed_scalars), ctypes.c_void_p(out_proj_ptr),
                                         ctypes.c_void_p(out_affine_ptr)), "vmpc_repeat_dev")
 
     def fixed_base(self, base_affine_ptr, scalars_ptr, n, out_affine_ptr):

@@ -169,7 +169,12 @@ k_repeat(const uint32_t *__restrict__ bases, size_t n_bases, int bases_affine,
         s.v[0] = x.x; s.v[1] = x.y; s.v[2] = x.z; s.v[3] = x.w;
         s.v[4] = y.x; s.v[5] = y.y; s.v[6] = y.z; s.v[7] = y.w;
     }
-    if (signed_scalars) {
+    if (signed_scalars == 2) {
+        // sign-magnitude: |n| < 2^255 in bits 0..254, bit 255 set for n < 0 (exponents the caller has
+        // already converted with pivot._int: plain Python ints are not residues and may exceed l)
+        if (s.v[7] >> 31) a = ge_proj_neg(a);
+        s.v[7] &= 0x7fffffffu;
+    } else if (signed_scalars) {
         // pivot._int on a signed field element: residues above l/2 are negative ints, and
         // `a ** n` with n < 0 inverts the base first (oracle pt_repeat)
         fr mag;

@@ -239,30 +239,70 @@ def _scalars_on_device(x):
     return ScalarVector.from_ints([_residue(_int(x_i)) for x_i in x])
 
 
-def vector_commitment(x, gamma, g, h, exact_representative=False):
-    """Pedersen vector commitment, Definition 1 of AC20 (pivot.py:139-145):
-    h^gamma * prod_i g_i^{x_i}, as one (len(x)+1)-term Pippenger MSM on the GPU.
+def _exact_commitment(x, gamma, gv, h):
+    """The reference's own operation sequence (pivot.py:143-145) on the device:
+    `g[i] ** _int(x_i)` per term (right-to-left ladder, a negative exponent inverts the base),
+    `list_mul` (mpctools.reduce tree, identity appended), then `(h ** gamma) * prod` - so the
+    un-normalised (X:Y:Z) of the result is the one the reference holds [mpyc-recall formulas]."""
+    import numpy as np
+    ctx = gv.ctx
+    n = len(x)
+    if not gv.has_proj:
+        raise ValueError("exact_representative needs projective generators")
+    terms = ctx.alloc(max(1, 96 * n))
+    if isinstance(x, ScalarVector):
+        ctx.repeat(gv.proj_ptr, n, False, x.ptr, n, 0, terms.ptr, None)       # residues as they are
+    elif n:
+        exps = [_int(v) for v in x]
+        # plain Python ints are not residues: they keep their sign and their size (z' of a later
+        # round is hundreds of bits longer, compressed_pivot.py:76); the ladder kernel takes
+        # sign-magnitude exponents below 2^255, the few longer ones run on the host
+        big = [i for i, e in enumerate(exps) if abs(e) >> 255]
+        enc = b"".join(((abs(e) if not abs(e) >> 255 else 0) | ((1 << 255) if e < 0 and not abs(e) >> 255 else 0))
+                       .to_bytes(32, "little") for e in exps)
+        sc = ctx.upload(np.frombuffer(enc, np.uint8))
+        ctx.repeat(gv.proj_ptr, n, False, sc.ptr, n, 2, terms.ptr, None)
+        for i in big:
+            term = Ed25519Point.repeat(gv[i], exps[i])
+            ctx.upload_into(terms.ptr + 96 * i, np.frombuffer(term.to_proj_bytes(), np.uint8))
+    out = ctx.alloc(96)
+    ctx.tree_reduce(terms.ptr, n, True, out.ptr)
+    prod = Ed25519Point.from_proj_bytes(ctx.download(out.ptr, 96).tobytes())
+    return Ed25519Point.operation(Ed25519Point.repeat(h, _int(gamma)), prod)
 
-    The returned element is affine-normalised (Z = 1).  With exact_representative=True the
-    reference's per-term `**` and reduce tree are replayed on the device instead, giving the
-    same un-normalised (X:Y:Z) the reference would hold (needed only if the caller hashes the
-    commitment without normalising it, e.g. circuit_sat_cb.py:107)."""
+
+def _wants_exact(x, gv):
+    """List inputs are the reference's calling convention (demo_zkp_ac20.py, circuit_sat_cb.py): there
+    the caller may hash or print the commitment WITHOUT normalising it (circuit_sat_cb.py:107-111,
+    demo_zkp_ac20.py:84), so the representative is part of the contract.  Device vectors are the
+    N = 2^20 convention: group element only, Pippenger."""
+    return not isinstance(x, ScalarVector) and gv.has_proj
+
+
+def vector_commitment(x, gamma, g, h, exact_representative=None):
+    """Pedersen vector commitment, Definition 1 of AC20 (pivot.py:139-145):
+    h^gamma * prod_i g_i^{x_i}.
+
+    `x` a Python list (the reference's convention): the reference's per-term `**` and reduce tree
+    are replayed on the device, and the returned element has the same un-normalised (X:Y:Z) the
+    reference would hold - bit-identical transcripts for callers that hash it as it is
+    (circuit_sat_cb.py:107).  `x` a device ScalarVector: one (len(x)+1)-term Pippenger MSM, the
+    result affine-normalised (Z = 1).  `exact_representative` forces either path."""
     assert len(g) >= len(x), "Not enough generators."
     n = len(x)
     gv = _points_on_device(g)
-    xs = _scalars_on_device(x)
-    ctx = gv.ctx
+    if exact_representative is None:
+        exact_representative = _wants_exact(x, gv)
     if exact_representative:
-        if not gv.has_proj:
-            raise ValueError("exact_representative needs projective generators")
-        terms = ctx.alloc(max(1, 96 * n))
-        signed = not isinstance(x, ScalarVector) and any(not isinstance(v, int) for v in x)
-        ctx.repeat(gv.proj_ptr, n, False, xs.ptr, n, signed, terms.ptr, None)
-        out = ctx.alloc(96)
-        ctx.tree_reduce(terms.ptr, n, True, out.ptr)
-        prod = Ed25519Point.from_proj_bytes(ctx.download(out.ptr, 96).tobytes())
-        return Ed25519Point.operation(Ed25519Point.repeat(h, _int(gamma)), prod)
-    return _commit_launch(xs, gamma, gv, h, ctx).result()
+        return _exact_commitment(x, gamma, gv[:n] if len(gv) != n else gv, _as_point(h))
+    xs = _scalars_on_device(x)
+    return _commit_launch(xs, gamma, gv, _as_point(h), gv.ctx).result()
+
+
+def _as_point(obj):
+    if isinstance(obj, Ed25519Point):
+        return obj
+    return Ed25519Point((int(obj[0]), int(obj[1]), int(obj[2])))
 
 
 class _PendingCommitment:
@@ -320,6 +360,9 @@ def vector_commitment_pair(x_a, gamma_a, g_a, x_b, gamma_b, g_b, h):
     from .device import get_aux_context
     assert len(g_a) >= len(x_a) and len(g_b) >= len(x_b), "Not enough generators."
     gva, gvb = _points_on_device(g_a), _points_on_device(g_b)
+    if _wants_exact(x_a, gva) and _wants_exact(x_b, gvb):
+        # list mode: the proof's A_i, B_i carry the reference's representatives
+        return vector_commitment(x_a, gamma_a, gva, h), vector_commitment(x_b, gamma_b, gvb, h)
     xa, xb = _scalars_on_device(x_a), _scalars_on_device(x_b)
     main, aux = gva.ctx, get_aux_context()
     aux.wait_for(main)                 # inputs were produced on the main stream
