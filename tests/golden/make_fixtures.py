@@ -331,6 +331,63 @@ def demo_case(seed):
     return captured
 
 
+def mpc_case(n, seed):
+    """the reference's MPyC driver (verifiable_mpc/ac20/mpc_ac20.py:35-51,141-269) run
+    with ONE party (m = 1: shares are the values; how test/test_demo_zkp_mpc_ac20.py:17-23 runs it) on
+    the shim's single-party `mpc`.  Pins what is opened and hashed when, the draw order of the jointly
+    random exponents / masks, and the proof; group elements affine (the representative real MPyC's
+    secure_repeat would return is unknown)."""
+    import verifiable_mpc.ac20.mpc_ac20 as mpc_ac20
+    from mpyc.runtime import mpc
+    group, _ = group_and_field()
+    secfld = mpc.SecFld(modulus=group.order)
+    gf = secfld.field
+    rng = random.Random(seed)
+    mpc._rng = random.Random(seed + 1)
+    st = mpc._rng.getstate()
+    generators = mpc.run(mpc_ac20.create_generators(group, secfld, n))
+    # secure_repeat OPENS a group element; which representative real MPyC hands back is unknown, and the
+    # generators enter the first pre-image as they are (mpc_ac20.py:238).  The harness therefore passes
+    # them on normalised - on both sides - so that the transcript is a function of group elements only.
+    generators = {"g": [p.normalize() for p in generators["g"]], "h": generators["h"],
+                  "k": generators["k"].normalize()}
+    replay = random.Random()
+    replay.setstate(st)
+    exps = [replay.randrange(group.order) for _ in range(n + 1)]          # [0] is k's (mpc_ac20.py:50)
+    x_plain = [gf(rng.randrange(group.order)) for _ in range(n)]
+    x_plain[1], x_plain[2] = gf(0), gf(-1)
+    gamma_plain = gf(rng.randrange(1, group.order))
+    x = [secfld(v) for v in x_plain]
+    gamma = secfld(gamma_plain)
+    L = pivot.LinearForm([gf(rng.randrange(group.order)) for _ in range(n)])
+    P = mpc.run(mpc_ac20.vector_commitment(x, gamma, generators["g"], generators["h"]))
+    y = L(x)                                                               # secret
+    mpc._rng = random.Random(seed + 2)
+    st = mpc._rng.getstate()
+    with Recorder() as rec:
+        proof = mpc.run(mpc_ac20.protocol_5_prover(generators, P, L, y, x, gamma, gf))
+        n_prover = len(rec.calls)
+        ok = compressed_pivot.protocol_5_verifier(generators, P, L, y.share, proof, gf)
+    assert ok is True and rec.calls[n_prover:] == rec.calls[:n_prover]
+    replay.setstate(st)
+    r = [replay.randrange(group.order) for _ in range(n)]
+    rho = replay.randrange(group.order)
+    rounds = (n + 1).bit_length() - 2
+    return {"n": n, "seed": seed, "rounds": rounds, "parties": 1,
+            "gen_exponents": [hx(e) for e in exps],
+            "generators": {"g": [pt_affine_hex(p) for p in generators["g"]],
+                           "h": pt_affine_hex(generators["h"]), "k": pt_affine_hex(generators["k"])},
+            "x": [hx(v.value) for v in x_plain], "gamma": hx(gamma_plain.value),
+            "L": [hx(v.value) for v in L.coeffs], "y": hx(y.share.value),
+            "r": [hx(v) for v in r], "rho": hx(rho), "P": pt_affine_hex(P),
+            "proof": {"t": hx(proof["t"].value), "A": pt_affine_hex(proof["A"]),
+                      "A_i": [pt_affine_hex(proof[f"A{i}"]) for i in range(rounds)],
+                      "B_i": [pt_affine_hex(proof[f"B{i}"]) for i in range(rounds)],
+                      "z_prime": [hx(int(v) % group.order) for v in proof["z_prime"]]},
+            "proof_keys": list(proof.keys()),
+            "hashes": rec.calls[:n_prover], "verified": ok}
+
+
 def pynocchio_case(seed):
     """BASELINE config 5 shape: the reference's Pinocchio key generation and compute_proof
     (trinocchio/pynocchio.py:101-273) on the demo's program (demos/demo_zkp_pynocchio.py:45-50),
@@ -396,6 +453,8 @@ def main():
         json.dump(out, f, indent=0, sort_keys=True)
     with open(os.path.join(HERE, "ac20_ed25519_n1023.json"), "w") as f:
         json.dump(p5_case(1023, SEED + 500), f, indent=0, sort_keys=True)
+    with open(os.path.join(HERE, "mpc_ac20_m1.json"), "w") as f:
+        json.dump({"cases": [mpc_case(7, SEED + 800), mpc_case(31, SEED + 900)]}, f, indent=0, sort_keys=True)
     try:
         with open(os.path.join(HERE, "pynocchio_bn256.json"), "w") as f:
             json.dump(pynocchio_case(SEED + 700), f, indent=0, sort_keys=True)

@@ -105,3 +105,56 @@ def test_missing_gpu_fails_loudly():
         vm.get_context()
     with pytest.raises(RuntimeError):
         pivot.vector_commitment([1], 1, [vm.Ed25519Point.generator], vm.Ed25519Point.generator)
+
+
+def test_mpc_party_runtime_opens_and_recombines():
+    """verifiable_mpc_amd.mpc_ac20 host logic (no GPU): Shamir dealing, the M-point Lagrange weights,
+    linear arithmetic on shares, `output` across three in-process parties."""
+    import asyncio
+    import random
+    from verifiable_mpc_amd import mpc_ac20
+    ELL = ed.ELL
+    rng = random.Random(9)
+    parties, threshold = 3, 1
+    hub = mpc_ac20.LocalHub(parties)
+    rts = [mpc_ac20.PartyRuntime(p, parties, threshold, random.Random(p), hub) for p in range(parties)]
+    assert [rt.lagrange for rt in rts] == mpc_ac20.recombination_vector([1, 2, 3])
+    assert sum(rt.lagrange for rt in rts) % ELL == 1
+    secrets = [rng.randrange(ELL) for _ in range(4)]
+    shares = mpc_ac20.deal(secrets, threshold, parties, rng)
+    # any threshold + 1 = 2 parties recombine as well
+    lam2 = mpc_ac20.recombination_vector([1, 3])
+    assert (lam2[0] * shares[0][0] + lam2[1] * shares[2][0]) % ELL == secrets[0]
+    gf = vm.GF(ELL)
+
+    async def party(rt):
+        a, b, c, d = (rt.secret(s) for s in shares[rt.pid])
+        expr = 3 * a - b + gf(7) * c + 11          # linear: local on shares
+        fresh = rt._random()
+        opened = await rt.output([expr, d, 5, fresh])
+        single = await rt.output(a + d)
+        return opened, single
+
+    async def everybody():
+        return await asyncio.gather(*[party(rt) for rt in rts])
+    results = asyncio.new_event_loop().run_until_complete(everybody())
+    want = (3 * secrets[0] - secrets[1] + 7 * secrets[2] + 11) % ELL
+    for opened, single in results:
+        assert int(opened[0]) % ELL == want and int(opened[1]) % ELL == secrets[3] and opened[2] == 5
+        assert opened[3] == results[0][0][3]                   # the jointly random value is the same everywhere
+        assert int(single) % ELL == (secrets[0] + secrets[3]) % ELL
+    with pytest.raises(NotImplementedError):
+        rts[0].secret(1) * rts[0].secret(2)
+    assert pivot._int(rts[0].secret(1)).share == 1            # pivot.py:119-128: secure objects pass through
+
+
+def test_install_mpc_patches_reference_module(monkeypatch):
+    import sys
+    import types
+    from verifiable_mpc_amd import mpc_ac20
+    pkg = "fake_ref_pkg_mpc"
+    for name in ("", ".mpc_ac20"):
+        monkeypatch.setitem(sys.modules, pkg + name, types.ModuleType(pkg + name))
+    patched = mpc_ac20.install_mpc(pkg)
+    assert sys.modules[pkg + ".mpc_ac20"].protocol_5_prover is mpc_ac20.protocol_5_prover
+    assert len(patched) == 4
