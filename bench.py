@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--sharded-prove", action="store_true",
                     help="also time the sharded compact prover (needs a process group; opt-in so that a "
                          "collective going wrong cannot cost the headline line)")
+    ap.add_argument("--variable-base", action="store_true",
+                    help="headline on generators given as plain affine points (prepared per call) instead of "
+                         "generators resident in prepared form; the other mode is always reported beside it")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one commitment in flight (default: 2, on two streams of the same GPU)")
     args = ap.parse_args()
@@ -260,15 +263,25 @@ def main():
     exps = vm.ScalarVector.from_array(rand_scalars(rng, n))
     points = vm.PointVector.fixed_base(group.generator, exps, keep_proj=False)
     scalars = vm.ScalarVector.from_array(rand_scalars(rng, n))
+    # The generators of a Pedersen commitment are a CRS (circuit_sat_r1cs.py:47-93 creates them once, every
+    # commitment reuses them), so by default they are RESIDENT IN PREPARED FORM: the (y-x, y+x, 2dxy) image of
+    # each affine point, one 128-byte line, computed once at CRS load (untimed) - a representation of the same
+    # 2^20 points, no multiples of them.  `variable_base` = the same commitment from plain affine points,
+    # converted inside every call (k_msm_prep); both modes are timed and reported.
+    points_prepared = vm.PointVector(points.a, None, ctx).precompute([], rows=1)
+    points_plain = points
+    if not args.variable_base:
+        points = points_prepared
     shard = parallel.ShardedMsm(ctx, world, rank, dist, torch, force_collective=args.force_collective)
 
     depth = 1 if args.no_pipeline else shard.n_slots
 
-    def run_steps(k):
+    def run_steps(k, pts=None):
         """k commitments, up to `depth` in flight; every result is fetched to the host."""
+        pts = points if pts is None else pts
         pending, last = [], None
         for i in range(k):
-            pending.append(shard.launch(scalars, points, i % depth))
+            pending.append(shard.launch(scalars, pts, i % depth))
             if len(pending) == depth:
                 last = shard.finish(pending.pop(0))
         while pending:
@@ -318,6 +331,19 @@ def main():
         iso = {k: ms / max(c, 1) for k, (ms, c) in c0.profile_read(reset=True).items()}
         c0.profile(False)
         alu_peak = max(c0.madd_rate(400) for _ in range(3))
+    # the other generator form, same K steps, same brackets
+    other_pts = points_plain if points is points_prepared else points_prepared
+    run_steps(args.warmup, other_pts)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t2 = time.perf_counter()
+    other_result = run_steps(args.steps, other_pts)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    other_elapsed = time.perf_counter() - t2
+    assert other_result == result, "prepared and plain generators disagree"
 
     # size-independent correctness property at full size: sum_i s_i * (e_i * B) == (sum s_i e_i) * B
     if world == 1:
@@ -343,6 +369,9 @@ def main():
             "config": {"workload": f"Pedersen vector-commitment MSM, n=2^{args.log2n} Ed25519 "
                                    f"generators per GPU, uniform 252-bit scalars",
                        "terms_per_gpu": n, "total_terms": world * n, "commitments_in_flight": depth,
+                       "generators": ("plain affine points, prepared inside every call" if args.variable_base else
+                                      "resident in prepared form (128-byte niels image of each point, made once "
+                                      "at CRS load, untimed)"),
                        "collective": "all_gather(128 B/rank) + ordered add" if shard.collective else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_bucket", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -360,6 +389,9 @@ def main():
                                  "kernel_ms_alone": iso_bucket_s * 1e3,
                                  "mixed_additions_per_launch": madds,
                                  "window_bits": c_bits, "windows": windows}},
+            ("prepared_generators" if args.variable_base else "variable_base"): {
+                "value": world * n * args.steps / other_elapsed, "ms_per_step": other_elapsed / args.steps * 1e3,
+                "note": "same K steps and brackets with the generators in the other form"},
             "stages_us": {k: round(ms / max(c, 1) * 1e3, 1) for k, (ms, c) in prof.items()},
             "alone": {"ms_per_commitment": round(iso_ms, 4),
                       "stages_us": {k: round(v * 1e3, 1) for k, v in iso.items()}},

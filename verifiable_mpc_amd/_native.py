@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvmpc_hip.so")
+LIB_PATH = os.environ.get("VMPC_LIB_PATH") or os.path.join(_HERE, "libvmpc_hip.so")   # override: developer A/B builds
 
 OK = 0
 E_INVAL, E_NONCANON, E_NOTONCURVE, E_NOMEM, E_HIP, E_NODEV = -22, -34, -33, -12, -5, -19

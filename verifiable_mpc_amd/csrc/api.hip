@@ -61,10 +61,10 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
     }
     const char *w = getenv("VMPC_MSM_WINDOW");
     if (w) c->window_override = atoi(w);
-    const char *sr = getenv("VMPC_SORT_RANGE");     // tuning knob: buckets per sort workgroup
-    if (sr && atoi(sr) >= 64) c->sort_range = atoi(sr);
-    const char *ss = getenv("VMPC_SORT_SLICES");
-    if (ss && atoi(ss) >= 1) c->sort_slices = atoi(ss);
+    const char *bw = getenv("VMPC_BUCKET_WGS_PER_CU");
+    if (bw && atoi(bw) >= 0) c->bucket_wgs_per_cu = atoi(bw);
+    const char *sf = getenv("VMPC_SORT_FINE_BITS");   // tuning knob: fine bits of the two-level bucket sort
+    if (sf && atoi(sf) >= 0) c->sort_fine_bits = atoi(sf);
     *out = c;
     return VMPC_OK;
 }

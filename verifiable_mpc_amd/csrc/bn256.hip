@@ -304,7 +304,7 @@ static int bn_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, si
     }
     if (n >= (1ull << 31) / 17) return VMPC_E_INVAL;
     msm_plan p;
-    msm_make_plan(ctx, n, 0, 256, p);
+    msm_make_plan(ctx, n, 0, 256, p, &BN_ORDER);
     msm_ws w;
     msm_layout(p, w, nullptr, C::ENTRY_WORDS * 4, C::ACC_WORDS * 4);
     VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
@@ -389,6 +389,8 @@ static int bn_table_msm_dev(vmpc_ctx *ctx, const void *table, size_t table_n, co
     p.scalar_bits = 256;
     p.c = BN_TABLE_C;
     p.W = 1;
+    p.top_row = -1;
+    p.top_max_b = 0;
     msm_plan_geometry(ctx, p);
     msm_ws w;
     msm_layout(p, w, nullptr, 0, C::ACC_WORDS * 4);

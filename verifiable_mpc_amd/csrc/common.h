@@ -50,8 +50,8 @@ struct vmpc_ctx {
     size_t ws_used = 0;
     uint32_t *d_status = nullptr;
     int window_override = 0;
-    int sort_slices = 0;           // 0 = automatic
-    int sort_range = 4096;         // buckets per sort workgroup (msm_sort.h)
+    int bucket_wgs_per_cu = 0;     // > 0: persistent bucket kernel with this many 256-thread workgroups per CU
+    int sort_fine_bits = -1;       // fine bits of the two-level bucket sort; -1 = automatic (msm_sort.hip)
     int cu_count = 256;
     hipEvent_t xevent = nullptr;   // cross-context ordering (vmpc_ctx_wait_for)
     // profiling

@@ -8,13 +8,9 @@
 // normal form is defined as output.
 //
 // Pipeline (all on one stream, no host round trip):
-//   prep     affine (x,y) -> niels (y-x, y+x, 2dxy), 96 B/point, coalesced 16-B accesses
-//   recode   32-B scalars -> W signed c-bit digits (int16, window-major)
-//   hist     per (window, slice) workgroup: digit histogram in LDS (up to 128 KiB)
-//   counts   per-bucket totals + per-slice exclusive offsets
-//   scan     exclusive scan of bucket totals -> bucket start offsets
-//   scatter  per (window, slice) workgroup: LDS cursors -> bucket-sorted point indices
-//   plan     cut every bucket's run into <= 64-entry segments, number them by length
+//   prep     affine (x,y) -> niels (y-x, y+x, 2dxy), one 128-B line per point, coalesced 16-B accesses
+//   recode, hist1, scan, part1, fine, plan   (msm_sort.hip: signed digits, two-level bucket sort,
+//            segment task table)
 //   bucket   one lane per segment: mixed additions (7M); finish: LDS tree for split buckets
 //   reduce   per window: chunked running sums + LDS tree -> sum_b b*B_b partials
 //   final    window sums, Horner over windows (c doublings each), one inversion -> affine
@@ -156,207 +152,7 @@ k_msm_prep(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__re
     niels_st_line(niels + NIELS_WORDS * i, q);
 }
 
-// ---- recode: scalar -> signed digits ----------------------------------------------------
-// Row w of `digits` holds window w of every term: main terms at [0, n_main), extra terms at
-// [extra_pos, extra_pos + n_extra), zeros (= no entry) everywhere else up to the row stride n_pad.
-__global__ void __launch_bounds__(MSM_BLOCK)
-k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__restrict__ sc_extra,
-             size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *__restrict__ digits, int c, int W,
-             int wpr, size_t set_stride, msm_modulus mod, uint32_t *__restrict__ status) {
-    // digit w of term i goes to digits[(w % wpr) * set_stride + (w / wpr) * n_pad + i]: plain MSMs have
-    // wpr = W and set_stride = n_pad (row w = window w); fixed-base tables of r rows have wpr = W / r
-    // bucket sets, each a row of r * n_pad entries whose index is the table position (w / wpr, i)
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
-    const uint32_t *src = nullptr;
-    if (i < n_main) src = sc + 8 * i;
-    else if (sc_extra && i >= extra_pos && i < extra_pos + n_extra) src = sc_extra + 8 * (i - extra_pos);
-    if (!src) {                              // the sort kernels read whole 16-byte vectors of a row
-        for (int w = 0; w < W; w++) digits[(size_t)(w % wpr) * set_stride + (size_t)(w / wpr) * n_pad + i] = 0;
-        return;
-    }
-    uint32_t s[8];
-    load_u32x8(s, src);
-    {   // canonical residue? (s < modulus); the caller is told at the next sync point
-        bool ge = true;
-#pragma unroll
-        for (int k = 7; k >= 0; k--) {
-            if (s[k] != mod.v[k]) {
-                ge = s[k] > mod.v[k];
-                break;
-            }
-        }
-        if (ge) atomicAdd(&status[VMPC_ST_NONCANON], 1u);
-    }
-    const uint32_t mask = (1u << c) - 1u;
-    const uint32_t half = 1u << (c - 1);
-    uint32_t carry = 0;
-    for (int w = 0; w < W; w++) {
-        uint32_t raw = (s[0] & mask) + carry;
-        int32_t d;
-        if (raw >= half) {
-            d = (int32_t)raw - (int32_t)(1u << c);
-            carry = 1;
-        } else {
-            d = (int32_t)raw;
-            carry = 0;
-        }
-        digits[(size_t)(w % wpr) * set_stride + (size_t)(w / wpr) * n_pad + i] = (int16_t)d;
-        // s >>= c  (c < 32; static limb indices keep s[] in registers)
-#pragma unroll
-        for (int k = 0; k < 7; k++) s[k] = (s[k] >> c) | (s[k + 1] << (32 - c));
-        s[7] >>= c;
-    }
-}
-
-// ---- hist / scatter: bucket sort of one window's digits -----------------------------------
-// A workgroup owns (slice s, bucket range r, window w): it streams the slice's digits (16-byte
-// vectors of 8, re-read once per range - a window's digit row is L2 resident) and handles only
-// the entries whose bucket falls in its range.  Partitioning by BUCKET RANGE rather than only by
-// slice is what makes the scatter's stores combine: all entries of a bucket come from one
-// workgroup (per slice), so the 4-byte stores into that bucket's run meet in one XCD's L2 instead
-// of arriving from 32 workgroups on 8 XCDs (measured: 222 us -> see DESIGN.md section 5), and the
-// LDS array shrinks from 128 KiB to range_len * 4 bytes.
-template <bool SCATTER>
-__device__ __forceinline__ void msm_sort_visit(const int16_t *__restrict__ dw, size_t lo, size_t hi,
-                                               uint32_t lo_b, uint32_t nbr, uint32_t *lds,
-                                               uint32_t *__restrict__ sorted) {
-    for (size_t i = lo + 8 * (size_t)threadIdx.x; i < hi; i += 8 * (size_t)blockDim.x) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(dw + i);
-        const uint32_t word[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int d = (int)(int16_t)(word[k >> 1] >> (16 * (k & 1)));
-            const uint32_t a = (uint32_t)(d < 0 ? -d : d);
-            const uint32_t t = a - lo_b;                  // d == 0 wraps: bucket 0 is nobody's
-            if (t < nbr) {
-                if (SCATTER) {
-                    uint32_t pos = atomicAdd(&lds[t], 1u);
-                    sorted[pos] = (uint32_t)(i + k) | (d < 0 ? 0x80000000u : 0u);
-                } else {
-                    atomicAdd(&lds[t], 1u);
-                }
-            }
-        }
-    }
-}
-
-__global__ void __launch_bounds__(MSM_SORT_BLOCK)
-k_msm_hist(const int16_t *__restrict__ digits, size_t n_pad, size_t slice_len, int nb1, int S, int R,
-           int range_len, uint32_t *__restrict__ hist) {
-    extern __shared__ uint32_t lds[];
-    const int s = blockIdx.x / R, r = blockIdx.x % R, w = blockIdx.y;   // r fastest: see msm_make_plan (XCD affinity)
-    const uint32_t lo_b = (uint32_t)r * range_len + 1;
-    const uint32_t nbr = min((uint32_t)range_len, (uint32_t)nb1 - lo_b);
-    for (uint32_t b = threadIdx.x; b < nbr; b += blockDim.x) lds[b] = 0;
-    __syncthreads();
-    size_t lo = (size_t)s * slice_len;
-    size_t hi = min(lo + slice_len, n_pad);
-    msm_sort_visit<false>(digits + (size_t)w * n_pad, lo, hi, lo_b, nbr, lds, nullptr);
-    __syncthreads();
-    uint32_t *out = hist + ((size_t)w * S + s) * nb1;
-    for (uint32_t b = threadIdx.x; b < nbr; b += blockDim.x) out[lo_b + b] = lds[b];
-    if (r == 0 && threadIdx.x == 0) out[0] = 0;
-}
-
-// ---- counts: per-bucket totals; hist[w][s][b] becomes the exclusive offset of slice s ---
-__global__ void __launch_bounds__(MSM_BLOCK)
-k_msm_counts(uint32_t *__restrict__ hist, int W, int S, int nb1, uint32_t *__restrict__ counts) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)W * nb1) return;
-    int w = (int)(t / nb1), b = (int)(t % nb1);
-    uint32_t run = 0;
-    for (int s = 0; s < S; s++) {
-        size_t idx = ((size_t)w * S + s) * nb1 + b;
-        uint32_t v = hist[idx];
-        hist[idx] = run;
-        run += v;
-    }
-    counts[t] = run;
-}
-
-// ---- scatter: bucket-sorted point indices -------------------------------------------------
-__global__ void __launch_bounds__(MSM_SORT_BLOCK)
-k_msm_scatter(const int16_t *__restrict__ digits, size_t n_pad, size_t slice_len, int nb1, int S, int R,
-              int range_len, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ starts,
-              uint32_t *__restrict__ sorted) {
-    extern __shared__ uint32_t lds[];
-    const int s = blockIdx.x / R, r = blockIdx.x % R, w = blockIdx.y;   // r fastest: see msm_make_plan (XCD affinity)
-    const uint32_t lo_b = (uint32_t)r * range_len + 1;
-    const uint32_t nbr = min((uint32_t)range_len, (uint32_t)nb1 - lo_b);
-    const uint32_t *off = hist + ((size_t)w * S + s) * nb1 + lo_b;
-    const uint32_t *st = starts + (size_t)w * nb1 + lo_b;
-    for (uint32_t b = threadIdx.x; b < nbr; b += blockDim.x) lds[b] = st[b] + off[b];
-    __syncthreads();
-    size_t lo = (size_t)s * slice_len;
-    size_t hi = min(lo + slice_len, n_pad);
-    msm_sort_visit<true>(digits + (size_t)w * n_pad, lo, hi, lo_b, nbr, lds, sorted);
-}
-
-// ---- bucket accumulation, segment-balanced -----------------------------------------------
-// A lane per bucket is unbalanced three ways: Poisson spread of bucket sizes inside a wave,
-// the under-full top window (scalars < 2^253 leave it 2^3..2^13 times fewer buckets, each
-// that much fuller), and skewed witnesses (many 0/1/small scalars put half the terms into
-// one bucket).  So every bucket's sorted run is cut into segments of <= MSM_SEG entries and
-// ONE LANE PROCESSES ONE SEGMENT; segments are numbered by decreasing length (a counting
-// sort over the 64 possible lengths) so the 64 lanes of a wave run loops of equal trip
-// count.  Buckets that needed more than one segment are finished by a workgroup-wide LDS
-// tree over their partial sums.
-
-// plan, pass 1: segments per bucket + per-block histogram of segment lengths
-__global__ void __launch_bounds__(MSM_BLOCK)
-k_msm_plan1(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nblocks,
-            int seg_shift, uint32_t *__restrict__ nseg, uint32_t *__restrict__ block_hist,
-            uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ ctrl /*[0]=heavy count*/) {
-    // segments hold <= MSM_SEG << seg_shift entries; lengths are binned in units of 2^seg_shift
-    const uint32_t seg_log = MSM_SEG_LOG2 + seg_shift, unit_round = (1u << seg_shift) - 1u;
-    __shared__ uint32_t lh[MSM_SEG + 1];
-    __shared__ uint32_t heavy_n, heavy_base;
-    if (threadIdx.x <= MSM_SEG) lh[threadIdx.x] = 0;
-    if (threadIdx.x == 0) heavy_n = 0;
-    __syncthreads();
-    uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t cnt = ci < nslots ? counts[ci] : 0;
-    uint32_t full = cnt >> seg_log, rem = cnt & ((1u << seg_log) - 1u);
-    uint32_t ns = full + (rem ? 1u : 0u);
-    if (ci < nslots) nseg[ci] = ns;
-    if (full) atomicAdd(&lh[MSM_SEG], full);
-    if (rem) atomicAdd(&lh[(rem + unit_round) >> seg_shift], 1u);
-    uint32_t my_heavy = 0;
-    if (ns > 1) my_heavy = atomicAdd(&heavy_n, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0 && heavy_n) heavy_base = atomicAdd(&ctrl[0], heavy_n);
-    __syncthreads();
-    if (ns > 1) heavy_list[heavy_base + my_heavy] = ci;
-    // layout [(SEG - L) * nblocks + block]: longest segments get the smallest task ids
-    if (threadIdx.x >= 1 && threadIdx.x <= MSM_SEG)
-        block_hist[(size_t)(MSM_SEG - threadIdx.x) * nblocks + blockIdx.x] = lh[threadIdx.x];
-}
-
-// plan, pass 2: write the task table (bucket slot, segment index), grouped by length
-__global__ void __launch_bounds__(MSM_BLOCK)
-k_msm_plan2(const uint32_t *__restrict__ counts, uint32_t nslots, uint32_t nblocks, int seg_shift,
-            const uint32_t *__restrict__ block_base, uint2 *__restrict__ tasks) {
-    const uint32_t seg_log = MSM_SEG_LOG2 + seg_shift, unit_round = (1u << seg_shift) - 1u;
-    __shared__ uint32_t cur[MSM_SEG + 1];
-    if (threadIdx.x <= MSM_SEG) cur[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ci >= nslots) return;
-    uint32_t cnt = counts[ci];
-    uint32_t full = cnt >> seg_log, rem = cnt & ((1u << seg_log) - 1u);
-    if (rem) {
-        uint32_t bin = (rem + unit_round) >> seg_shift;
-        uint32_t r = atomicAdd(&cur[bin], 1u);
-        tasks[block_base[(size_t)(MSM_SEG - bin) * nblocks + blockIdx.x] + r] = make_uint2(ci, full);
-    }
-    if (full) {
-        uint32_t r = atomicAdd(&cur[MSM_SEG], full);
-        uint32_t base = block_base[blockIdx.x] + r;
-        for (uint32_t sidx = 0; sidx < full; sidx++) tasks[base + sidx] = make_uint2(ci, sidx);
-    }
-}
-
+// ---- bucket accumulation, segment-balanced (task table: msm_sort.hip) -------------------------------
 __device__ __forceinline__ ge_niels niels_ld(const uint32_t *niels, uint32_t e) {
     return niels_ld_line(niels + NIELS_WORDS * (size_t)(e & 0x7fffffffu));
 }
@@ -365,14 +161,19 @@ __device__ __forceinline__ ge_niels niels_ld(const uint32_t *niels, uint32_t e) 
 #ifndef MSM_BUCKET_WAVES
 #define MSM_BUCKET_WAVES 4
 #endif
+#ifdef MSM_BUCKET_EU
+__attribute__((amdgpu_waves_per_eu(MSM_BUCKET_EU, MSM_BUCKET_EU)))
+#endif
 __global__ void __launch_bounds__(MSM_BLOCK, MSM_BUCKET_WAVES)
 k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ sorted,
              const uint32_t *__restrict__ starts, const uint32_t *__restrict__ counts,
              const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
              const uint2 *__restrict__ tasks, const uint32_t *__restrict__ n_tasks, int nb1, int seg,
              uint32_t *__restrict__ buckets, uint32_t *__restrict__ partial) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= *n_tasks) return;
+    // grid-stride over the task table: a launch with fewer workgroups than tasks / 256 (persistent form,
+    // msm_accumulate) leaves register-file room on every SIMD for other streams' kernels
+    const uint32_t n_live = *n_tasks;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_live; t += gridDim.x * blockDim.x) {
     uint2 tk = tasks[t];
     uint32_t ci = tk.x, sidx = tk.y;
     uint32_t cnt = counts[ci];
@@ -402,6 +203,7 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
         ext_st(buckets + EXT_WORDS * msm_bucket_slot(ci, nb1), acc);
     else
         ext_st(partial + EXT_WORDS * (size_t)(seg_starts[ci] + sidx), acc);
+    }
 }
 
 // buckets that took several segments.  Lightly split ones (<= MSM_FINISH_SERIAL partial sums,
@@ -667,10 +469,12 @@ extern "C" int vmpc_ed25519_madd_rate(vmpc_ctx *ctx, int iters, double *madds_pe
     return VMPC_OK;
 }
 
+static const msm_modulus ED25519_L = {VMPC_FR_L};
+
 extern "C" int vmpc_ed25519_msm_plan(vmpc_ctx *ctx, size_t n, int *c_bits, int *windows) {
     if (!ctx || !c_bits || !windows || n == 0) return VMPC_E_INVAL;
     msm_plan p;
-    msm_make_plan(ctx, n, 0, 253, p);
+    msm_make_plan(ctx, n, 0, 253, p, &ED25519_L);
     *c_bits = p.c;
     *windows = p.W;
     return VMPC_OK;
@@ -691,203 +495,6 @@ k_points_validate(const uint32_t *__restrict__ aff, size_t n, unsigned long long
     if (!ok) atomicAdd(bad, 1ull);
 }
 
-// ---- host side ---------------------------------------------------------------------------
-// Window width.  Measured on MI355X (scripts/window_sweep.py), not modelled: the tail stages
-// (reduce, recombination) are latency chains whose length barely depends on c, so the widest
-// window the int16 digits allow wins as soon as the bucket stage matters (n > 2^13); below that
-// c = 11 keeps the reduce short.  Both choices also leave the top window of a 253-bit scalar
-// empty or well spread (W*c = 264 resp. 256), where other widths pile n/2 entries into one bucket.
-static int msm_pick_window(size_t n, int scalar_bits) {
-    if (scalar_bits == 253) return n > (1u << 13) ? 16 : 11;   // Ed25519; BN-256 keeps the model
-    double best = 1e300;
-    int best_c = 4;
-    for (int c = 4; c <= MSM_MAX_C; c++) {
-        int W = (scalar_bits + 2 + c - 1) / c;
-        double cost = (double)W * ((double)n + 2.5 * (double)(1u << (c - 1)));
-        if (cost < best) {
-            best = cost;
-            best_c = c;
-        }
-    }
-    return best_c;
-}
-
-void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits, msm_plan &p) {
-    p.n_main = n_main;
-    p.n_extra = n_extra;
-    p.n_total = n_main + n_extra;
-    p.scalar_bits = scalar_bits;
-    p.c = ctx->window_override ? ctx->window_override : msm_pick_window(p.n_total, scalar_bits);
-    if (p.c < 4) p.c = 4;
-    if (p.c > MSM_MAX_C) p.c = MSM_MAX_C;
-    // the signed recoding may carry one bit past the top: W * c >= scalar_bits + 2 keeps the top
-    // window's raw digit below 2^(c-1) (253-bit Ed25519 scalars: W = ceil(255 / c))
-    p.W = (scalar_bits + 2 + p.c - 1) / p.c;
-    while (p.W > 64) {   // the recombination kernels give one lane to each window (64-lane wave)
-        p.c++;
-        p.W = (scalar_bits + 2 + p.c - 1) / p.c;
-    }
-    msm_plan_geometry(ctx, p);
-}
-
-// everything that follows from (n_total, c, W): sort decomposition, segment length, reduce shape
-void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
-    p.nb = 1 << (p.c - 1);
-    p.nb1 = p.nb + 1;
-    // sort workgroups = (slice, bucket range, window).  Two things make the scatter's 4-byte
-    // stores combine into whole lines before they leave L2 (each XCD has its own):
-    //  * XCD affinity - workgroups are dealt round-robin to the 8 XCDs in linear block order, and
-    //    the range index is the fastest-varying part of blockIdx.x with R a multiple of 8 (R = 8
-    //    for c = 16), so every store into a given bucket range goes through the SAME L2, from
-    //    whichever slice it comes (range-major order, which spreads a range over all XCDs: 228 us
-    //    instead of 149 us at n = 2^20);
-    //  * temporal locality - windows are dispatched one after the other, and with >= 128
-    //    workgroups per window only ~4 windows' runs are being filled at any time (32 per
-    //    window = 8 windows in flight: 222 us).
-    // Ranges of <= 4096 buckets (16 KiB of LDS); slices of <= 65536 terms but at least 128/R of
-    // them, >= 4096 terms each, at most 256 (the per-slice histogram is W*S*nb1 words).
-    p.n_pad = (p.n_total + 7) & ~(size_t)7;
-    p.range_len = p.nb < ctx->sort_range ? p.nb : ctx->sort_range;
-    p.R = (p.nb + p.range_len - 1) / p.range_len;
-    size_t want = (p.n_total + 65535) >> 16;
-    size_t S_min = (size_t)(128 + p.R - 1) / p.R;
-    if (want < S_min) want = S_min;
-    if (want > 256) want = 256;
-    size_t max_s = (p.n_total + 4095) / 4096;
-    if (want > max_s) want = max_s;
-    int S = want < 1 ? 1 : (int)want;
-    if (ctx->sort_slices) S = ctx->sort_slices;
-    p.S = S;
-    p.slice_len = (((p.n_pad + S - 1) / S) + 7) & ~(size_t)7;
-    // segment length: the bucket stage wants ~4 tasks per lane of the chip (2^18) of equal length.
-    // 64 entries up to W * n = 2^24 (n = 2^20 at c = 16), doubled from there - otherwise every
-    // bucket of a 2^22-term MSM is split in three and the finish stage (one more gather of
-    // 160-byte partial sums) costs 14 %
-    p.seg_shift = 0;
-    while (p.seg_shift < 4 && (((size_t)MSM_SEG << p.seg_shift) << 18) < (size_t)p.W * p.n_total) p.seg_shift++;
-    // reduce: chunk-lanes per window (chunk length a power of two): the per-lane work is a
-    // dependency chain, so shorter chunks on more lanes cut the latency
-    // (with few windows - fixed-base tables - more chunk-lanes per window keep the same ~64 K lanes busy)
-    int chunks = MSM_REDUCE_CHUNKS;
-    while (chunks * 2 * p.W <= MSM_REDUCE_CHUNKS * 16 && chunks * 2 <= 32768) chunks *= 2;
-    if (chunks > p.nb) chunks = p.nb;
-    p.chunks = chunks;
-    p.chunk_len = p.nb / chunks;
-    p.red_blocks = (chunks + MSM_BLOCK - 1) / MSM_BLOCK;
-}
-
-void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, size_t acc_bytes) {
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-        size_t o = off;
-        off += vmpc_align(bytes);
-        return base ? (void *)(base + o) : (void *)nullptr;
-    };
-    size_t nbk = (size_t)p.W * p.nb1;
-    w.entries = (uint32_t *)take(p.n_total * entry_bytes);
-    w.digits = (int16_t *)take((size_t)p.W * p.n_pad * 2);
-    w.hist = (uint32_t *)take((size_t)p.W * p.S * p.nb1 * 4);
-    w.counts = (uint32_t *)take(nbk * 4);
-    w.starts = (uint32_t *)take(nbk * 4);
-    w.sorted = (uint32_t *)take((size_t)p.W * p.n_total * 4);
-    w.buckets = (uint32_t *)take((size_t)p.W * p.nb * acc_bytes);
-    w.partials = (uint32_t *)take((size_t)p.W * p.red_blocks * acc_bytes);
-    // segment planning: at most M/SEG full segments plus one remainder per non-empty bucket
-    size_t m_max = (size_t)p.W * p.n_total;
-    size_t nonempty_max = m_max < (size_t)p.W * p.nb ? m_max : (size_t)p.W * p.nb;
-    w.t_max = m_max / ((size_t)MSM_SEG << p.seg_shift) + nonempty_max;
-    w.plan_blocks = (uint32_t)((nbk + MSM_BLOCK - 1) / MSM_BLOCK);
-    size_t hist_n = (size_t)MSM_SEG * w.plan_blocks;
-    w.nseg = (uint32_t *)take(nbk * 4);
-    w.seg_starts = (uint32_t *)take(nbk * 4);
-    w.block_hist = (uint32_t *)take(hist_n * 4);
-    w.block_base = (uint32_t *)take(hist_n * 4);
-    w.heavy_list = (uint32_t *)take(nbk * 4);
-    w.ctrl = (uint32_t *)take(64);
-    w.tasks = (uint2 *)take(w.t_max * 8);
-    w.seg_partial = (uint32_t *)take(w.t_max * acc_bytes);
-    size_t scan_n = nbk > hist_n ? nbk : hist_n;
-    w.scan_ws = take(vmpc_scan_ws_bytes(scan_n, 4));
-    w.total = off;
-}
-
-int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scalars, size_t n,
-                   const void *extra_scalars, const msm_modulus &modulus) {
-    hipStream_t st = ctx->stream;
-    const size_t n_total = p.n_total;
-    const unsigned gb = (unsigned)((p.n_pad + MSM_BLOCK - 1) / MSM_BLOCK);
-    {
-        vmpc_stage_scope s(ctx, "msm_recode");
-        k_msm_recode<<<gb, MSM_BLOCK, 0, st>>>((const uint32_t *)scalars, n,
-                                              (const uint32_t *)extra_scalars, n, n_total - n, p.n_pad, w.digits, p.c,
-                                              p.W, p.W, p.n_pad, modulus, ctx->d_status);
-        VMPC_KERNEL_CHECK();
-    }
-    return msm_sort_digits(ctx, p, w);
-}
-
-int msm_recode_rows(vmpc_ctx *ctx, const void *scalars, size_t n_main, const void *extra_scalars,
-                    size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *digits, int c, int W, int rows,
-                    const msm_modulus &modulus) {
-    vmpc_stage_scope s(ctx, "msm_recode");
-    const int wpr = W / rows;
-    k_msm_recode<<<(unsigned)((n_pad + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
-        (const uint32_t *)scalars, n_main, (const uint32_t *)extra_scalars, extra_pos, n_extra, n_pad, digits, c,
-        W, wpr, (size_t)rows * n_pad, modulus, ctx->d_status);
-    VMPC_KERNEL_CHECK();
-    return VMPC_OK;
-}
-
-// hist -> counts/scan -> scatter -> plan over digits already in w.digits
-int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
-    hipStream_t st = ctx->stream;
-    const size_t lds_bytes = (size_t)p.range_len * 4;
-    if (lds_bytes > 48 * 1024) {
-        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_hist,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_scatter,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    }
-    {
-        vmpc_stage_scope s(ctx, "msm_hist");
-        k_msm_hist<<<dim3(p.S * p.R, p.W), MSM_SORT_BLOCK, lds_bytes, st>>>(
-            w.digits, p.n_pad, p.slice_len, p.nb1, p.S, p.R, p.range_len, w.hist);
-        VMPC_KERNEL_CHECK();
-    }
-    size_t nbk = (size_t)p.W * p.nb1;
-    {
-        vmpc_stage_scope s(ctx, "msm_counts_scan");
-        k_msm_counts<<<(unsigned)((nbk + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
-            w.hist, p.W, p.S, p.nb1, w.counts);
-        VMPC_KERNEL_CHECK();
-        VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint32_t>(st, w.counts, w.starts, nbk, w.scan_ws,
-                                                            (uint32_t *)nullptr)));
-    }
-    {
-        vmpc_stage_scope s(ctx, "msm_scatter");
-        k_msm_scatter<<<dim3(p.S * p.R, p.W), MSM_SORT_BLOCK, lds_bytes, st>>>(
-            w.digits, p.n_pad, p.slice_len, p.nb1, p.S, p.R, p.range_len, w.hist, w.starts, w.sorted);
-        VMPC_KERNEL_CHECK();
-    }
-    {
-        vmpc_stage_scope s(ctx, "msm_plan");
-        VMPC_HIP_CHECK(hipMemsetAsync(w.ctrl, 0, 64, st));
-        k_msm_plan1<<<w.plan_blocks, MSM_BLOCK, 0, st>>>(w.counts, (uint32_t)nbk, w.plan_blocks, p.seg_shift, w.nseg,
-                                                        w.block_hist, w.heavy_list, w.ctrl);
-        VMPC_KERNEL_CHECK();
-        size_t hist_n = (size_t)MSM_SEG * w.plan_blocks;
-        VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint32_t>(st, w.block_hist, w.block_base, hist_n,
-                                                            w.scan_ws, w.ctrl + 1)));   // ctrl[1] = #tasks
-        VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint32_t>(st, w.nseg, w.seg_starts, nbk, w.scan_ws,
-                                                            (uint32_t *)nullptr)));
-        k_msm_plan2<<<w.plan_blocks, MSM_BLOCK, 0, st>>>(w.counts, (uint32_t)nbk, w.plan_blocks, p.seg_shift,
-                                                        w.block_base, w.tasks);
-        VMPC_KERNEL_CHECK();
-    }
-    return VMPC_OK;
-}
-
-static const msm_modulus ED25519_L = {VMPC_FR_L};
 
 // bucket accumulation -> finish -> reduce -> recombination over a sorted task table; `entries` is
 // the niels array the sorted indices refer to (the call's own prepared points, or a fixed-base table)
@@ -896,7 +503,10 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
     hipStream_t st = ctx->stream;
     {
         vmpc_stage_scope s(ctx, "msm_bucket");
-        k_msm_bucket<<<(unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
+        unsigned grid = (unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK);
+        if (ctx->bucket_wgs_per_cu > 0 && (unsigned)(ctx->bucket_wgs_per_cu * ctx->cu_count) < grid)
+            grid = (unsigned)(ctx->bucket_wgs_per_cu * ctx->cu_count);
+        k_msm_bucket<<<grid, MSM_BLOCK, 0, st>>>(
             entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
             MSM_SEG << p.seg_shift, w.buckets, w.seg_partial);
         VMPC_KERNEL_CHECK();
@@ -947,7 +557,7 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
     }
     if (n_total >= (1ull << 31) / 16) return VMPC_E_INVAL;  // index / offset width
     msm_plan p;
-    msm_make_plan(ctx, n, n_extra, 253, p);
+    msm_make_plan(ctx, n, n_extra, 253, p, &ED25519_L);
     msm_ws w;
     msm_layout(p, w, nullptr, NIELS_WORDS * 4, EXT_WORDS * 4);
     VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
@@ -1043,6 +653,16 @@ extern "C" int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table
     p.scalar_bits = 253;
     p.c = MSM_TABLE_C;
     p.W = MSM_TABLE_W / rows;
+    p.top_row = -1;
+    p.top_max_b = 0;
+    if (rows == 1) {          // prepared generators: every window is its own row, the top one included
+        msm_plan q;
+        msm_make_plan(ctx, p.n_total, 0, 253, q, &ED25519_L);
+        if (q.c == p.c && q.W == p.W) {
+            p.top_row = q.top_row;
+            p.top_max_b = q.top_max_b;
+        }
+    }
     msm_plan_geometry(ctx, p);
     msm_ws w;
     msm_layout(p, w, nullptr, 0, EXT_WORDS * 4);

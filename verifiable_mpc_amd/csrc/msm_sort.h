@@ -1,6 +1,6 @@
-// Curve-independent half of the Pippenger pipeline (implemented in msm.hip): signed-digit
-// recoding, per-window bucket sort (LDS histograms / cursors), bucket offsets, and the
-// length-balanced segment task table.  Shared by the Ed25519 MSM (msm.hip) and the BN-256
+// Curve-independent half of the Pippenger pipeline (implemented in msm_sort.hip): signed-digit
+// recoding, the two-level per-window bucket sort (coarse bins partitioned in LDS, fine buckets
+// resolved per bin), bucket offsets, and the length-balanced segment task table.  Shared by the Ed25519 MSM (msm.hip) and the BN-256
 // G1/G2 MSMs (bn256.hip); the curve-specific kernels (entry preparation, bucket accumulation,
 // bucket reduction, window recombination) live with their curve.
 #pragma once
@@ -20,11 +20,15 @@ struct msm_plan {
     size_t n_main, n_extra, n_total;
     int scalar_bits;    // scalars are < 2^scalar_bits
     int c, W, nb, nb1;  // nb = 2^(c-1) buckets per window, nb1 = nb + 1 (bucket 0 unused)
-    int S;              // slices per window in the sort kernels
-    size_t slice_len;   // multiple of 8
     int seg_shift;      // segments of MSM_SEG << seg_shift entries
-    int R;              // bucket ranges per window in the sort kernels
-    int range_len;      // buckets per range (the LDS array of one sort workgroup)
+    int LB;             // fine bits: bucket b = coarse << LB | fine, 2^LB <= 512 fine buckets per coarse bin
+    int NC;             // coarse bins per window = nb >> LB
+    int J;              // chunks of 8192 terms per digit row
+    int idx_bits;       // bits of a term index (ceil log2 n_pad)
+    int fine_in_entry;  // the 32-bit entry between the two sort passes carries the fine bucket (idx_bits + LB <= 31)
+    int top_row;        // digit row that is the top window alone (-1: none); its bins use LB_top fine bits
+    uint32_t top_max_b; // largest bucket index a canonical scalar's top digit reaches
+    int LB_top;
     size_t n_pad;       // digit row stride: n_total rounded up to 8 (rows are 16-byte aligned, zero padded)
     int chunks;         // chunk-threads per window in the reduce kernel
     int chunk_len;      // buckets per chunk (power of two)
@@ -33,7 +37,10 @@ struct msm_plan {
 
 struct msm_ws {
     uint32_t *entries;      // prepared points, entry_bytes each
-    uint32_t *hist, *counts, *starts, *sorted;
+    uint32_t *hist1;        // [W][NC][J] coarse-bin counts per chunk, scanned in place; [hist1_n] = #entries
+    size_t hist1_n;
+    uint32_t *stage1;       // entries partitioned by (window, coarse bin)
+    uint32_t *counts, *starts, *sorted;
     uint32_t *buckets;      // W * nb accumulators, acc_bytes each
     uint32_t *partials;     // W * red_blocks accumulators
     uint32_t *nseg, *seg_starts, *block_hist, *block_base, *heavy_list, *ctrl;
@@ -50,10 +57,12 @@ struct msm_modulus {
     uint32_t v[8];
 };
 
-void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits, msm_plan &p);
+// `modulus` (scalars are canonical residues below it) lets the plan bound the top window's digits
+void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits, msm_plan &p,
+                   const msm_modulus *modulus = nullptr);
 void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p);   // from (n_total, c, W) already set
 void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, size_t acc_bytes);
-// recode -> hist -> counts/scan -> scatter -> plan: fills digits, sorted, starts, counts, nseg,
+// recode -> hist1 -> scan -> part1 -> fine -> plan: fills digits, sorted, starts, counts, nseg,
 // seg_starts, heavy_list, tasks, ctrl[0] = #split buckets, ctrl[1] = #tasks
 int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scalars, size_t n,
                    const void *extra_scalars, const msm_modulus &modulus);

@@ -1,0 +1,734 @@
+// Curve-independent half of the Pippenger pipeline for gfx950 (shared by msm.hip and bn256.hip):
+//
+//   recode   32-byte scalars -> W signed c-bit digits (int16 rows, 16-byte aligned)
+//   hist1    per (chunk of 8192 terms, window): LDS histogram of COARSE bins (high bits of the bucket)
+//   scan     one exclusive scan over [window][coarse bin][chunk] -> where every chunk's run of a bin goes
+//   part1    per (chunk, window): counting sort of the chunk by coarse bin INSIDE LDS, then each bin's
+//            run leaves as one contiguous piece (64 entries = 256 B at n = 2^20) - whole lines, not the
+//            4-byte scattered stores of a one-pass bucket sort
+//   fine     per (coarse bin, window): the bin's entries (contiguous, ~8 K, L2 resident) are read twice:
+//            histogram of the <= 512 FINE buckets in LDS, then scattered to their final, bucket-sorted
+//            place - a 32-KiB region that this one workgroup fills completely within microseconds, so
+//            the 4-byte stores merge in its XCD's L2.  Bucket counts and start offsets fall out here.
+//   plan     cut every bucket's run into <= 64-entry segments, number them by length (tasks)
+//
+// An entry between part1 and fine is  index | fine bucket << idx_bits | sign << 31  (4 bytes): the
+// digits array is read sequentially twice and never gathered.  Replaces the round-1 (slice, bucket range)
+// one-pass sort, which moved 559 MB for 67 MB of indices (partial-line read-modify-writes) and re-read
+// every digit row once per bucket range.
+//
+// Replaces the O(n) Python loop `[g[i] ** _int(x_i) for i, x_i in enumerate(x)]` of
+// verifiable_mpc/ac20/pivot.py:143 only in the sense that it orders its terms for the bucket method; the
+// arithmetic lives with the curve.
+#include "common.h"
+#include "msm_sort.h"
+#include "scan.h"
+
+#define SORT_T 8192            // terms per chunk = 1024 threads x one 16-byte vector of 8 digits
+#define SORT_BLOCK 1024
+#define SORT_WAVES (SORT_BLOCK / 64)
+#define SORT_FINE_CAP 12288    // entries of a coarse bin staged in LDS (48 KiB): 1.5 x the 8 K target
+
+__device__ __forceinline__ void load_u32x8(uint32_t dst[8], const uint32_t *src) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(src);
+    uint4 a = p[0], b = p[1];
+    dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+    dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+}
+
+// ---- recode: scalar -> signed digits ----------------------------------------------------
+// Row w of `digits` holds window w of every term: main terms at [0, n_main), extra terms at
+// [extra_pos, extra_pos + n_extra), zeros (= no entry) everywhere else up to the row stride n_pad.
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__restrict__ sc_extra,
+             size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *__restrict__ digits, int c, int W,
+             int wpr, size_t set_stride, msm_modulus mod, uint32_t *__restrict__ status) {
+    // digit w of term i goes to digits[(w % wpr) * set_stride + (w / wpr) * n_pad + i]: plain MSMs have
+    // wpr = W and set_stride = n_pad (row w = window w); fixed-base tables of r rows have wpr = W / r
+    // bucket sets, each a row of r * n_pad entries whose index is the table position (w / wpr, i)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    const uint32_t *src = nullptr;
+    if (i < n_main) src = sc + 8 * i;
+    else if (sc_extra && i >= extra_pos && i < extra_pos + n_extra) src = sc_extra + 8 * (i - extra_pos);
+    if (!src) {                              // the sort kernels read whole 16-byte vectors of a row
+        for (int w = 0; w < W; w++) digits[(size_t)(w % wpr) * set_stride + (size_t)(w / wpr) * n_pad + i] = 0;
+        return;
+    }
+    uint32_t s[8];
+    load_u32x8(s, src);
+    {   // canonical residue? (s < modulus); the caller is told at the next sync point
+        bool ge = true;
+#pragma unroll
+        for (int k = 7; k >= 0; k--) {
+            if (s[k] != mod.v[k]) {
+                ge = s[k] > mod.v[k];
+                break;
+            }
+        }
+        if (ge) {
+            // the call fails with VMPC_E_NONCANON at its sync point; until then the term counts as zero, so
+            // that every digit the sort sees obeys the bounds the plan derived from the modulus
+            atomicAdd(&status[VMPC_ST_NONCANON], 1u);
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = 0;
+        }
+    }
+    const uint32_t mask = (1u << c) - 1u;
+    const uint32_t half = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        uint32_t raw = (s[0] & mask) + carry;
+        int32_t d;
+        if (raw >= half) {
+            d = (int32_t)raw - (int32_t)(1u << c);
+            carry = 1;
+        } else {
+            d = (int32_t)raw;
+            carry = 0;
+        }
+        digits[(size_t)(w % wpr) * set_stride + (size_t)(w / wpr) * n_pad + i] = (int16_t)d;
+        // s >>= c  (c < 32; static limb indices keep s[] in registers)
+#pragma unroll
+        for (int k = 0; k < 7; k++) s[k] = (s[k] >> c) | (s[k + 1] << (32 - c));
+        s[7] >>= c;
+    }
+}
+
+// ---- coarse histogram per (chunk, window) ---------------------------------------------------
+// digit d != 0 lands in bucket b = |d| - 1 in [0, nb); coarse bin = b >> LB, fine bucket = b & (2^LB - 1)
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_sort_hist1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, int top_row, int LB_top, int J,
+             uint32_t *__restrict__ hist1, uint32_t *__restrict__ ctrl) {
+    extern __shared__ uint32_t lds[];
+    const int j = blockIdx.x, w = blockIdx.y;
+    if (w == top_row) LB = LB_top;
+    // ctrl[0] = #split buckets, [1] = #tasks, [2] = #partial sums, [16 ..) = tasks per (length class, window)
+    if (j == 0 && w == 0)
+        for (int i = threadIdx.x; i < 16 + MSM_SEG * (int)gridDim.y; i += SORT_BLOCK) ctrl[i] = 0;
+    for (int b = threadIdx.x; b < NC; b += SORT_BLOCK) lds[b] = 0;
+    __syncthreads();
+    const size_t i0 = (size_t)j * SORT_T + 8 * (size_t)threadIdx.x;
+    if (i0 < n_pad) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(digits + (size_t)w * n_pad + i0);
+        const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int d = (int)(int16_t)(word[k >> 1] >> (16 * (k & 1)));
+            if (d != 0) atomicAdd(&lds[((uint32_t)(d < 0 ? -d : d) - 1u) >> LB], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NC; b += SORT_BLOCK) hist1[((size_t)w * NC + b) * J + j] = lds[b];
+}
+
+// ---- partition a chunk by coarse bin in LDS; every bin's run leaves contiguous -----------------
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_sort_part1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, int top_row, int LB_top, int J,
+             int idx_bits, const uint32_t *__restrict__ gbase, uint32_t *__restrict__ out) {
+    extern __shared__ uint32_t lds[];
+    uint32_t *cnt = lds;                 // [NC]  run lengths
+    uint32_t *lbase = lds + NC;          // [NC]  run starts inside the stage
+    uint32_t *gb = lds + 2 * NC;         // [NC]  where the run goes in global memory
+    uint32_t *scratch = lds + 3 * NC;    // [16]
+    uint32_t *stage = lds + 3 * NC + 16; // [SORT_T]
+    // (a persistent form - two workgroups per CU walking the items - measured slower: 52 vs 38 us)
+    const int j = blockIdx.x, w = blockIdx.y;
+    if (w == top_row) LB = LB_top;
+    for (int b = threadIdx.x; b < NC; b += SORT_BLOCK) {
+        cnt[b] = 0;
+        gb[b] = gbase[((size_t)w * NC + b) * J + j];   // strided 4-byte loads: issued first, used last
+    }
+    __syncthreads();
+    const size_t i0 = (size_t)j * SORT_T + 8 * (size_t)threadIdx.x;
+    uint32_t tag[8];     // coarse bin << 16 | rank inside the bin's run; 0xffffffff = no entry
+    uint32_t word[4] = {0, 0, 0, 0};
+    if (i0 < n_pad) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(digits + (size_t)w * n_pad + i0);
+        word[0] = v.x; word[1] = v.y; word[2] = v.z; word[3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int d = (int)(int16_t)(word[k >> 1] >> (16 * (k & 1)));
+        tag[k] = 0xffffffffu;
+        if (d != 0) {
+            const uint32_t cb = ((uint32_t)(d < 0 ? -d : d) - 1u) >> LB;
+            tag[k] = (cb << 16) | atomicAdd(&cnt[cb], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the run lengths, 1024 bins per pass
+    {
+        uint32_t running = 0;
+        for (int b0 = 0; b0 < NC; b0 += SORT_BLOCK) {
+            const int b = b0 + (int)threadIdx.x;
+            uint32_t v = b < NC ? cnt[b] : 0u, tot;
+            uint32_t ex = vmpc_block_excl_scan<uint32_t>(v, &tot, scratch);
+            if (b < NC) lbase[b] = running + ex;
+            running += tot;
+        }
+    }
+    __syncthreads();
+    // idx_bits == 31: the fine bucket does not fit beside the index; k_sort_fine re-reads the digit
+    const uint32_t fmask = idx_bits < 31 ? (1u << LB) - 1u : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (tag[k] != 0xffffffffu) {
+            const int d = (int)(int16_t)(word[k >> 1] >> (16 * (k & 1)));
+            const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+            stage[lbase[tag[k] >> 16] + (tag[k] & 0xffffu)] =
+                (uint32_t)(i0 + k) | ((b & fmask) << (idx_bits & 31)) | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = wave; b < NC; b += SORT_WAVES) {
+        const uint32_t len = cnt[b], lb = lbase[b], g = gb[b];
+        for (uint32_t k = lane; k < len; k += 64) out[g + k] = stage[lb + k];
+    }
+}
+
+// ---- fine sort of one (coarse bin, window): counts, starts, bucket-sorted indices -----------------
+template <bool FINE_IN_ENTRY>
+__device__ __forceinline__ uint32_t sort_fine_of(uint32_t e, int idx_bits, uint32_t fmask,
+                                                 const int16_t *__restrict__ drow) {
+    if (FINE_IN_ENTRY) return (e >> idx_bits) & fmask;
+    const int d = (int)drow[e & 0x7fffffffu];       // huge index spaces (fixed-base tables beyond 2^22 entries
+    return ((uint32_t)(d < 0 ? -d : d) - 1u) & fmask;   // per fine bit): one 2-byte gather per entry instead
+}
+
+#define SORT_FINE_REG (SORT_FINE_CAP / SORT_BLOCK)     // entries per thread of a staged bin
+
+// LB of a row, and (top row only) the buckets no digit of a canonical scalar reaches are marked empty
+__device__ __forceinline__ int sort_row_lb(int w, int cb, int NC, int LB, int top_row, int LB_top, int nb1,
+                                           uint32_t *__restrict__ counts, uint32_t *__restrict__ nseg) {
+    if (w != top_row) return LB;
+    if (counts) {
+        const uint32_t covered = (uint32_t)NC << LB_top, nb = (uint32_t)nb1 - 1u;
+        for (uint32_t u = covered + cb * SORT_BLOCK + threadIdx.x; u < nb; u += NC * SORT_BLOCK) {
+            counts[(size_t)w * nb1 + 1 + u] = 0;
+            nseg[(size_t)w * nb1 + 1 + u] = 0;
+        }
+    }
+    return LB_top;
+}
+
+// One workgroup per (coarse bin, window).  A bin of up to SORT_FINE_CAP entries (every bin of uniformly
+// distributed scalars) lives in registers between the two phases: one read of the entries, one LDS atomic
+// each - whose return value IS the entry's rank inside its bucket - then the bucket-sorted order is
+// assembled in LDS and leaves as whole lines (4-byte stores scattered over the bin's 32-KiB region cost one
+// L2 request each: 135 us at n = 2^20; LDS takes them at bank rate).  Larger bins (skewed witnesses, the
+// under-full top window of some plans) are only counted here and sorted by k_sort_fine_big.
+// The tail is pass 1 of the segment planning: segments per bucket, the block's histogram of segment lengths,
+// and partial-sum slots for buckets that need several segments.
+template <bool FINE_IN_ENTRY>
+__global__ void __launch_bounds__(SORT_BLOCK, 8)      // 8 waves per SIMD = two workgroups per CU (<= 64 VGPRs)
+k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase, int NC, int W, int LB, int top_row,
+            int LB_top, int J, int idx_bits, int nb1, const int16_t *__restrict__ digits, size_t n_pad,
+            uint32_t *__restrict__ counts, uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
+            int seg_shift, uint32_t *__restrict__ nseg, uint32_t *__restrict__ block_hist,
+            uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ seg_starts,
+            uint32_t *__restrict__ ctrl /*[0] = #split buckets, [2] = #partial sums, [3] = #big bins*/) {
+    __shared__ uint32_t cnt[512], cur[512], scratch[16];
+    __shared__ uint32_t lh[MSM_SEG + 1], heavy_n, heavy_segs, heavy_base, heavy_seg_base;
+    __shared__ uint32_t stage[SORT_FINE_CAP];
+    // top window first: under-full, so its bins are the fullest
+    const int cb = blockIdx.x % NC, w = W - 1 - blockIdx.x / NC;
+    LB = sort_row_lb(w, cb, NC, LB, top_row, LB_top, nb1, counts, nseg);
+    const int NF = 1 << LB;
+    const size_t slot = (size_t)w * NC + cb;
+    const uint32_t lo = gbase[slot * J], hi = gbase[(slot + 1) * J];   // gbase[H] = total
+    const uint32_t fmask = (uint32_t)NF - 1u, imask = FINE_IN_ENTRY ? (1u << idx_bits) - 1u : 0x7fffffffu;
+    const int16_t *drow = digits + (size_t)w * n_pad;
+    const int lane = threadIdx.x & 63;
+    const bool staged = hi - lo <= SORT_FINE_CAP;
+    for (int f = threadIdx.x; f < NF; f += SORT_BLOCK) cnt[f] = 0;
+    if (threadIdx.x <= MSM_SEG) lh[threadIdx.x] = 0;
+    if (threadIdx.x == 0) heavy_n = heavy_segs = 0;
+    __syncthreads();
+    uint32_t ev[SORT_FINE_REG], rk2[SORT_FINE_REG / 2];      // ranks < 2^16, two per register
+    if (staged) {
+#pragma unroll
+        for (int k = 0; k < SORT_FINE_REG; k++) {
+            const uint32_t i = lo + k * SORT_BLOCK + threadIdx.x;
+            ev[k] = i < hi ? in[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < SORT_FINE_REG; k++) {
+            uint32_t r = 0;
+            if (lo + k * SORT_BLOCK + threadIdx.x < hi)
+                r = atomicAdd(&cnt[sort_fine_of<FINE_IN_ENTRY>(ev[k], idx_bits, fmask, drow)], 1u);
+            rk2[k >> 1] = (k & 1) ? (rk2[k >> 1] | (r << 16)) : r;
+        }
+    } else {
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) {
+            const uint32_t f = sort_fine_of<FINE_IN_ENTRY>(in[i], idx_bits, fmask, drow);
+            // skewed witnesses (mostly 0 / 1) put a whole wave's entries into one bucket: one atomic per wave
+            const unsigned long long act = __ballot(1);
+            const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+            if (__ballot(f == f0) == act) {
+                if (lane == (int)__builtin_ctzll(act)) atomicAdd(&cnt[f0], (uint32_t)__popcll(act));
+            } else {
+                atomicAdd(&cnt[f], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t v = threadIdx.x < (unsigned)NF ? cnt[threadIdx.x] : 0u, tot;
+        uint32_t ex = vmpc_block_excl_scan<uint32_t>(v, &tot, scratch);
+        const size_t ci = (size_t)w * nb1 + 1 + (size_t)cb * NF + threadIdx.x;   // bucket |d| = b + 1
+        if (threadIdx.x < (unsigned)NF) {
+            counts[ci] = v;
+            starts[ci] = lo + ex;
+            cur[threadIdx.x] = ex;
+        }
+        if (cb == 0 && threadIdx.x == 0) {       // slot 0 of a window is nobody's bucket
+            counts[(size_t)w * nb1] = 0;
+            starts[(size_t)w * nb1] = lo;
+            nseg[(size_t)w * nb1] = 0;
+        }
+        const uint32_t seg_log = MSM_SEG_LOG2 + seg_shift, unit_round = (1u << seg_shift) - 1u;
+        const uint32_t full = v >> seg_log, rem = v & ((1u << seg_log) - 1u);
+        const uint32_t ns = full + (rem ? 1u : 0u);
+        uint32_t my_heavy = 0, my_seg = 0;
+        if (threadIdx.x < (unsigned)NF) {
+            nseg[ci] = ns;
+            if (full) atomicAdd(&lh[MSM_SEG], full);
+            if (rem) atomicAdd(&lh[(rem + unit_round) >> seg_shift], 1u);
+            if (ns > 1) {
+                my_heavy = atomicAdd(&heavy_n, 1u);
+                my_seg = atomicAdd(&heavy_segs, ns);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && heavy_n) {       // slots handed out by one global atomic per workgroup
+            heavy_base = atomicAdd(&ctrl[0], heavy_n);
+            heavy_seg_base = atomicAdd(&ctrl[2], heavy_segs);
+        }
+        if (threadIdx.x == 0 && !staged) atomicAdd(&ctrl[3], 1u);
+        __syncthreads();
+        if (threadIdx.x < (unsigned)NF && ns > 1) {
+            heavy_list[heavy_base + my_heavy] = (uint32_t)ci;
+            seg_starts[ci] = heavy_seg_base + my_seg;
+        }
+        // this block's segments per length class, one 256-byte line; k_msm_ranks turns the column of a
+        // window's blocks into first ranks
+        if (threadIdx.x >= 1 && threadIdx.x <= MSM_SEG)
+            block_hist[slot * MSM_SEG + (threadIdx.x - 1)] = lh[threadIdx.x];
+    }
+    if (!staged) return;
+#pragma unroll
+    for (int k = 0; k < SORT_FINE_REG; k++) {
+        if (lo + k * SORT_BLOCK + threadIdx.x < hi) {
+            const uint32_t e = ev[k];
+            const uint32_t f = sort_fine_of<FINE_IN_ENTRY>(e, idx_bits, fmask, drow);
+            stage[cur[f] + ((rk2[k >> 1] >> (16 * (k & 1))) & 0xffffu)] = (e & imask) | (e & 0x80000000u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < hi - lo; i += SORT_BLOCK) sorted[lo + i] = stage[i];
+}
+
+// Bins beyond the stage: tiles of SORT_FINE_CAP entries, each sorted in LDS by fine bucket with tile-local
+// ranks; a bucket's run of the tile then leaves as one contiguous piece (one wave per bucket; the whole
+// workgroup for a run that dominates the tile), appended at the bucket's cursor.  Launched over all bins;
+// a workgroup whose bin was staged (or when no bin was big: ctrl[3] == 0) exits at once.
+template <bool FINE_IN_ENTRY>
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_sort_fine_big(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase, int NC, int W, int LB,
+                int top_row, int LB_top, int J, int idx_bits, int nb1, const int16_t *__restrict__ digits,
+                size_t n_pad, const uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
+                const uint32_t *__restrict__ ctrl) {
+    if (ctrl[3] == 0) return;
+    const int cb = blockIdx.x % NC, w = W - 1 - blockIdx.x / NC;
+    const size_t slot = (size_t)w * NC + cb;
+    const uint32_t lo = gbase[slot * J], hi = gbase[(slot + 1) * J];
+    if (hi - lo <= SORT_FINE_CAP) return;
+    __shared__ uint32_t tcnt[512], tex[512], cur[512], scratch[16], long_runs[SORT_FINE_CAP / 512 + 1], n_long;
+    __shared__ uint32_t stage[SORT_FINE_CAP];
+    LB = sort_row_lb(w, cb, NC, LB, top_row, LB_top, nb1, nullptr, nullptr);
+    const int NF = 1 << LB;
+    const uint32_t fmask = (uint32_t)NF - 1u, imask = FINE_IN_ENTRY ? (1u << idx_bits) - 1u : 0x7fffffffu;
+    const int16_t *drow = digits + (size_t)w * n_pad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < (unsigned)NF) cur[threadIdx.x] = starts[(size_t)w * nb1 + 1 + (size_t)cb * NF + threadIdx.x];
+    uint32_t ev[SORT_FINE_REG], rk2[SORT_FINE_REG / 2];
+    for (uint32_t t0 = lo; t0 < hi; t0 += SORT_FINE_CAP) {
+        const uint32_t t1 = t0 + SORT_FINE_CAP < hi ? t0 + SORT_FINE_CAP : hi;
+        for (int f = threadIdx.x; f < NF; f += SORT_BLOCK) tcnt[f] = 0;
+        if (threadIdx.x == 0) n_long = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SORT_FINE_REG; k++) {
+            const uint32_t i = t0 + k * SORT_BLOCK + threadIdx.x;
+            ev[k] = i < t1 ? in[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < SORT_FINE_REG; k++) {
+            uint32_t r = 0;
+            if (t0 + k * SORT_BLOCK + threadIdx.x < t1) {
+                const uint32_t f = sort_fine_of<FINE_IN_ENTRY>(ev[k], idx_bits, fmask, drow);
+                const unsigned long long act = __ballot(1);
+                const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+                if (__ballot(f == f0) == act) {          // a wave of one bucket (skew): one atomic
+                    uint32_t base = 0;
+                    if (lane == (int)__builtin_ctzll(act)) base = atomicAdd(&tcnt[f0], (uint32_t)__popcll(act));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    r = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+                } else {
+                    r = atomicAdd(&tcnt[f], 1u);
+                }
+            }
+            rk2[k >> 1] = (k & 1) ? (rk2[k >> 1] | (r << 16)) : r;
+        }
+        __syncthreads();
+        {
+            uint32_t v = threadIdx.x < (unsigned)NF ? tcnt[threadIdx.x] : 0u, tot;
+            uint32_t ex = vmpc_block_excl_scan<uint32_t>(v, &tot, scratch);
+            if (threadIdx.x < (unsigned)NF) tex[threadIdx.x] = ex;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SORT_FINE_REG; k++) {
+            if (t0 + k * SORT_BLOCK + threadIdx.x < t1) {
+                const uint32_t e = ev[k];
+                const uint32_t f = sort_fine_of<FINE_IN_ENTRY>(e, idx_bits, fmask, drow);
+                stage[tex[f] + ((rk2[k >> 1] >> (16 * (k & 1))) & 0xffffu)] = (e & imask) | (e & 0x80000000u);
+            }
+        }
+        __syncthreads();
+        for (int f = wave; f < NF; f += SORT_WAVES) {
+            const uint32_t len = tcnt[f], src = tex[f], dst = cur[f];
+            if (len > 512) {                            // a bucket that dominates the tile: whole workgroup, below
+                if (lane == 0) long_runs[atomicAdd(&n_long, 1u)] = (uint32_t)f;
+                continue;
+            }
+            for (uint32_t k = lane; k < len; k += 64) sorted[dst + k] = stage[src + k];
+            if (lane == 0) cur[f] = dst + len;
+        }
+        __syncthreads();
+        for (uint32_t r = 0; r < n_long; r++) {
+            const uint32_t f = long_runs[r];
+            const uint32_t len = tcnt[f], src = tex[f], dst = cur[f];
+            for (uint32_t k = threadIdx.x; k < len; k += SORT_BLOCK) sorted[dst + k] = stage[src + k];
+        }
+        __syncthreads();
+        if (threadIdx.x < n_long) cur[long_runs[threadIdx.x]] += tcnt[long_runs[threadIdx.x]];
+        __syncthreads();
+    }
+}
+
+// block_hist[block][class] (segments of that length in the block) -> the block's first rank among its
+// window's segments of that class, in place; the window's class totals go to ctrl[16 + class * W + w].
+// One workgroup per window: thread (class, group) walks NC / 16 consecutive blocks.
+__global__ void __launch_bounds__(1024)
+k_msm_ranks(uint32_t *__restrict__ block_hist, int NC, int W, uint32_t *__restrict__ ctrl) {
+    __shared__ uint32_t part[16][MSM_SEG];
+    const int w = blockIdx.x, cls = threadIdx.x % MSM_SEG, g = threadIdx.x / MSM_SEG;      // 16 groups
+    const int per = (NC + 15) / 16, b0 = g * per, b1 = b0 + per < NC ? b0 + per : NC;
+    uint32_t run = 0;
+    for (int b = b0; b < b1; b++) run += block_hist[((size_t)w * NC + b) * MSM_SEG + cls];
+    part[g][cls] = run;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int k = 0; k < 16; k++) {
+        const uint32_t v = part[k][cls];
+        if (k < g) before += v;
+        total += v;
+    }
+    run = before;
+    for (int b = b0; b < b1; b++) {
+        const size_t at = ((size_t)w * NC + b) * MSM_SEG + cls;
+        const uint32_t v = block_hist[at];
+        block_hist[at] = run;
+        run += v;
+    }
+    // class index cls = L - 1; cells are ordered longest class first
+    if (g == 0) ctrl[16 + (MSM_SEG - 1 - cls) * W + w] = total;
+}
+
+// first task id of every (length class, window) cell: exclusive scan of the 64 x W totals in the order
+// longest class first, windows ascending - longest segments get the smallest task ids
+__global__ void __launch_bounds__(1024)
+k_msm_classes(uint32_t *__restrict__ ctrl, int W, uint32_t *__restrict__ class_base) {
+    __shared__ uint32_t scratch[16];
+    const int ncell = MSM_SEG * W;                  // <= 4096
+    uint32_t running = 0;
+    for (int k0 = 0; k0 < ncell; k0 += 1024) {
+        const int k = k0 + (int)threadIdx.x;
+        uint32_t v = k < ncell ? ctrl[16 + k] : 0u, tot;
+        uint32_t ex = vmpc_block_excl_scan<uint32_t>(v, &tot, scratch);
+        if (k < ncell) class_base[k] = running + ex;
+        running += tot;
+    }
+    if (threadIdx.x == 0) ctrl[1] = running;        // #tasks
+}
+
+// plan, pass 2 (pass 1 is the tail of k_sort_fine): one block per (window, coarse bin), one thread per
+// bucket: task id = first id of the (length, window) cell + this block's first rank in it + a local rank
+__global__ void __launch_bounds__(512)
+k_msm_plan2(const uint32_t *__restrict__ counts, int NC, int W, int NF, int top_row, int NF_top, int nb1, int seg_shift,
+            const uint32_t *__restrict__ class_base, const uint32_t *__restrict__ block_rank,
+            uint2 *__restrict__ tasks) {
+    const uint32_t seg_log = MSM_SEG_LOG2 + seg_shift, unit_round = (1u << seg_shift) - 1u;
+    __shared__ uint32_t cur[MSM_SEG + 1], first[MSM_SEG + 1];
+    const uint32_t block = blockIdx.x;
+    const int w = block / NC, cb = block % NC;
+    if (threadIdx.x >= 1 && threadIdx.x <= MSM_SEG) {
+        cur[threadIdx.x] = 0;
+        first[threadIdx.x] = class_base[(MSM_SEG - threadIdx.x) * W + w] +
+                             block_rank[(size_t)block * MSM_SEG + (threadIdx.x - 1)];
+    }
+    __syncthreads();
+    if (w == top_row) NF = NF_top;
+    if (threadIdx.x >= (unsigned)NF) return;
+    const size_t ci = (size_t)w * nb1 + 1 + (size_t)cb * NF + threadIdx.x;
+    uint32_t cnt = counts[ci];
+    uint32_t full = cnt >> seg_log, rem = cnt & ((1u << seg_log) - 1u);
+    if (rem) {
+        uint32_t bin = (rem + unit_round) >> seg_shift;
+        uint32_t r = atomicAdd(&cur[bin], 1u);
+        tasks[first[bin] + r] = make_uint2((uint32_t)ci, full);
+    }
+    if (full) {
+        uint32_t r = atomicAdd(&cur[MSM_SEG], full);
+        uint32_t base = first[MSM_SEG] + r;
+        for (uint32_t sidx = 0; sidx < full; sidx++) tasks[base + sidx] = make_uint2((uint32_t)ci, sidx);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------
+// Window width.  Measured on MI355X (scripts/window_sweep.py), not modelled: the tail stages
+// (reduce, recombination) are latency chains whose length barely depends on c, so the widest
+// window the int16 digits allow wins as soon as the bucket stage matters (n > 2^13); below that
+// c = 11 keeps the reduce short.  Both choices also leave the top window of a 253-bit scalar
+// empty or well spread (W*c = 264 resp. 256), where other widths pile n/2 entries into one bucket.
+static int msm_pick_window(size_t n, int scalar_bits) {
+    if (scalar_bits == 253) return n > (1u << 13) ? 16 : 11;   // Ed25519; BN-256 keeps the model
+    double best = 1e300;
+    int best_c = 4;
+    for (int c = 4; c <= MSM_MAX_C; c++) {
+        int W = (scalar_bits + 2 + c - 1) / c;
+        double cost = (double)W * ((double)n + 2.5 * (double)(1u << (c - 1)));
+        if (cost < best) {
+            best = cost;
+            best_c = c;
+        }
+    }
+    return best_c;
+}
+
+// largest bucket index (|digit| - 1, after the signed recoding's carry) the top window can hold for
+// canonical scalars: (modulus - 1) >> (c * (W - 1)), plus the carry, minus one
+static uint32_t msm_top_max_bucket(const msm_modulus &mod, int c, int W) {
+    uint32_t m1[8];
+    uint64_t borrow = 1;
+    for (int i = 0; i < 8; i++) {
+        uint64_t v = (uint64_t)mod.v[i] - borrow;
+        m1[i] = (uint32_t)v;
+        borrow = (v >> 63) & 1;
+    }
+    const int shift = c * (W - 1);
+    if (shift >= 256) return 0;
+    uint64_t top = 0;
+    for (int bit = 0; bit < 32 && shift + bit < 256; bit++)
+        top |= (uint64_t)((m1[(shift + bit) >> 5] >> ((shift + bit) & 31)) & 1u) << bit;
+    for (int bit = shift + 32; bit < 256; bit++)
+        if ((m1[bit >> 5] >> (bit & 31)) & 1u) return 0xffffffffu;
+    return (uint32_t)(top > 0xfffffffeull ? 0xffffffffull : top);     // raw + carry - 1 = raw
+}
+
+void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits, msm_plan &p,
+                   const msm_modulus *modulus) {
+    p.n_main = n_main;
+    p.n_extra = n_extra;
+    p.n_total = n_main + n_extra;
+    p.scalar_bits = scalar_bits;
+    p.c = ctx->window_override ? ctx->window_override : msm_pick_window(p.n_total, scalar_bits);
+    if (p.c < 4) p.c = 4;
+    if (p.c > MSM_MAX_C) p.c = MSM_MAX_C;
+    // the signed recoding may carry one bit past the top: W * c >= scalar_bits + 2 keeps the top
+    // window's raw digit below 2^(c-1) (253-bit Ed25519 scalars: W = ceil(255 / c))
+    p.W = (scalar_bits + 2 + p.c - 1) / p.c;
+    while (p.W > 64) {   // the recombination kernels give one lane to each window (64-lane wave)
+        p.c++;
+        p.W = (scalar_bits + 2 + p.c - 1) / p.c;
+    }
+    p.top_row = -1;
+    p.top_max_b = 0;
+    if (modulus) {
+        p.top_row = p.W - 1;
+        p.top_max_b = msm_top_max_bucket(*modulus, p.c, p.W);
+    }
+    msm_plan_geometry(ctx, p);
+}
+
+// everything that follows from (n_total, c, W): sort decomposition, segment length, reduce shape
+void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
+    p.nb = 1 << (p.c - 1);
+    p.nb1 = p.nb + 1;
+    p.n_pad = (p.n_total + 7) & ~(size_t)7;
+    // two-level sort: bucket b = coarse << LB | fine.  The fine buckets of a coarse bin are resolved by
+    // one workgroup in LDS (<= 512), the index and the fine bucket share a 32-bit entry with the sign,
+    // and a coarse bin should hold ~8 K entries (its workgroup reads it twice out of L2) - but not be
+    // so narrow that a chunk's run of a bin (8192 / NC entries) drops below a quarter line.
+    p.idx_bits = 1;
+    while (((size_t)1 << p.idx_bits) < p.n_pad) p.idx_bits++;
+    int lb = p.c - 1;
+    if (lb > 9) lb = 9;
+    while (lb > 0 && (p.nb >> lb) < 512 && (p.n_total >> (p.c - 1 - lb)) > 8192) lb--;
+    if (ctx->sort_fine_bits >= 0 && ctx->sort_fine_bits <= lb && (p.nb >> ctx->sort_fine_bits) <= 4096)
+        lb = ctx->sort_fine_bits;                                                          // tuning knob
+    p.LB = lb;
+    p.NC = p.nb >> lb;                                       // <= 4096 (c <= 16, lb >= 3 whenever nb > 4096)
+    p.fine_in_entry = p.idx_bits + lb <= 31;
+    // the top window alone in its row (plain MSMs, one-row tables): its digits stop at top_max_b, so its
+    // coarse bins are cut finer - the smallest LB_top that still maps every reachable bucket below NC
+    p.LB_top = lb;
+    if (p.top_row >= 0) {
+        int lt = 0;
+        while (lt < lb && (p.top_max_b >> lt) > (uint32_t)(p.NC - 1)) lt++;
+        p.LB_top = lt;
+    }
+    p.J = (int)((p.n_pad + SORT_T - 1) / SORT_T);
+    // segment length: the bucket stage wants ~4 tasks per lane of the chip (2^18) of equal length.
+    // 64 entries up to W * n = 2^24 (n = 2^20 at c = 16), doubled from there - otherwise every
+    // bucket of a 2^22-term MSM is split in three and the finish stage (one more gather of
+    // 160-byte partial sums) costs 14 %
+    p.seg_shift = 0;
+    while (p.seg_shift < 4 && (((size_t)MSM_SEG << p.seg_shift) << 18) < (size_t)p.W * p.n_total) p.seg_shift++;
+    // reduce: chunk-lanes per window (chunk length a power of two): the per-lane work is a
+    // dependency chain, so shorter chunks on more lanes cut the latency
+    // (with few windows - fixed-base tables - more chunk-lanes per window keep the same ~64 K lanes busy)
+    int chunks = MSM_REDUCE_CHUNKS;
+    while (chunks * 2 * p.W <= MSM_REDUCE_CHUNKS * 16 && chunks * 2 <= 32768) chunks *= 2;
+    if (chunks > p.nb) chunks = p.nb;
+    p.chunks = chunks;
+    p.chunk_len = p.nb / chunks;
+    p.red_blocks = (chunks + MSM_BLOCK - 1) / MSM_BLOCK;
+}
+
+void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, size_t acc_bytes) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += vmpc_align(bytes);
+        return base ? (void *)(base + o) : (void *)nullptr;
+    };
+    size_t nbk = (size_t)p.W * p.nb1;
+    w.entries = (uint32_t *)take(p.n_total * entry_bytes);
+    w.digits = (int16_t *)take((size_t)p.W * p.n_pad * 2);
+    w.hist1_n = (size_t)p.W * p.NC * p.J;
+    w.hist1 = (uint32_t *)take((w.hist1_n + 1) * 4);
+    w.counts = (uint32_t *)take(nbk * 4);
+    w.starts = (uint32_t *)take(nbk * 4);
+    w.stage1 = (uint32_t *)take((size_t)p.W * p.n_total * 4);
+    w.sorted = (uint32_t *)take((size_t)p.W * p.n_total * 4);
+    w.buckets = (uint32_t *)take((size_t)p.W * p.nb * acc_bytes);
+    w.partials = (uint32_t *)take((size_t)p.W * p.red_blocks * acc_bytes);
+    // segment planning: at most M/SEG full segments plus one remainder per non-empty bucket
+    size_t m_max = (size_t)p.W * p.n_total;
+    size_t nonempty_max = m_max < (size_t)p.W * p.nb ? m_max : (size_t)p.W * p.nb;
+    w.t_max = m_max / ((size_t)MSM_SEG << p.seg_shift) + nonempty_max;
+    w.plan_blocks = (uint32_t)(p.W * p.NC);                  // one block of the task table per (window, coarse bin)
+    size_t hist_n = (size_t)MSM_SEG * w.plan_blocks;
+    w.block_hist = (uint32_t *)take(hist_n * 4);              // [block][length class]: the block's first rank in the cell
+    w.block_base = (uint32_t *)take((size_t)MSM_SEG * p.W * 4);   // [length class][window]: the cell's first task id
+    w.nseg = (uint32_t *)take(nbk * 4);
+    w.seg_starts = (uint32_t *)take(nbk * 4);                 // written for split buckets only
+    w.heavy_list = (uint32_t *)take(nbk * 4);
+    w.ctrl = (uint32_t *)take((16 + (size_t)MSM_SEG * p.W) * 4);
+    w.tasks = (uint2 *)take(w.t_max * 8);
+    w.seg_partial = (uint32_t *)take(w.t_max * acc_bytes);
+    size_t scan_n = hist_n;
+    if (w.hist1_n > scan_n) scan_n = w.hist1_n;
+    w.scan_ws = take(vmpc_scan_ws_bytes(scan_n, 4));
+    w.total = off;
+}
+
+int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scalars, size_t n,
+                   const void *extra_scalars, const msm_modulus &modulus) {
+    hipStream_t st = ctx->stream;
+    const size_t n_total = p.n_total;
+    const unsigned gb = (unsigned)((p.n_pad + MSM_BLOCK - 1) / MSM_BLOCK);
+    {
+        vmpc_stage_scope s(ctx, "msm_recode");
+        k_msm_recode<<<gb, MSM_BLOCK, 0, st>>>((const uint32_t *)scalars, n,
+                                              (const uint32_t *)extra_scalars, n, n_total - n, p.n_pad, w.digits, p.c,
+                                              p.W, p.W, p.n_pad, modulus, ctx->d_status);
+        VMPC_KERNEL_CHECK();
+    }
+    return msm_sort_digits(ctx, p, w);
+}
+
+int msm_recode_rows(vmpc_ctx *ctx, const void *scalars, size_t n_main, const void *extra_scalars,
+                    size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *digits, int c, int W, int rows,
+                    const msm_modulus &modulus) {
+    vmpc_stage_scope s(ctx, "msm_recode");
+    const int wpr = W / rows;
+    k_msm_recode<<<(unsigned)((n_pad + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
+        (const uint32_t *)scalars, n_main, (const uint32_t *)extra_scalars, extra_pos, n_extra, n_pad, digits, c,
+        W, wpr, (size_t)rows * n_pad, modulus, ctx->d_status);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+// hist1 -> scan -> part1 -> fine -> plan over digits already in w.digits
+int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
+    hipStream_t st = ctx->stream;
+    const dim3 chunk_grid(p.J, p.W);
+    {
+        vmpc_stage_scope s(ctx, "msm_hist");
+        k_sort_hist1<<<chunk_grid, SORT_BLOCK, (size_t)p.NC * 4, st>>>(w.digits, p.n_pad, p.NC, p.LB, p.top_row,
+                                                                      p.LB_top, p.J, w.hist1, w.ctrl);
+        VMPC_KERNEL_CHECK();
+        VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint32_t>(st, w.hist1, w.hist1, w.hist1_n, w.scan_ws,
+                                                            w.hist1 + w.hist1_n)));    // [H] = #entries
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_part");
+        const size_t lds_bytes = ((size_t)3 * p.NC + 16 + SORT_T) * 4;
+        if (lds_bytes > 48 * 1024)
+            VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_sort_part1,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        k_sort_part1<<<chunk_grid, SORT_BLOCK, lds_bytes, st>>>(
+            w.digits, p.n_pad, p.NC, p.LB, p.top_row, p.LB_top, p.J, p.fine_in_entry ? p.idx_bits : 31, w.hist1,
+            w.stage1);
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_sort");
+        const unsigned grid = (unsigned)p.NC * (unsigned)p.W;
+        if (p.fine_in_entry) {
+            k_sort_fine<true><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.LB_top, p.J,
+                                                          p.idx_bits, p.nb1, w.digits, p.n_pad, w.counts, w.starts,
+                                                          w.sorted, p.seg_shift, w.nseg, w.block_hist, w.heavy_list,
+                                                          w.seg_starts, w.ctrl);
+            k_sort_fine_big<true><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.LB_top,
+                                                              p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.starts,
+                                                              w.sorted, w.ctrl);
+        } else {
+            k_sort_fine<false><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.LB_top, p.J,
+                                                           p.idx_bits, p.nb1, w.digits, p.n_pad, w.counts, w.starts,
+                                                           w.sorted, p.seg_shift, w.nseg, w.block_hist, w.heavy_list,
+                                                           w.seg_starts, w.ctrl);
+            k_sort_fine_big<false><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.LB_top,
+                                                               p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.starts,
+                                                               w.sorted, w.ctrl);
+        }
+        VMPC_KERNEL_CHECK();
+    }
+    {
+        vmpc_stage_scope s(ctx, "msm_plan");
+        k_msm_ranks<<<p.W, 1024, 0, st>>>(w.block_hist, p.NC, p.W, w.ctrl);
+        VMPC_KERNEL_CHECK();
+        k_msm_classes<<<1, 1024, 0, st>>>(w.ctrl, p.W, w.block_base);
+        VMPC_KERNEL_CHECK();
+        k_msm_plan2<<<w.plan_blocks, 512, 0, st>>>(w.counts, p.NC, p.W, 1 << p.LB, p.top_row, 1 << p.LB_top, p.nb1,
+                                                  p.seg_shift, w.block_base, w.block_hist, w.tasks);
+        VMPC_KERNEL_CHECK();
+    }
+    return VMPC_OK;
+}

@@ -57,6 +57,12 @@ class HipBackend:
         ctx = self.ctxs[slot]
         if ctx is not self.ctxs[0]:
             ctx.wait_for(self.ctxs[0])
+        table = getattr(points, "_table", None)
+        if table is not None and points._table_tail == 0 and len(scalars) <= table.n:
+            # generators held in prepared form (PointVector.precompute): no per-call point preparation
+            ctx.msm_table(table.ptr, table.n, len(table.extra_bytes), scalars.ptr, len(scalars), None,
+                          self.partial_bufs[slot].data_ptr(), None, rows=table.rows)
+            return
         ctx.msm(scalars.ptr, points.affine_ptr, len(scalars), None, None, 0,
                 self.partial_bufs[slot].data_ptr(), None)
 
