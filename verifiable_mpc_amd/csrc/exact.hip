@@ -64,6 +64,8 @@ struct u256_arg {
     uint32_t v[8];
 };
 
+static inline unsigned ex_grid(size_t n) { return (unsigned)((n + EX_BLOCK - 1) / EX_BLOCK); }
+
 // ---- fold ---------------------------------------------------------------------------------
 #ifndef EX_FOLD_WAVES
 #define EX_FOLD_WAVES 2
@@ -219,6 +221,59 @@ k_normalize(const uint32_t *__restrict__ proj, size_t n, uint32_t *__restrict__ 
     ex_fe_st(out_aff + 16 * i + 8, a.y);
 }
 
+// Montgomery's trick: one field inversion per NORM_BATCH elements instead of one each (265 of the ~275
+// multiplications of a normalisation are the inversion).  A lane owns the elements t, t + lanes, t + 2 lanes, ...
+// (coalesced across the wave); the running products Z_0 ... Z_k wait in the elements' own 64-byte output
+// slots, so no scratch memory is needed.  An element with Z = 0 (not a point) is left out of the product and
+// comes out as (0, 0), which no validation accepts.
+#define NORM_BATCH 8
+__global__ void __launch_bounds__(EX_BLOCK)
+k_normalize_batched(const uint32_t *__restrict__ proj, size_t n, size_t lanes, uint32_t *__restrict__ out_aff) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    fe run = fe_one();
+#pragma unroll 1
+    for (int k = 0; k < NORM_BATCH; k++) {
+        const size_t e = t + (size_t)k * lanes;
+        if (e >= n) break;
+        const fe Z = ex_fe_ld(proj + 24 * e + 16);
+        if (!fe_is_zero(Z)) run = fe_mul(run, Z);
+        ex_fe_st(out_aff + 16 * e, run);
+    }
+    fe inv = fe_inv(run);
+#pragma unroll 1
+    for (int k = NORM_BATCH - 1; k >= 0; k--) {
+        const size_t e = t + (size_t)k * lanes;
+        if (e >= n) continue;
+        const fe Z = ex_fe_ld(proj + 24 * e + 16);
+        if (fe_is_zero(Z)) {
+            ex_fe_st(out_aff + 16 * e, fe_zero());
+            ex_fe_st(out_aff + 16 * e + 8, fe_zero());
+            continue;
+        }
+        const fe prev = k > 0 ? ex_fe_ld(out_aff + 16 * (e - lanes)) : fe_one();
+        const fe zi = fe_mul(inv, prev);          // 1 / Z_e
+        inv = fe_mul(inv, Z);                     // 1 / (Z_0 ... Z_{e-1})
+        const fe x = fe_mul(ex_fe_ld(proj + 24 * e), zi), y = fe_mul(ex_fe_ld(proj + 24 * e + 8), zi);
+        ex_fe_st(out_aff + 16 * e, x);
+        ex_fe_st(out_aff + 16 * e + 8, y);
+    }
+}
+
+// the same over a buffer of n x 96-byte points, entry point for other translation units (msm.hip)
+int vmpc_normalize_launch(vmpc_ctx *ctx, const void *proj, size_t n, void *out_affine) {
+    if (n == 0) return VMPC_OK;
+    if (n < 4096) {        // short vectors: the chain of one inversion is the whole latency either way
+        k_normalize<<<ex_grid(n), EX_BLOCK, 0, ctx->stream>>>((const uint32_t *)proj, n, (uint32_t *)out_affine);
+    } else {
+        const size_t lanes = (n + NORM_BATCH - 1) / NORM_BATCH;
+        k_normalize_batched<<<ex_grid(lanes), EX_BLOCK, 0, ctx->stream>>>((const uint32_t *)proj, n, lanes,
+                                                                         (uint32_t *)out_affine);
+    }
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
 __global__ void __launch_bounds__(EX_BLOCK)
 k_affine_to_proj(const uint32_t *__restrict__ aff, size_t n, uint32_t *__restrict__ out_proj) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -229,7 +284,6 @@ k_affine_to_proj(const uint32_t *__restrict__ aff, size_t n, uint32_t *__restric
     ex_fe_st(out_proj + 24 * i + 16, p.Z);
 }
 
-static inline unsigned ex_grid(size_t n) { return (unsigned)((n + EX_BLOCK - 1) / EX_BLOCK); }
 
 extern "C" int vmpc_fold_dev(vmpc_ctx *ctx, const void *g_l, const void *g_r, int in_affine,
                              const uint8_t c[32], size_t half, void *out_proj, void *out_affine) {
@@ -309,10 +363,7 @@ extern "C" int vmpc_normalize_dev(vmpc_ctx *ctx, const void *proj, size_t n, voi
     if (n == 0) return VMPC_OK;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     vmpc_stage_scope s(ctx, "normalize");
-    k_normalize<<<ex_grid(n), EX_BLOCK, 0, ctx->stream>>>((const uint32_t *)proj, n,
-                                                          (uint32_t *)out_affine);
-    VMPC_KERNEL_CHECK();
-    return VMPC_OK;
+    return vmpc_normalize_launch(ctx, proj, n, out_affine);
 }
 
 extern "C" int vmpc_affine_to_proj_dev(vmpc_ctx *ctx, const void *affine, size_t n, void *out_proj) {

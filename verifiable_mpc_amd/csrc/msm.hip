@@ -610,10 +610,32 @@ k_msm_table_build(const uint32_t *__restrict__ aff, size_t n_main, const uint32_
     niels_st_line(table + NIELS_WORDS * i, ge_niels_from_affine(a));
     ge_ext q = ge_ext_from_affine(a);
     const int dbl_per_row = MSM_TABLE_C * (MSM_TABLE_W / rows);
+    // Rows 1 .. rows-1 need the AFFINE form of 2^(k rho) P: one inversion for all of them (Montgomery's
+    // trick).  Pass 1 parks (X, Y, Z, Z_1 ... Z_rho) of row rho in the row's own 128-byte slot; pass 2 walks
+    // back with the running inverse and overwrites the slot with the niels entry.
+    fe run = fe_one();
     for (int r = 1; r < rows; r++) {
         for (int k = 0; k < dbl_per_row; k++) q = ge_dbl(q);
-        ge_aff b = ge_ext_to_affine(q);
-        niels_st_line(table + NIELS_WORDS * ((size_t)r * stride + i), ge_niels_from_affine(b));
+        run = fe_mul(run, q.Z);
+        uint32_t *slot = table + NIELS_WORDS * ((size_t)r * stride + i);
+        fe_st8(slot, q.X);
+        fe_st8(slot + 8, q.Y);
+        fe_st8(slot + 16, q.Z);
+        fe_st8(slot + 24, run);
+    }
+    if (rows > 1) {
+        fe inv = fe_inv(run);
+        for (int r = rows - 1; r >= 1; r--) {
+            uint32_t *slot = table + NIELS_WORDS * ((size_t)r * stride + i);
+            const fe Z = fe_ld8(slot + 16);
+            const fe prev = r > 1 ? fe_ld8(table + NIELS_WORDS * ((size_t)(r - 1) * stride + i) + 24) : fe_one();
+            const fe zi = fe_mul(inv, prev);
+            inv = fe_mul(inv, Z);
+            ge_aff b;
+            b.x = fe_canon(fe_mul(fe_ld8(slot), zi));
+            b.y = fe_canon(fe_mul(fe_ld8(slot + 8), zi));
+            niels_st_line(slot, ge_niels_from_affine(b));
+        }
     }
 }
 
@@ -679,6 +701,8 @@ extern "C" int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table
 // 253-doubling ladder per element: a comb table  T[w][d-1] = d * 2^(8w) * B,  d = 1..128, w = 0..31
 // (4096 niels entries, 512 KiB, L2 resident) turns every output into 32 mixed additions of signed
 // 8-bit digits plus one inversion - 6x less work than the exact replay of vmpc_repeat_dev.
+int vmpc_normalize_launch(vmpc_ctx *ctx, const void *proj, size_t n, void *out_affine);   // exact.hip
+
 #define FB_C 8
 #define FB_W 32
 #define FB_D 128
@@ -712,7 +736,7 @@ k_fb_table(const uint32_t *__restrict__ bases, uint32_t *__restrict__ table /*FB
 
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_fb_apply(const uint32_t *__restrict__ table, const uint32_t *__restrict__ sc, size_t n, msm_modulus mod,
-           uint32_t *__restrict__ status, uint32_t *__restrict__ out_aff) {
+           uint32_t *__restrict__ status, uint32_t *__restrict__ out_proj) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t s[8];
@@ -747,9 +771,11 @@ k_fb_apply(const uint32_t *__restrict__ table, const uint32_t *__restrict__ sc, 
         }
     }
     // scalars are < l < 2^253: the top digit is < 32, no carry leaves the last window
-    ge_aff a = ge_ext_to_affine(acc);
-    fe_st8(out_aff + 16 * i, a.x);
-    fe_st8(out_aff + 16 * i + 8, a.y);
+    // (X : Y : Z) goes out un-normalised: the inversion would be 265 of this lane's 489 multiplications;
+    // vmpc_normalize_launch shares one among eight elements (Montgomery's trick, exact.hip)
+    fe_st8(out_proj + 24 * i, acc.X);
+    fe_st8(out_proj + 24 * i + 8, acc.Y);
+    fe_st8(out_proj + 24 * i + 16, acc.Z);
 }
 
 extern "C" int vmpc_fixed_base_dev(vmpc_ctx *ctx, const void *base_affine, const void *scalars, size_t n,
@@ -760,18 +786,20 @@ extern "C" int vmpc_fixed_base_dev(vmpc_ctx *ctx, const void *base_affine, const
     hipStream_t st = ctx->stream;
     const size_t bases_bytes = vmpc_align((size_t)FB_W * EXT_WORDS * 4);
     const size_t table_bytes = vmpc_align((size_t)FB_W * FB_D * NIELS_WORDS * 4);
-    VMPC_CHECK(vmpc_ws_reserve(ctx, bases_bytes + table_bytes + 512));
+    const size_t proj_bytes = vmpc_align(n * 96);
+    VMPC_CHECK(vmpc_ws_reserve(ctx, bases_bytes + table_bytes + proj_bytes + 1024));
     uint32_t *bases = (uint32_t *)vmpc_ws_take(ctx, bases_bytes);
     uint32_t *table = (uint32_t *)vmpc_ws_take(ctx, table_bytes);
+    uint32_t *proj = (uint32_t *)vmpc_ws_take(ctx, proj_bytes);
     vmpc_stage_scope s(ctx, "fixed_base");
     k_fb_bases<<<1, 64, 0, st>>>((const uint32_t *)base_affine, bases);
     VMPC_KERNEL_CHECK();
     k_fb_table<<<(FB_W * FB_D + MSM_BLOCK - 1) / MSM_BLOCK, MSM_BLOCK, 0, st>>>(bases, table);
     VMPC_KERNEL_CHECK();
     k_fb_apply<<<(unsigned)((n + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
-        table, (const uint32_t *)scalars, n, ED25519_L, ctx->d_status, (uint32_t *)out_affine);
+        table, (const uint32_t *)scalars, n, ED25519_L, ctx->d_status, proj);
     VMPC_KERNEL_CHECK();
-    return VMPC_OK;
+    return vmpc_normalize_launch(ctx, proj, n, out_affine);
 }
 
 extern "C" int vmpc_points_sum_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, void *out_ext,
