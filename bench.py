@@ -229,6 +229,8 @@ def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch):
     gamma = 0x7654321
     y = gf(L(x))
     P = crs.commit([(x.concat([gamma]), None)])[0]
+    out["blocks"] = world
+    out["scalars_per_rank_and_round"] = 3 * (N // world)
     for attempt in ("first_call", "steady"):
         r = vm.ScalarVector.from_array(rand_scalars(rng, n))
         ctx.sync()
@@ -258,8 +260,9 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL all-gather + ordered combine even with one rank (self-test)")
     ap.add_argument("--sharded-prove", action="store_true",
-                    help="also time the sharded compact prover (needs a process group; opt-in so that a "
-                         "collective going wrong cannot cost the headline line)")
+                    help="time the sharded compact prover also with one rank (--force-collective); with more "
+                         "than one rank it is timed by default (--no-sharded-prove to skip)")
+    ap.add_argument("--no-sharded-prove", action="store_true")
     ap.add_argument("--variable-base", action="store_true",
                     help="headline on generators given as plain affine points (prepared per call) instead of "
                          "generators resident in prepared form; the other mode is always reported beside it")
@@ -461,16 +464,35 @@ def main():
             except Exception as e:
                 line["bn256_n2^18"] = {"error": f"{type(e).__name__}: {e}"}
     sharded_info = None
-    if dist and args.sharded_prove:
-        # every rank takes part; a failure here must not cost the headline line
+    if dist and (args.sharded_prove or (world > 1 and not args.no_sharded_prove)):
+        # every rank takes part; neither a failure nor a stuck collective here may cost the headline line:
+        # rank 0 arms a watchdog that prints the line without this section and leaves
+        watchdog = None
+        if rank == 0:
+            import threading
+
+            def give_up():
+                line["ac20_n2^20_sharded"] = {"error": "no result within 240 s"}
+                print(json.dumps(line), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(240.0, give_up)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             sharded_info = {k: round(v, 2) for k, v in
                             sharded_prove_timing(vm, ctx, 20, world, rank, dist, torch).items()}
         except Exception as e:
             sharded_info = {"error": f"{type(e).__name__}: {e}"}
+        if watchdog is not None:
+            watchdog.cancel()
     if rank == 0:
         if sharded_info is not None:
             line["ac20_n2^20_sharded"] = sharded_info
+        try:        # RCCL's version banner sits in the C stdio buffer: push it out first, the JSON line is the last line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

@@ -187,6 +187,11 @@ int vmpc_fr_tail_scalars_dev(vmpc_ctx *ctx, const uint8_t *challenges, int t, in
  * c_{t-1} is passed: two products per element and round instead of up to t + 1. */
 int vmpc_fr_tail_scalars_inc_dev(vmpc_ctx *ctx, const uint8_t newest_challenge[32], int t, int log2_m0,
                                  const void *z, void *products, void *out_a, void *out_b);
+/* the same for positions j0 .. j0 + count - 1 only; products / out_a / out_b hold `count` elements (one rank's
+ * block of g_hat in the sharded prover: scalar work proportional to the block, not to N) */
+int vmpc_fr_tail_scalars_block_dev(vmpc_ctx *ctx, const uint8_t newest_challenge[32], int t, int log2_m0,
+                                   const void *z, size_t j0, size_t count, void *products, void *out_a,
+                                   void *out_b);
 /* synchronous: result copied to host */
 int vmpc_fr_dot_dev(vmpc_ctx *ctx, const void *a, const void *b, size_t n, uint8_t out[32]);
 /* the same, result left in device memory (32 bytes at out_dev, asynchronous) */

@@ -33,7 +33,7 @@ SYMBOLS = [
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
     "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_fr_dot_to_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
     "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
-    "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev",
+    "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev", "vmpc_fr_tail_scalars_block_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
     "vmpc_bn256_validate_dev", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
 ]
@@ -110,6 +110,7 @@ def load_library():
         "vmpc_fr_challenge_products_dev": (i32, [vp, vp, i32, i32, vp, sz, vp]),
         "vmpc_fr_tail_scalars_dev": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "vmpc_fr_tail_scalars_inc_dev": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
+        "vmpc_fr_tail_scalars_block_dev": (i32, [vp, vp, i32, i32, vp, sz, sz, vp, vp, vp]),
         "vmpc_bn256_g1_msm": (i32, [vp, vp, sz, vp]),
         "vmpc_bn256_g2_msm": (i32, [vp, vp, sz, vp]),
         "vmpc_bn256_g1_msm_dev": (i32, [vp, vp, vp, sz, vp]),
@@ -519,6 +520,13 @@ class Context:
         _check(self.lib.vmpc_fr_tail_scalars_inc_dev(self.handle, buf, t, log2_m0, ctypes.c_void_p(z_ptr),
                                                      ctypes.c_void_p(products_ptr), ctypes.c_void_p(out_a_ptr),
                                                      ctypes.c_void_p(out_b_ptr)), "vmpc_fr_tail_scalars_inc_dev")
+
+    def fr_tail_scalars_block(self, newest_challenge, t, log2_m0, z_ptr, j0, count, products_ptr, out_a_ptr,
+                              out_b_ptr):
+        buf = ctypes.create_string_buffer(scalar_to_bytes(newest_challenge) if t else bytes(32), 32)
+        _check(self.lib.vmpc_fr_tail_scalars_block_dev(self.handle, buf, t, log2_m0, ctypes.c_void_p(z_ptr), j0, count,
+                                                       ctypes.c_void_p(products_ptr), ctypes.c_void_p(out_a_ptr),
+                                                       ctypes.c_void_p(out_b_ptr)), "vmpc_fr_tail_scalars_block_dev")
 
     def fr_dot(self, a_ptr, b_ptr, n):
         out = ctypes.create_string_buffer(32)

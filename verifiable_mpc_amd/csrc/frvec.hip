@@ -147,29 +147,32 @@ k_fr_tail_scalars(fr_chal_arg ch, int t, int log2_m0, const uint32_t *__restrict
 // incremental form: `prod` holds s[j] for the first t-1 challenges (all ones for t = 0) and is updated
 // in place with the newest one, so a round costs two products per element instead of up to t + 1
 __global__ void __launch_bounds__(FR_BLOCK)
-k_fr_tail_scalars_inc(fr_arg c_new, int t, int log2_m0, const uint32_t *__restrict__ z,
+k_fr_tail_scalars_inc(fr_arg c_new, int t, int log2_m0, const uint32_t *__restrict__ z, size_t j0, size_t count,
                       uint32_t *__restrict__ prod, uint32_t *__restrict__ out_a, uint32_t *__restrict__ out_b) {
+    // positions j0 .. j0 + count - 1 of the length-2^log2_m0 vectors; prod / out_a / out_b hold that block only
+    // (a rank of the sharded prover owns one block of g_hat: verifiable_mpc_amd/sharded.py)
     const size_t m0 = (size_t)1 << log2_m0;
     const size_t m = m0 >> t, h = m >> 1;
     fr c;
 #pragma unroll
     for (int k = 0; k < 8; k++) c.v[k] = c_new.v[k];
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m0;
-         j += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t j = j0 + i;
         fr s;
         if (t == 0) {
             s = fr_zero();
             s.v[0] = 1;
         } else {
-            s = frv_ld(prod + 8 * j);
+            s = frv_ld(prod + 8 * i);
             if (((j >> (log2_m0 - t)) & 1) == 0) s = fr_mul(s, c);
         }
-        frv_st(prod + 8 * j, s);
+        frv_st(prod + 8 * i, s);
         size_t u = j & (m - 1);
         bool right = u >= h;
         fr acc = fr_mul(frv_ld(z + 8 * (right ? u - h : u + h)), s);
-        frv_st(out_a + 8 * j, right ? acc : fr_zero());
-        frv_st(out_b + 8 * j, right ? fr_zero() : acc);
+        frv_st(out_a + 8 * i, right ? acc : fr_zero());
+        frv_st(out_b + 8 * i, right ? fr_zero() : acc);
     }
 }
 
@@ -289,16 +292,24 @@ extern "C" int vmpc_fr_tail_scalars_dev(vmpc_ctx *ctx, const uint8_t *challenges
 
 extern "C" int vmpc_fr_tail_scalars_inc_dev(vmpc_ctx *ctx, const uint8_t newest_challenge[32], int t, int log2_m0,
                                             const void *z, void *products, void *out_a, void *out_b) {
+    return vmpc_fr_tail_scalars_block_dev(ctx, newest_challenge, t, log2_m0, z, 0, (size_t)1 << (log2_m0 > 40 ? 0 : log2_m0),
+                                          products, out_a, out_b);
+}
+
+extern "C" int vmpc_fr_tail_scalars_block_dev(vmpc_ctx *ctx, const uint8_t newest_challenge[32], int t, int log2_m0,
+                                              const void *z, size_t j0, size_t count, void *products, void *out_a,
+                                              void *out_b) {
     if (!ctx || t < 0 || t > 40 || log2_m0 < 1 || log2_m0 > 40 || t >= log2_m0 || (t && !newest_challenge) ||
-        !z || !products || !out_a || !out_b)
+        !z || !products || !out_a || !out_b || j0 + count > ((size_t)1 << log2_m0))
         return VMPC_E_INVAL;
+    if (count == 0) return VMPC_OK;
     fr_arg a;
     memset(&a, 0, sizeof a);
     if (t) VMPC_CHECK(fr_arg_from(newest_challenge, a));
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     vmpc_stage_scope s(ctx, "fr_tail_scalars");
-    k_fr_tail_scalars_inc<<<fr_grid((size_t)1 << log2_m0), FR_BLOCK, 0, ctx->stream>>>(
-        a, t, log2_m0, (const uint32_t *)z, (uint32_t *)products, (uint32_t *)out_a, (uint32_t *)out_b);
+    k_fr_tail_scalars_inc<<<fr_grid(count), FR_BLOCK, 0, ctx->stream>>>(
+        a, t, log2_m0, (const uint32_t *)z, j0, count, (uint32_t *)products, (uint32_t *)out_a, (uint32_t *)out_b);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }

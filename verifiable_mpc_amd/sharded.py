@@ -1,26 +1,35 @@
 """Compact-transcript Protocol 5 prover with the generators sharded over GPUs.
 
-What shards is the group work.  `g_hat = g || h` (N = 2^k points) is cut into G contiguous blocks,
-one per rank (one process per GPU); every rank keeps the scalar vectors whole - x, r, L are
-32 bytes per entry and their folds are O(N) - and computes, for every commitment of the proof,
-the partial sum over ITS block on its own fixed-base table (include/vmpc.h vmpc_msm_table_dev).
-The only exchange is an all-gather of 128-byte extended points - one for the announcement A,
-one per round carrying A_i and B_i together (compressed_pivot.py:110, :41-42) - after which every rank adds the
-G partial points in rank order with the same device routine, so all ranks hold bit-identical
-A_i, B_i, derive the same challenges, and need no broadcast.  The generators are never folded
-(compressed_pivot._tabulated explains why that is the cheaper form even on one GPU): round i
-commits to the UNFOLDED block with the pending challenge products multiplied into the scalars
-(csrc/frvec.hip k_fr_tail_scalars), so no generator ever crosses a link.
+What shards is the group work AND the O(N)-per-round scalar work that feeds it.  `g_hat = g || h`
+(N = 2^k points) is cut into G blocks, one per rank (one process per GPU).  For every commitment of the
+proof a rank computes the partial sum over ITS block on its own fixed-base table
+(include/vmpc.h vmpc_msm_table_dev), with scalars it derives for its block only
+(vmpc_fr_tail_scalars_block_dev).  The only exchange is an all-gather of 128-byte extended points - one
+for the announcement A, one per round carrying A_i and B_i together (compressed_pivot.py:110, :41-42) -
+after which every rank adds the G partial points in rank order with the same device routine, so all ranks
+hold bit-identical A_i, B_i, derive the same challenges, and need no broadcast.  The generators are never
+folded (compressed_pivot._tabulated explains why that is the cheaper form even on one GPU): round i
+commits to the UNFOLDED block with the pending challenge products multiplied into the scalars, so no
+generator ever crosses a link.
+
+Blocks are CONTIGUOUS ([r N/G, (r+1) N/G)), not the cyclic i mod G that SURVEY.md 8e sketched: cyclic
+sharding keeps a FOLD local (index i pairs with i + half), but this prover does not fold - and contiguous
+blocks are what make the CRS digest (whole 4096-byte chunks per rank) and the per-block scalar kernel
+(one index range) local.  The cyclic layout remains what parallel.ShardedMsm uses for a single commitment.
+
+What stays replicated: the witness-side vectors z_hat and L~ (32 bytes per entry) and their folds
+z' = z_l + c z_r, L' = c L_l + L_r - together 2N elements over the whole proof, against 3N per ROUND for
+the per-generator scalars that are now block-local.
 
 The proof is the same dict, with the same values, as
 compressed_pivot.protocol_5_prover(..., transcript="compact") and verifies with
 compressed_pivot.protocol_5_verifier.
 
-`ShardedCrs` can also hold ALL G blocks in one process (`loopback`): the partial sums are then
-computed one block after the other on the same GPU.  That is how the block arithmetic (offsets,
-which rank adds the k term, rank-ordered combine) is tested on a single-GPU box
-(tests/test_gpu_sharded.py); the multi-process path differs only in where the other ranks'
-partial points come from.
+Everything that touches a device goes through a small `ops` object (`DeviceOps` below), so that the
+host logic - block arithmetic, which rank adds the k term, gather layout, rank-ordered combine, challenge
+derivation - also runs under `gloo` with world_size 2 on CPU, where the test supplies host `ops` built
+on the oracle (tests/test_sharded_gloo.py).  `ShardedCrs` can also hold ALL G blocks in one process
+(`loopback`): that is how the block arithmetic is tested on a single-GPU box (tests/test_gpu_sharded.py).
 """
 import hashlib
 
@@ -32,43 +41,115 @@ from .device import DeviceScalar, PointVector, ScalarVector, get_context, reduce
 from .groups import Ed25519Point
 
 
-class CrsShard:
-    """Block `index` of g_hat on this GPU: points [lo, lo + n) with their fixed-base table
-    (extras: k)."""
+class DeviceOps:
+    """The device side of the sharded prover on this process's GPU (csrc/msm.hip, frvec.hip, sha256.hip)."""
 
-    def __init__(self, index, lo, points, k, rows=None):
-        assert isinstance(points, PointVector)
-        self.index, self.lo, self.n = index, lo, len(points)
-        self.points = points
-        points.precompute([k], rows=rows)
-        self.table = points._table
+    def __init__(self, ctx=None):
+        self.ctx = ctx or get_context()
 
-    def leaf_digests(self):
-        """SHA-256 of every 4096-byte chunk of this block's affine bytes (compact CRS digest)"""
-        return self.points.ctx.sha256_chunks(self.points.affine_ptr, 64 * self.n, cp.CHUNK)
+    # -- CRS blocks ---------------------------------------------------------------------------------
+    def make_block(self, h, exponents, append_h, k, rows):
+        """points = [h ** e for e in exponents] (+ h itself for the last block), tabulated with extra k"""
+        pts = PointVector.fixed_base(h, ScalarVector.from_array(exponents, self.ctx), self.ctx, keep_proj=False)
+        if append_h:
+            pts = pts.concat([h])
+        pts.precompute([k], rows=rows)
+        return pts
 
-    def partial(self, ctx, v, gamma, out_ext_ptr):
-        """out = sum_i v[lo + i] * g_hat[lo + i]  (+ gamma * k when gamma is not None)"""
+    def leaf_digests(self, block):
+        return block.ctx.sha256_chunks(block.affine_ptr, 64 * len(block), cp.CHUNK)
+
+    # -- replicated scalar vectors ----------------------------------------------------------------------
+    def vector(self, v):
+        return pivot._as_device(v)
+
+    def form_digest(self, L):
+        return cp._form_digest(L)
+
+    def axpy(self, c, x, y):
+        return x.axpy(c, y)                # csrc/frvec.hip
+
+    def concat(self, v, tail):
+        return v + list(tail)
+
+    def to_field_list(self, v, gf):
+        return [gf(x) for x in v.to_ints()]
+
+    # -- one rank's block ------------------------------------------------------------------------------------
+    def new_products(self, n_loc):
+        return ScalarVector.empty(n_loc, self.ctx)
+
+    def block_scalars(self, newest_challenge, t, log2_n, z_hat, lo, n_loc, products):
+        """this block's slice of the round's commitment scalars v_a, v_b (length n_loc each)"""
+        v_a, v_b = ScalarVector.empty(n_loc, self.ctx), ScalarVector.empty(n_loc, self.ctx)
+        self.ctx.fr_tail_scalars_block(newest_challenge, t, log2_n, z_hat.ptr, lo, n_loc, products.ptr,
+                                       v_a.ptr, v_b.ptr)
+        return v_a, v_b
+
+    def block_slice(self, v, lo, n_loc):
+        return v[lo:lo + n_loc]
+
+    def partial(self, block, v_block, gamma, out_ptr, stream_index):
+        """out (128-byte extended point at device address out_ptr) = <v_block, block> (+ gamma k)"""
+        from .device import get_aux_context
+        ctx = self.ctx
+        if stream_index:
+            ctx = get_aux_context()
+            ctx.wait_for(self.ctx)
         esc = ctx.upload(np.zeros(32, np.uint8))
         if isinstance(gamma, DeviceScalar):
             ctx.copy(esc.ptr, gamma.ptr, 32)
         elif gamma is not None:
             ctx.upload_into(esc.ptr, np.frombuffer(reduce_scalar(gamma).to_bytes(32, "little"), np.uint8))
-        ctx.msm_table(self.table.ptr, self.n, 1, v.ptr + 32 * self.lo, self.n, esc.ptr, out_ext_ptr, None,
-                      rows=self.table.rows)
-        return esc          # keep alive until the stream is done with it
+        t = block._table
+        ctx.msm_table(t.ptr, len(block), 1, v_block.ptr, len(block), esc.ptr, out_ptr, None, rows=t.rows)
+        return ctx, (esc, v_block)          # stream to wait for, buffers to keep alive until then
+
+    # -- exchange buffers and the ordered combine ----------------------------------------------------------------
+    def buffers(self, W, K, torch):
+        """(mine, gathered, address of mine, address of gathered): K points from each of W ranks"""
+        if torch is None:                   # loopback: the blocks' partial points land directly in `gathered`
+            g = self.ctx.alloc(128 * W * K)
+            return None, g, None, g.ptr
+        # torch.empty: no fill kernel on torch's stream that the vmpc streams (non-blocking, unordered
+        # with it) could race with; every byte is written by the partial sums / the all-gather
+        mine = torch.empty(128 * K, dtype=torch.uint8, device="cuda")
+        gathered = torch.empty(128 * K * W, dtype=torch.uint8, device="cuda")
+        return mine, gathered, mine.data_ptr(), gathered.data_ptr()
+
+    def wait_collective(self, torch):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ev.synchronize()
+
+    def combine(self, gathered_ptr, W, K):
+        """K sums of W points each, added in rank order: the same bits on every rank"""
+        res = self.ctx.alloc(128 * K)
+        self.ctx.points_sum_many(gathered_ptr, W, K, res.ptr, None)
+        self.ctx.sync()
+        raw = self.ctx.download(res.ptr, 128 * K).tobytes()
+        return [Ed25519Point.from_proj_bytes(raw[128 * j:128 * j + 96]).normalize() for j in range(K)]
+
+
+class CrsShard:
+    """Block `index` of g_hat: points [lo, lo + n) (tabulated with extra k when on a device)."""
+
+    def __init__(self, index, lo, points):
+        self.index, self.lo, self.n = index, lo, len(points)
+        self.points = points
 
 
 class ShardedCrs:
     """g_hat = g || h in `world` blocks.  `shards` holds this process's blocks: one in the
     multi-process setting (`dist` given), all of them in loopback."""
 
-    def __init__(self, N, world, shards, h, k, dist=None, torch=None, ctx=None):
+    def __init__(self, N, world, shards, h, k, dist=None, torch=None, ctx=None, ops=None):
         assert N & (N - 1) == 0 and N % world == 0 and N // world >= 64, "block = whole digest chunks"
         self.N, self.world, self.shards = N, world, sorted(shards, key=lambda s: s.index)
         self.h, self.k = h, k
         self.dist, self.torch = dist, torch
-        self.ctx = ctx or get_context()
+        self.ops = ops or DeviceOps(ctx)
+        self.ctx = getattr(self.ops, "ctx", None)
         self.loopback = dist is None
         if self.loopback:
             assert [s.index for s in self.shards] == list(range(world)), "loopback holds every block"
@@ -80,25 +161,22 @@ class ShardedCrs:
 
     # -- construction from the exponents (tests / bench: g_i = r_i * h as create_generators does) ----
     @classmethod
-    def from_exponents(cls, h, k, exponents, world, ranks, dist=None, torch=None, ctx=None, rows=None):
+    def from_exponents(cls, h, k, exponents, world, ranks, dist=None, torch=None, ctx=None, rows=None, ops=None):
         """exponents: (N - 1, 32) uint8 array (the same on every rank); `ranks`: the blocks to build"""
-        ctx = ctx or get_context()
+        ops = ops or DeviceOps(ctx)
         N = len(exponents) + 1
         n_loc = N // world
         shards = []
         for r in ranks:
             lo, hi = r * n_loc, (r + 1) * n_loc
-            sl = exponents[lo:min(hi, N - 1)]
-            pts = PointVector.fixed_base(h, ScalarVector.from_array(sl, ctx), ctx, keep_proj=False)
-            if hi == N:                               # the last block ends with h itself
-                pts = pts.concat([h])
-            shards.append(CrsShard(r, lo, pts, k, rows))
-        return cls(N, world, shards, h, k, dist, torch, ctx)
+            # the last block ends with h itself (g_hat = g || h, compressed_pivot.py:138)
+            shards.append(CrsShard(r, lo, ops.make_block(h, exponents[lo:min(hi, N - 1)], hi == N, k, rows)))
+        return cls(N, world, shards, h, k, dist, torch, ctx, ops)
 
     # -- compact CRS digest, identical to compressed_pivot.generators_digest(g, h, k) ---------------------
     def digest(self):
         if self._digest is None:
-            local = {s.index: s.leaf_digests() for s in self.shards}
+            local = {s.index: self.ops.leaf_digests(s.points) for s in self.shards}
             if self.loopback:
                 blocks = [local[i] for i in range(self.world)]
             else:
@@ -111,90 +189,85 @@ class ShardedCrs:
         return self._digest
 
     # -- commitments ------------------------------------------------------------------------------------
-    def commit(self, items):
-        """items: [(v, gamma)] with v a ScalarVector of length N over g_hat and gamma the exponent of k
-        (None = no k term).  Returns the commitments, identical on every rank.  One exchange for all of
-        them: every rank contributes len(items) partial points (128 bytes each)."""
-        from .device import get_aux_context
-        ctx, W, K = self.ctx, self.world, len(items)
-        # partial points, laid out [rank][item] as the all-gather will produce them
-        if self.loopback:
-            gathered, gptr, mine = ctx.alloc(128 * W * K), None, None
-            gptr = gathered.ptr
-        else:
-            # torch.empty: no fill kernel on torch's stream that the vmpc streams (non-blocking, unordered
-            # with it) could race with; every byte is written by the partial sums / the all-gather
-            mine = self.torch.empty(128 * K, dtype=self.torch.uint8, device="cuda")
-            gathered = self.torch.empty(128 * K * W, dtype=self.torch.uint8, device="cuda")
-            gptr = gathered.data_ptr()
-        keep, used = [], [ctx]
-        for j, (v, gamma) in enumerate(items):
-            assert len(v) == self.N
-            cctx = ctx
-            if j % 2 == 1:                # A_i and B_i of a round run side by side on two streams
-                cctx = get_aux_context()
-                cctx.wait_for(ctx)
-                used.append(cctx)
-            for s in self.shards:
-                dst = (gptr + 128 * (s.index * K + j)) if self.loopback else (mine.data_ptr() + 128 * j)
-                keep.append(s.partial(cctx, v, gamma if s.index == 0 else None, dst))
-        for c in used:
-            c.sync()                                              # partial points are complete
+    def commit_blocks(self, items):
+        """items: [(per_shard, gamma)]: per_shard maps a shard index to that block's scalar vector (length
+        N / world), gamma is the exponent of k (None = no k term; added by block 0's owner only).  Returns
+        the commitments, identical on every rank.  One exchange for all of them: every rank contributes
+        len(items) partial points of 128 bytes."""
+        ops, W, K = self.ops, self.world, len(items)
+        mine, gathered, mine_ptr, gathered_ptr = ops.buffers(W, K, None if self.loopback else self.torch)
+        pending = []
+        try:
+            for j, (per_shard, gamma) in enumerate(items):
+                for s in self.shards:
+                    dst = (gathered_ptr + 128 * (s.index * K + j)) if self.loopback else (mine_ptr + 128 * j)
+                    # A_i and B_i of a round run side by side on two streams
+                    pending.append(ops.partial(s.points, per_shard[s.index], gamma if s.index == 0 else None,
+                                               dst, j % 2))
+        finally:
+            for stream, _ in pending:       # partial points complete (also before buffers are dropped on error)
+                if stream is not None:
+                    stream.sync()
         if not self.loopback:
             self.dist.all_gather_into_tensor(gathered, mine)      # the exchange: W x K x 128 bytes
-            ev = self.torch.cuda.Event()
-            ev.record(self.torch.cuda.current_stream())
-            ev.synchronize()
-        res = ctx.alloc(128 * K)
-        ctx.points_sum_many(gptr, W, K, res.ptr, None)            # rank order: same bits everywhere
-        ctx.sync()
-        raw = ctx.download(res.ptr, 128 * K).tobytes()
-        del keep
-        return [Ed25519Point.from_proj_bytes(raw[128 * j:128 * j + 96]).normalize() for j in range(K)]
+            ops.wait_collective(self.torch)
+        out = ops.combine(gathered_ptr, W, K)
+        del pending
+        return out
+
+    def commit(self, items):
+        """items: [(v, gamma)] with v a full-length (N) scalar vector over g_hat"""
+        n_loc = self.N // self.world
+        for v, _ in items:
+            assert len(v) == self.N
+        return self.commit_blocks([({s.index: self.ops.block_slice(v, s.lo, n_loc) for s in self.shards}, gamma)
+                                   for v, gamma in items])
 
 
 def protocol_5_prover(crs, P, L, y, x, gamma, gf, r, rho):
     """compressed_pivot.protocol_5_prover (compressed_pivot.py:89-145) with transcript="compact",
     the group work sharded over `crs`.  x, r: the witness and its masks (length N - 1), rho: int."""
     order = gf.order
+    ops = crs.ops
     n = len(x)
     assert n + 1 == crs.N, "This implementation requires n+1 to be power of 2 (else, use padding with zeros)."
-    ctx = crs.ctx
     L, y = pivot.affine_to_linear(L, y, n)
-    x, r = pivot._as_device(x), pivot._as_device(r)
-    L = pivot.AffineForm(cp._coeffs_dev(L), L.constant)
+    x, r = ops.vector(x), ops.vector(r)
+    L = pivot.AffineForm(ops.vector(L.coeffs), L.constant)
     proof = {}
     t = L(r)
     if isinstance(t, int):
         t = gf(t)
-    A = crs.commit([(r.concat([rho]), None)])[0]                 # sum r_i g_i + rho h
+    A = crs.commit([(ops.concat(r, [rho]), None)])[0]            # sum r_i g_i + rho h
     proof["t"], proof["A"] = t, A
     P = cp._pt(P)
-    seed = hashlib.sha256(b"vmpc-ac20/p5/v1" + crs.digest() + cp._form_digest(L) + P.to_affine_bytes()
+    seed = hashlib.sha256(b"vmpc-ac20/p5/v1" + crs.digest() + ops.form_digest(L) + P.to_affine_bytes()
                           + cp._sc_bytes(pivot._residue(y)) + cp._sc_bytes(pivot._residue(t))
                           + A.to_affine_bytes()).digest()
     c0 = cp._challenge(hashlib.sha256(seed + b"\x00").digest(), order)
     c1 = cp._challenge(hashlib.sha256(seed + b"\x01").digest(), order)
-    z_hat = x.axpy(c0, r).concat([gf(c0 * gamma + rho)])
+    z_hat = ops.concat(ops.axpy(c0, x, r), [gf(c0 * gamma + rho)])
     L_tilde = cp._extend_form(L, c1)
     transcript = cp._p5_setup(None, crs.k, seed, "compact", order)
 
     log2_n = crs.N.bit_length() - 1
+    n_loc = crs.N // crs.world
     challenges, round_i = [], 0
-    products = ScalarVector.empty(crs.N, ctx)                   # challenge products per generator
+    products = {s.index: ops.new_products(n_loc) for s in crs.shards}     # challenge products per generator
     while True:
         half = len(z_hat) // 2
         z_l, z_r, gamma_a, gamma_b = cp._round_prover_scalars(L_tilde, z_hat, half, gf)
-        v_a, v_b = ScalarVector.empty(crs.N, ctx), ScalarVector.empty(crs.N, ctx)
-        ctx.fr_tail_scalars_inc(challenges[-1] if challenges else 0, len(challenges), log2_n, z_hat.ptr,
-                                products.ptr, v_a.ptr, v_b.ptr)
-        A_i, B_i = crs.commit([(v_a, gamma_a), (v_b, gamma_b)])
+        v_a, v_b = {}, {}
+        for s in crs.shards:                 # scalar work proportional to the block, not to N
+            v_a[s.index], v_b[s.index] = ops.block_scalars(challenges[-1] if challenges else 0, len(challenges),
+                                                           log2_n, z_hat, s.lo, n_loc, products[s.index])
+        A_i, B_i = crs.commit_blocks([(v_a, gamma_a), (v_b, gamma_b)])
         proof["A" + str(round_i)], proof["B" + str(round_i)] = A_i, B_i
         c = transcript.round_challenge(round_i, A_i, B_i, None, crs.k, None, None)
         challenges.append(c)
         L_tilde = cp._fold_form(L_tilde, c, half, gf)
         z_hat = cp._fold_witness(z_l, z_r, c, half)
         if len(z_hat) <= 2:
-            proof["z_prime"] = [gf(v) for v in z_hat.to_ints()]
+            proof["z_prime"] = ops.to_field_list(z_hat, gf)
             return proof
         round_i += 1
