@@ -73,6 +73,34 @@ def cpu_baseline(log2_sample, seed):
                       f"{dt:.1f} s on 1 core"}
 
 
+def strong_cpu_baseline(log2n, seed):
+    """oracle/cpu_pippenger.c: the same commitment by Pippenger (signed windows, 51-bit limbs, 7M mixed additions)
+    on every host core - the algorithm class the GPU path uses, so that the GPU/CPU ratio has an honest
+    denominator next to the reference algorithm's."""
+    from oracle import c_oracle
+    n = 1 << log2n
+    rng = np.random.default_rng(seed)
+    base = np.frombuffer(
+        (15112221349535400772501151409588531511454012693041857206046113283949847762202).to_bytes(32, "little")
+        + (46316835694926478169428394003475163141307993866256225615783033603165251855960).to_bytes(32, "little")
+        + (1).to_bytes(32, "little"), np.uint8)
+    _, pts_small = c_oracle.fixed_base(base, rand_scalars(rng, 256))
+    pts = np.tile(pts_small, (n // 256, 1))
+    sc = rand_scalars(rng, n)
+    cores = os.cpu_count() or 1
+    out = {"algorithm": "Pippenger, signed windows, one slice per thread (oracle/cpu_pippenger.c)", "n": f"2^{log2n}"}
+    for label, threads in (("all_cores", cores), ("one_core", 1)):
+        m = n if threads > 1 else n >> 3
+        c_oracle.pippenger_msm(sc[:4096], pts[:4096], threads)              # warm the thread pool / caches
+        t0 = time.perf_counter()
+        c_oracle.pippenger_msm(sc[:m], pts[:m], threads)
+        dt = time.perf_counter() - t0
+        out[label] = {"threads": threads, "terms": m, "seconds": round(dt, 4), "scalar_mults_per_s": round(m / dt, 1)}
+    out["value"] = out["all_cores"]["scalar_mults_per_s"]
+    out["cores"] = cores
+    return out
+
+
 def python_reference_baseline(seed, budget_s=12.0):
     """The pure-Python statement of the REFERENCE algorithm (oracle/ac20_ref.vector_commitment: per-term
     right-to-left double-and-add on Python big ints + the reduce tree; the stand-in for the MPyC-based
@@ -445,6 +473,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_log2n, 5)
+            try:
+                line["cpu_baseline"]["strong_cpu"] = strong_cpu_baseline(args.log2n, 8)
+            except Exception as e:
+                line["cpu_baseline"]["strong_cpu"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 line["cpu_baseline"]["python_reference"] = python_reference_baseline(6)
             except Exception as e:

@@ -72,3 +72,31 @@ def fixed_base(base_proj, exps):
     op, oa = np.zeros((n, 96), np.uint8), np.zeros((n, 64), np.uint8)
     assert lib().oracle_fixed_base(_p(base_proj), _p(exps), n, _p(op), _p(oa)) == 0
     return op, oa
+
+
+# ---- "strong CPU" baseline: Pippenger on all cores (oracle/cpu_pippenger.c) ---------------------------------
+PIP_SRC = os.path.join(HERE, "cpu_pippenger.c")
+PIP_LIB = os.path.join(OUT_DIR, "libcpu_pippenger.so")
+_pip = None
+
+
+def build_pippenger(force=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    if force or not os.path.exists(PIP_LIB) or os.path.getmtime(PIP_LIB) < os.path.getmtime(PIP_SRC):
+        subprocess.check_call(["gcc", "-O3", "-shared", "-fPIC", "-pthread", "-o", PIP_LIB, PIP_SRC])
+    return PIP_LIB
+
+
+def pippenger_msm(scalars, points, threads=1, window=0):
+    """(n,32) u8 scalars < 2^253, (n,64) u8 affine points -> 64-byte affine sum (all `threads` cores)."""
+    global _pip
+    if _pip is None:
+        build_pippenger()
+        _pip = ctypes.CDLL(PIP_LIB)
+        _pip.cpu_pippenger_msm.restype = ctypes.c_int
+        _pip.cpu_pippenger_msm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_void_p]
+    scalars, points = _u8(scalars), _u8(points)
+    out = np.zeros(64, np.uint8)
+    assert _pip.cpu_pippenger_msm(_p(scalars), _p(points), len(scalars), int(threads), int(window), _p(out)) == 0
+    return out
