@@ -229,6 +229,12 @@ int vmpc_bn256_g1_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points
 int vmpc_bn256_g2_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, size_t n,
                           void *out_affine);
 /* group = 1 (G1) or 2 (G2): canonical encodings and curve equation; *n_bad = offenders (sync) */
+/* out_i = scalars[i] * base for one base point (group 1: 64-byte points, group 2: 128-byte): the key generation
+ * of the Pinocchio prover is n such products of the two generators (pynocchio.py:101-200).  Scalars: 32-byte
+ * little-endian integers below 2^256 (not reduced); affine outputs, all-zero bytes = infinity. */
+int vmpc_bn256_fixed_base_dev(vmpc_ctx *ctx, int group, const void *base_affine, const void *scalars, size_t n,
+                              void *out_affine);
+
 int vmpc_bn256_validate_dev(vmpc_ctx *ctx, int group, const void *points, size_t n, uint64_t *n_bad);
 /* Fixed-base tables over an evaluation-key vector (fixed per circuit; pynocchio.py:228-246 reads the
  * same evalkey entries for every proof): 17 rows 2^(16 w) * P_i.  vmpc_bn256_table_msm_dev computes

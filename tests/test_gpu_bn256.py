@@ -183,3 +183,47 @@ def test_compute_proof_matches_reference_fixture(vm):
     key = pn.PreparedKey(Q, evalkey)
     assert pn.compute_proof(Q, [h2i(v) for v in case["c"]], H(), key, D) == proof
     assert pn.compute_proof(Q, [h2i(v) for v in case["c"]], H(), key, None) == plain
+
+
+@pytest.mark.parametrize("gi", [0, 1])
+def test_fixed_base_batch_matches_oracle(vm, gi):
+    """vmpc_bn256_fixed_base_dev (the key generation's `int * generator`, pynocchio.py:101-200) against the
+    oracle's affine double-and-add; scalars need not be reduced mod n."""
+    from verifiable_mpc_amd import _native
+    grp, E, G, to_b, from_b, width = groups()[gi]
+    ctx = vm.get_context()
+    rng = random.Random(40 + grp)
+    sc = [0, 1, 2, bn.N - 1, bn.N, bn.N + 5, 2**256 - 1] + [rng.randrange(2**256) for _ in range(25)]
+    dg = ctx.upload(np.frombuffer(to_b(G), np.uint8))
+    ds = ctx.upload(_native.ints_to_array(sc, 32))
+    out = ctx.alloc(width * len(sc))
+    ctx.bn256_fixed_base(grp, dg.ptr, ds.ptr, len(sc), out.ptr)
+    raw = ctx.download(out.ptr, width * len(sc)).tobytes()
+    for i, s in enumerate(sc):
+        assert from_b(raw[width * i:width * (i + 1)]) == E.mul(s % bn.N, G), i
+
+
+@pytest.mark.parametrize("gi", [0, 1])
+def test_full_size_exponent_identity(vm, gi):
+    """BASELINE config 5 at its full size, 2^18 terms over DISTINCT points e_i * G made on the device:
+    sum s_i (e_i G) == (sum s_i e_i mod n) G for the variable-base MSM and for the prepared (tabulated) key."""
+    grp, E, G, to_b, from_b, width = groups()[gi]
+    ctx = vm.get_context()
+    n = 1 << 18
+    rng = np.random.default_rng(900 + grp)
+    ex = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    ex[:, 31] &= 0x7F
+    sc[:, 31] &= 0x7F
+    dg, de, ds = ctx.upload(np.frombuffer(to_b(G), np.uint8)), ctx.upload(ex), ctx.upload(sc)
+    dp, res, res2 = ctx.alloc(width * n), ctx.alloc(width), ctx.alloc(width)
+    ctx.bn256_fixed_base(grp, dg.ptr, de.ptr, n, dp.ptr)
+    assert ctx.bn256_validate(grp, dp.ptr, n) == 0
+    ctx.bn256_msm(grp, ds.ptr, dp.ptr, n, res.ptr)
+    table = ctx.bn256_table_build(grp, dp.ptr, n)
+    ctx.bn256_table_msm(grp, table.ptr, n, ds.ptr, n, res2.ptr, None)
+    ctx.sync()
+    tot = sum(int.from_bytes(bytes(a), "little") * int.from_bytes(bytes(b), "little") for a, b in zip(sc, ex)) % bn.N
+    want = E.mul(tot, G)
+    assert from_b(ctx.download(res.ptr, width).tobytes()) == want
+    assert from_b(ctx.download(res2.ptr, width).tobytes()) == want

@@ -35,7 +35,7 @@ SYMBOLS = [
     "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev", "vmpc_fr_tail_scalars_block_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
-    "vmpc_bn256_validate_dev", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
+    "vmpc_bn256_validate_dev", "vmpc_bn256_fixed_base_dev", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
 ]
 
 
@@ -116,6 +116,7 @@ def load_library():
         "vmpc_bn256_g1_msm_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_bn256_g2_msm_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_bn256_validate_dev": (i32, [vp, i32, vp, sz, u64p]),
+        "vmpc_bn256_fixed_base_dev": (i32, [vp, i32, vp, vp, sz, vp]),
         "vmpc_bn256_table_bytes": (i32, [i32, sz, vp]),
         "vmpc_bn256_table_build_dev": (i32, [vp, i32, vp, sz, vp]),
         "vmpc_bn256_table_msm_dev": (i32, [vp, i32, vp, sz, vp, sz, vp, vp]),
@@ -569,6 +570,11 @@ class Context:
                                                  ctypes.c_void_p(scalars_ptr), m, ctypes.c_void_p(out_ptr),
                                                  ctypes.c_void_p(out_jac_ptr)),
                "vmpc_bn256_table_msm_dev")
+
+    def bn256_fixed_base(self, group, base_ptr, scalars_ptr, n, out_ptr):
+        _check(self.lib.vmpc_bn256_fixed_base_dev(self.handle, group, ctypes.c_void_p(base_ptr),
+                                                  ctypes.c_void_p(scalars_ptr), n, ctypes.c_void_p(out_ptr)),
+               "vmpc_bn256_fixed_base_dev")
 
     def bn256_validate(self, group, points_ptr, n):
         bad = ctypes.c_uint64()

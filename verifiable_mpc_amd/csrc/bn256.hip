@@ -449,6 +449,45 @@ extern "C" int vmpc_bn256_validate_dev(vmpc_ctx *ctx, int group, const void *poi
     return VMPC_OK;
 }
 
+// ---- fixed-base batch: out_i = n_i * B ------------------------------------------------------------------
+// The evaluation / verification keys of the Pinocchio prover are n fixed-base scalar multiplications of the
+// two group generators (verifiable_mpc/trinocchio/pynocchio.py:101-200 `generate_evalkey`: one `int * point`
+// per key element).  One lane per element, left-to-right double-and-add over the 256 scalar bits; the
+// branches of the incomplete Weierstrass law are inside jac_madd.  Affine output (one inversion per lane).
+template <class C, class F>
+__global__ void __launch_bounds__(MSM_BLOCK)
+gk_fixed_base(const uint32_t *__restrict__ base, const uint32_t *__restrict__ sc, size_t n,
+              uint32_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const aff<F> b = aff_load<F>(base);
+    uint32_t s[8];
+    for (int k = 0; k < 8; k++) s[k] = sc[8 * i + k];
+    jac<F> acc = jac_identity<F>();
+    for (int bit = 255; bit >= 0; bit--) {
+        acc = jac_dbl<F>(acc);
+        if ((s[bit >> 5] >> (bit & 31)) & 1u) acc = jac_madd<F>(acc, b);
+    }
+    aff_store<F>(out + (size_t)C::AFF_WORDS * i, jac_to_affine<F>(acc));
+}
+
+extern "C" int vmpc_bn256_fixed_base_dev(vmpc_ctx *ctx, int group, const void *base_affine, const void *scalars,
+                                         size_t n, void *out_affine) {
+    if (!ctx || (group != 1 && group != 2) || !base_affine || (n && (!scalars || !out_affine))) return VMPC_E_INVAL;
+    if (n == 0) return VMPC_OK;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    const unsigned g = (unsigned)((n + MSM_BLOCK - 1) / MSM_BLOCK);
+    vmpc_stage_scope s(ctx, "bn_fixed_base");
+    if (group == 1)
+        gk_fixed_base<G1, Fp1Ops><<<g, MSM_BLOCK, 0, ctx->stream>>>((const uint32_t *)base_affine,
+                                                                     (const uint32_t *)scalars, n, (uint32_t *)out_affine);
+    else
+        gk_fixed_base<G2, Fp2Ops><<<g, MSM_BLOCK, 0, ctx->stream>>>((const uint32_t *)base_affine,
+                                                                     (const uint32_t *)scalars, n, (uint32_t *)out_affine);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
 // ---- host-buffer one-shots -------------------------------------------------------------------------
 static int bn_msm_host(int group, const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t *out) {
     const size_t pb = group == 1 ? 64 : 128;
