@@ -175,6 +175,20 @@ def prove_timing(vm, ctx, n_pow, rng):
         ok = vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, proof, gf, transcript=mode)
         out[f"verify_ms_{mode}"] = (time.perf_counter() - t0) * 1e3
         assert ok is True
+        # a Protocol-5 prove moves ~768 * N algorithmic bytes (two N-term commitments + per round
+        # two half-size commitments, the fold and the scalar folds); Fiat-Shamir text excluded
+        alg = 768 * N
+        ms = out[f"prove_ms_{mode}"]
+        out[f"roofline_{mode}"] = {
+            "bound": "hbm", "algorithmic_bytes": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9,
+            "peak_GBps": HBM_PEAK_GBPS, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "dominant": ("k_msm_bucket: 2 N-term table commitments per round (profiles/*_prove_compact_kernel_stats.csv)"
+                         if mode == "compact" else
+                         "host SHA-256 of ~1 GB of decimal pre-image text on one core (~85 % of the wall time); on "
+                         "the GPU k_fold, the exact replay of (g_l ** c) * g_r "
+                         "(profiles/*_prove_reference_kernel_stats.csv)"),
+            "transcript": ("build-defined compact byte transcript: NOT the reference's challenges" if mode == "compact"
+                           else "the reference's str(input_list) transcript: proofs bit-identical to the CPU reference")}
     return out
 
 
@@ -509,7 +523,7 @@ def main():
                 line["cpu_baseline"]["python_reference"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_prove and not args.force_collective:
             try:
-                line["ac20_n2^20"] = {k: round(v, 2) for k, v in
+                line["ac20_n2^20"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in
                                       prove_timing(vm, ctx, 20, np.random.default_rng(99)).items()}
             except Exception as e:  # the headline metric must still be reported
                 line["ac20_n2^20"] = {"error": f"{type(e).__name__}: {e}"}

@@ -1,8 +1,10 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): the default bench line, the rocprofv3 kernel-trace of the
-# same command, and the two PMC passes the HBM-traffic figure needs (separate passes, --pmc only).
-#   gpurun --timeout 1500 -- 'bash scripts/profile_round.sh r01d'
-# then, back in the build container:  python scripts/summarize_profiles.py r01d
+# Runs ON THE GPU BOX (through gpurun): the default bench line, rocprofv3 kernel-trace summaries of the same
+# command, of the commitment alone (--no-pipeline: the duration the roofline figure uses) and of the
+# Protocol-5 prove in both transcripts, and the two PMC passes the HBM-traffic figure needs (separate passes,
+# --pmc only, as MI355X_MICROARCH.md prescribes).
+#   gpurun --timeout 2400 -- 'bash scripts/profile_round.sh r02'
+# then, back in the build container:  python scripts/summarize_profiles.py r02
 set -u
 TAG=${1:-rXX}
 REPO=$(pwd)
@@ -10,15 +12,21 @@ OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py > "$OUT/bench_$TAG.json" 2> "$OUT/bench_$TAG.err"
-tail -c 400 "$OUT/bench_$TAG.json"
+tail -c 300 "$OUT/bench_$TAG.json"
 cd /tmp
-rm -rf "$OUT/prof_$TAG" "$OUT/pmc_fetch_$TAG" "$OUT/pmc_write_$TAG"
+rm -rf "$OUT"/prof_${TAG}* "$OUT"/pmc_fetch_$TAG "$OUT"/pmc_write_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -- \
     python3 "$REPO/bench.py" --no-cpu-baseline --no-prove > "$OUT/prof_$TAG.bench.json" 2> "$OUT/prof_$TAG.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_alone" -- \
+    python3 "$REPO/bench.py" --no-cpu-baseline --no-prove --no-pipeline > "$OUT/prof_${TAG}_alone.bench.json" 2> "$OUT/prof_${TAG}_alone.err"
+for MODE in compact reference; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_prove_$MODE" -- \
+      python3 "$REPO/scripts/prove_run.py" $MODE 20 3 > "$OUT/prof_${TAG}_prove_$MODE.json" 2> "$OUT/prof_${TAG}_prove_$MODE.err"
+done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$TAG" -- \
     python3 "$REPO/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-prove > /dev/null 2> "$OUT/pmc_fetch_$TAG.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$TAG" -- \
     python3 "$REPO/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-prove > /dev/null 2> "$OUT/pmc_write_$TAG.err"
 # keep what travels back small: stats + counter csv only
-find "$OUT/prof_$TAG" -name '*kernel_trace.csv' -delete
-ls -R "$OUT/prof_$TAG" "$OUT/pmc_fetch_$TAG" "$OUT/pmc_write_$TAG" | head -40
+find "$OUT" -name '*kernel_trace.csv' -delete
+ls "$OUT" | grep "$TAG" | head -40

@@ -34,10 +34,20 @@ def main():
     out = os.path.join(ROOT, "gpurun_out")
     prof = os.path.join(ROOT, "profiles")
     shutil.copy(os.path.join(out, f"bench_{tag}.json"), os.path.join(prof, f"{tag}_bench.json"))
-    stats = sorted(glob.glob(os.path.join(out, f"prof_{tag}", "**", "*kernel_stats.csv"), recursive=True),
-                   key=os.path.getmtime)
-    if stats:
-        shutil.copy(stats[-1], os.path.join(prof, f"{tag}_msm_n2^20_kernel_stats.csv"))
+    for sub, name in ((f"prof_{tag}", "msm_n2^20_kernel_stats.csv"),
+                      (f"prof_{tag}_alone", "msm_n2^20_alone_kernel_stats.csv"),
+                      (f"prof_{tag}_prove_compact", "prove_compact_kernel_stats.csv"),
+                      (f"prof_{tag}_prove_reference", "prove_reference_kernel_stats.csv")):
+        stats = sorted(glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True),
+                       key=os.path.getmtime)
+        if stats:
+            shutil.copy(stats[-1], os.path.join(prof, f"{tag}_{name}"))
+    for sub, name in ((f"prof_{tag}.bench.json", "bench_under_rocprof.json"),
+                      (f"prof_{tag}_alone.bench.json", "bench_alone_under_rocprof.json"),
+                      (f"prof_{tag}_prove_compact.json", "prove_compact_under_rocprof.json"),
+                      (f"prof_{tag}_prove_reference.json", "prove_reference_under_rocprof.json")):
+        if os.path.exists(os.path.join(out, sub)):
+            shutil.copy(os.path.join(out, sub), os.path.join(prof, f"{tag}_{name}"))
     fetch = counter_avgs(os.path.join(out, f"pmc_fetch_{tag}"), "FETCH_SIZE")
     write = counter_avgs(os.path.join(out, f"pmc_write_{tag}"), "WRITE_SIZE")
     kernels = {}
