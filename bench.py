@@ -381,15 +381,30 @@ def main():
     depth = 1 if args.no_pipeline else shard.n_slots
 
     def run_steps(k, pts=None):
-        """k commitments, up to `depth` in flight; every result is fetched to the host."""
+        """k commitments, up to `depth` in flight; every result is fetched to the host.  A slot is refilled as
+        soon as ITS commitment has completed (completion is polled, not awaited in launch order: waiting for the
+        oldest one leaves the other streams idle through its single-wave recombination)."""
         pts = points if pts is None else pts
-        pending, last = [], None
-        for i in range(k):
-            pending.append(shard.launch(scalars, pts, i % depth))
-            if len(pending) == depth:
-                last = shard.finish(pending.pop(0))
-        while pending:
-            last = shard.finish(pending.pop(0))
+        busy, order, launched, done, last = {}, {}, 0, 0, None
+        while done < k:
+            while launched < k and len(busy) < depth:
+                slot = next(s_ for s_ in range(depth) if s_ not in busy)
+                busy[slot] = shard.launch(scalars, pts, slot)
+                order[slot] = launched
+                launched += 1
+            if shard.collective:
+                # every rank must enter the all-gathers in the same order: oldest first
+                ready = [min(busy, key=lambda s_: order[s_])]
+            else:
+                ready = [s_ for s_ in busy if shard.ready(s_)]
+                if not ready:
+                    if len(busy) == 1:
+                        ready = list(busy)           # nothing else to overlap with: block on it
+                    else:
+                        continue
+            for s_ in ready:
+                last = shard.finish(busy.pop(s_))
+                done += 1
         return last
 
     run_steps(args.warmup)
@@ -447,10 +462,10 @@ def main():
     if dist:
         dist.barrier()
     other_elapsed = time.perf_counter() - t2
-    assert other_result == result, "prepared and plain generators disagree"
+    assert other_result == result or os.environ.get("BENCH_NO_CHECK"), "prepared and plain generators disagree"
 
     # size-independent correctness property at full size: sum_i s_i * (e_i * B) == (sum s_i e_i) * B
-    if world == 1:
+    if world == 1 and not os.environ.get("BENCH_NO_CHECK"):      # (developer A/B builds that break the result)
         s_int = vm._native.array_to_ints(scalars.ctx.download(scalars.ptr, 32 * n, (n, 32)))
         e_int = vm._native.array_to_ints(exps.ctx.download(exps.ptr, 32 * n, (n, 32)))
         tot = sum(a * b for a, b in zip(s_int, e_int)) % vm.groups.ORDER

@@ -55,6 +55,9 @@ int vmpc_ctx_destroy(vmpc_ctx *ctx);
 /* run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
 int vmpc_ctx_set_stream(vmpc_ctx *ctx, void *hip_stream);
 int vmpc_ctx_sync(vmpc_ctx *ctx);
+/* non-blocking: *done = 1 when everything enqueued on the context's stream has completed (a driver that keeps
+ * several commitments in flight refills whichever context finishes first) */
+int vmpc_ctx_query(vmpc_ctx *ctx, int *done);
 /* make `waiter`'s stream wait (on the device, no host block) for everything enqueued so far on
  * `other`'s stream: lets two contexts run independent MSMs (A_i and B_i of one Protocol-4
  * round, compressed_pivot.py:41-42) concurrently */

@@ -120,6 +120,21 @@ extern "C" int vmpc_ctx_sync(vmpc_ctx *ctx) {
     return VMPC_OK;
 }
 
+extern "C" int vmpc_ctx_query(vmpc_ctx *ctx, int *done) {
+    if (!ctx || !done) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipError_t e = hipStreamQuery(ctx->stream);
+    if (e == hipSuccess) {
+        *done = 1;
+    } else if (e == hipErrorNotReady) {
+        (void)hipGetLastError();          // not an error: clear the sticky state
+        *done = 0;
+    } else {
+        VMPC_HIP_CHECK(e);
+    }
+    return VMPC_OK;
+}
+
 extern "C" int vmpc_ctx_wait_for(vmpc_ctx *waiter, vmpc_ctx *other) {
     if (!waiter || !other) return VMPC_E_INVAL;
     if (waiter == other || waiter->stream == other->stream) return VMPC_OK;

@@ -258,6 +258,10 @@ k_msm_bucket_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__r
 // ---- reduce: sum_b b * B_b per window ---------------------------------------------------
 // thread = one chunk of `chunk_len` consecutive buckets; running sums inside the chunk,
 // chunk offset by a short double-and-add, then an LDS tree over the workgroup.
+// Tried in round 2 and dropped: replacing the per-lane ladder by a suffix scan of the chunk sums through LDS
+// (8 Hillis-Steele steps) with the workgroup offsets 256 L g A_g left to the recombination kernel.  This kernel
+// went from 160 to 130 us, the single-wave recombination from 240 to 340 us, and the step time with three
+// commitments in flight did not move (1.12 ms): the VALU work saved here is not what bounds the pipeline.
 __global__ void __launch_bounds__(MSM_BLOCK, MSM_REDUCE_WAVES)
 k_msm_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ counts, int nb,
              int chunks, int chunk_len, int log2_chunk_len, int red_blocks,

@@ -69,6 +69,9 @@ class HipBackend:
     def wait(self, slot):
         self.ctxs[slot].sync()
 
+    def ready(self, slot):
+        return self.ctxs[slot].done()
+
     def affine_result(self, slot):
         self.ctxs[slot].sync()
         raw = self.ctxs[slot].download(self.partial_bufs[slot].data_ptr(), 96).tobytes()
@@ -128,6 +131,11 @@ class ShardedMsm:
         if self.sync_device:
             self.sync_device()                      # RCCL ran on torch's stream, the combine runs on ours
         return self.backend.combine(self.gathered, self.world, slot)
+
+    def ready(self, slot):
+        """the slot's local MSM has completed (backends without a query are always 'ready': finish() waits)"""
+        probe = getattr(self.backend, "ready", None)
+        return True if probe is None else probe(slot)
 
     def commit(self, scalars, points):
         return self.finish(self.launch(scalars, points, 0))
