@@ -127,6 +127,14 @@ int vmpc_msm_table_build_dev(vmpc_ctx *ctx, const void *affine_points, size_t n,
 int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
                        const void *scalars, size_t m, const void *extra_scalars, void *out_ext,
                        void *out_affine);
+/* `batch` commitments over the same table in one pass (A_i and B_i of a round, compressed_pivot.py:41-42; or
+ * independent commitments a prover has queued): scalars[k] / extra_scalars[k] are DEVICE pointers held in HOST
+ * arrays of `batch` entries (extra_scalars may be NULL, or hold NULL entries); outputs are consecutive
+ * (128 bytes / 64 bytes per commitment).  Same results as `batch` calls of vmpc_msm_table_dev; the bucket
+ * reduction and the window recombination - latency chains - run once for the whole batch.  batch <= 16. */
+int vmpc_msm_table_batch_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                             const void *const *scalars, size_t m, const void *const *extra_scalars, int batch,
+                             void *out_ext, void *out_affine);
 
 /* sum of m extended points in index order, normalised (multi-GPU combine of the per-rank
  * partial commitments; also A * Q^c * B^(c^2) style products once the powers are points) */

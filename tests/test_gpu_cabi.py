@@ -459,3 +459,44 @@ def test_sha256_chunks(nat, ctx, nbytes):
         raw = data.tobytes()
         want = b"".join(hashlib.sha256(raw[o:o + chunk]).digest() for o in range(0, nbytes, chunk))
         assert got == want, (nbytes, chunk)
+
+
+@pytest.mark.parametrize("rows", [1, 4, 16])
+def test_table_batch_equals_single_commitments(nat, ctx, rows):
+    """vmpc_msm_table_batch_dev: K commitments over one table in one pass are the K single results - also
+    with different scalar distributions per commitment (uniform, sparse, all-equal), extras on some only."""
+    rng = random.Random(700 + rows)
+    n, K = 700, 5
+    _, pts = make_points(rng, n + 2)
+    g, extras = pts[:n], pts[n:]
+    dp, de = ctx.upload(aff_bytes(g)), ctx.upload(aff_bytes(extras))
+    table = ctx.msm_table_build(dp.ptr, n, de.ptr, 2, rows)
+    vecs = [[rng.randrange(ELL) for _ in range(n)],
+            [rng.randrange(ELL) if i % 2 else 0 for i in range(n)],        # half-populated (A_i / B_i shape)
+            [1] * n,
+            [0] * n,
+            [ELL - 1 - i for i in range(n)]]
+    exs = [[rng.randrange(ELL), 0], None, [0, 5], None, [ELL - 1, ELL - 2]]
+    dv = [ctx.upload(sc_bytes(nat, v)) for v in vecs]
+    dx = [ctx.upload(sc_bytes(nat, e)) if e is not None else None for e in exs]
+    single = []
+    for v, e in zip(dv, dx):
+        out = ctx.alloc(64)
+        ctx.msm_table(table.ptr, n, 2, v.ptr, n, e.ptr if e is not None else None, None, out.ptr, rows=rows)
+        single.append(dl_aff(ctx, out.ptr)[0])
+    outs, oute = ctx.alloc(64 * K), ctx.alloc(128 * K)
+    ctx.msm_table_batch(table.ptr, n, 2, [v.ptr for v in dv], n, [e.ptr if e is not None else None for e in dx],
+                        oute.ptr, outs.ptr, rows=rows)
+    assert dl_aff(ctx, outs.ptr, K) == single
+    raw = ctx.download(oute.ptr, 128 * K).tobytes()
+    for k in range(K):
+        X, Y, Z = (int.from_bytes(raw[128 * k + 32 * i:128 * k + 32 * i + 32], "little") for i in range(3))
+        assert ed.pt_affine((X, Y, Z)) == single[k][:2]
+    # and against the oracle for one of them
+    want = ed.pt_affine(ac.vector_commitment(vecs[0] + exs[0], 0, g + extras, ed.IDENTITY, signed_exponents=False))
+    assert single[0][:2] == want
+    # fewer terms than the table holds
+    ctx.msm_table_batch(table.ptr, n, 2, [dv[0].ptr, dv[4].ptr], 123, None, None, outs.ptr, rows=rows)
+    got = dl_aff(ctx, outs.ptr, 2)
+    for k, v in zip(range(2), (vecs[0], vecs[4])):
+        assert got[k][:2] == ed.pt_affine(ac.vector_commitment(v[:123], 0, g[:123], ed.IDENTITY, signed_exponents=False))

@@ -29,7 +29,7 @@ SYMBOLS = [
     "vmpc_memcpy_d2h", "vmpc_memcpy_d2d", "vmpc_ctx_profile", "vmpc_ctx_profile_read",
     "vmpc_ctx_set_window", "vmpc_ed25519_msm_plan", "vmpc_ed25519_madd_rate", "vmpc_ed25519_msm", "vmpc_ed25519_fold",
     "vmpc_ed25519_fixed_base_batch", "vmpc_fr_axpy", "vmpc_fr_dot", "vmpc_points_validate_dev",
-    "vmpc_msm_dev", "vmpc_msm_table_bytes", "vmpc_msm_table_build_dev", "vmpc_msm_table_dev", "vmpc_points_sum_dev", "vmpc_points_sum_many_dev", "vmpc_fixed_base_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
+    "vmpc_msm_dev", "vmpc_msm_table_bytes", "vmpc_msm_table_build_dev", "vmpc_msm_table_dev", "vmpc_msm_table_batch_dev", "vmpc_points_sum_dev", "vmpc_points_sum_many_dev", "vmpc_fixed_base_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
     "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_fr_dot_to_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
     "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
@@ -89,6 +89,7 @@ def load_library():
         "vmpc_msm_table_bytes": (i32, [sz, sz, i32, vp]),
         "vmpc_msm_table_build_dev": (i32, [vp, vp, sz, vp, sz, i32, vp]),
         "vmpc_msm_table_dev": (i32, [vp, vp, sz, sz, i32, vp, sz, vp, vp, vp]),
+        "vmpc_msm_table_batch_dev": (i32, [vp, vp, sz, sz, i32, vp, sz, vp, i32, vp, vp]),
         "vmpc_points_sum_dev": (i32, [vp, vp, sz, vp, vp]),
         "vmpc_points_sum_many_dev": (i32, [vp, vp, sz, sz, vp, vp]),
         "vmpc_repeat_dev": (i32, [vp, vp, sz, i32, vp, sz, i32, vp, vp]),
@@ -453,6 +454,18 @@ class Context:
                                            ctypes.c_void_p(extra_scalars_ptr),
                                            ctypes.c_void_p(out_ext_ptr), ctypes.c_void_p(out_affine_ptr)),
                "vmpc_msm_table_dev")
+
+    def msm_table_batch(self, table_ptr, table_n, table_extra, scalar_ptrs, m, extra_scalar_ptrs=None,
+                        out_ext_ptr=None, out_affine_ptr=None, rows=16):
+        """len(scalar_ptrs) commitments over one table in one pass; outputs consecutive (128 / 64 bytes each)"""
+        k = len(scalar_ptrs)
+        sc = (ctypes.c_void_p * k)(*[ctypes.c_void_p(p) for p in scalar_ptrs])
+        ex = None
+        if extra_scalar_ptrs is not None:
+            ex = (ctypes.c_void_p * k)(*[ctypes.c_void_p(p) for p in extra_scalar_ptrs])
+        _check(self.lib.vmpc_msm_table_batch_dev(self.handle, ctypes.c_void_p(table_ptr), table_n, table_extra, rows,
+                                                 sc, m, ex, k, ctypes.c_void_p(out_ext_ptr),
+                                                 ctypes.c_void_p(out_affine_ptr)), "vmpc_msm_table_batch_dev")
 
     def points_sum(self, ext_ptr, m, out_ext_ptr=None, out_affine_ptr=None):
         _check(self.lib.vmpc_points_sum_dev(self.handle, ctypes.c_void_p(ext_ptr), m,

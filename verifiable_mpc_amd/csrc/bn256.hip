@@ -391,6 +391,7 @@ static int bn_table_msm_dev(vmpc_ctx *ctx, const void *table, size_t table_n, co
     p.W = 1;
     p.top_row = -1;
     p.top_max_b = 0;
+    p.period = 0;
     msm_plan_geometry(ctx, p);
     msm_ws w;
     msm_layout(p, w, nullptr, 0, C::ACC_WORDS * 4);

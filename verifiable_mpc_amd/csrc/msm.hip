@@ -357,6 +357,10 @@ k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
             uint32_t *__restrict__ out_ext, uint32_t *__restrict__ out_aff) {
     __builtin_amdgcn_s_setprio(3);   // latency chain: win issue arbitration against co-resident bucket waves
     __shared__ uint32_t lds[64 * EXT_WORDS];
+    // block k = commitment k of a batch: its W windows, its own 128-byte / 64-byte output slot
+    partials += (size_t)EXT_WORDS * blockIdx.x * W * red_blocks;
+    if (out_ext) out_ext += 32 * blockIdx.x;
+    if (out_aff) out_aff += 16 * blockIdx.x;
     // phase 1: window sums.  lpw lanes share a window (strided partials), then a short tree.
     int lpw = 1;
     while (lpw * 2 * W <= 64 && lpw * 2 <= red_blocks) lpw *= 2;
@@ -504,6 +508,7 @@ k_points_validate(const uint32_t *__restrict__ aff, size_t n, unsigned long long
 // the niels array the sorted indices refer to (the call's own prepared points, or a fixed-base table)
 static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uint32_t *entries, void *out_ext,
                           void *out_affine) {
+    const int batch = p.W / p.period;        // commitments sharing this pass (1 unless vmpc_msm_table_batch_dev)
     hipStream_t st = ctx->stream;
     {
         vmpc_stage_scope s(ctx, "msm_bucket");
@@ -533,8 +538,8 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
     }
     {
         vmpc_stage_scope s(ctx, "msm_final");
-        k_msm_final<<<1, 64, 0, st>>>(w.partials, p.W, p.red_blocks, p.c, (uint32_t *)out_ext,
-                                      (uint32_t *)out_affine);
+        k_msm_final<<<batch, 64, 0, st>>>(w.partials, p.period, p.red_blocks, p.c, (uint32_t *)out_ext,
+                                          (uint32_t *)out_affine);
         VMPC_KERNEL_CHECK();
     }
     return VMPC_OK;
@@ -664,27 +669,33 @@ extern "C" int vmpc_msm_table_build_dev(vmpc_ctx *ctx, const void *affine_points
     return VMPC_OK;
 }
 
-extern "C" int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
-                                  const void *scalars, size_t m, const void *extra_scalars, void *out_ext,
-                                  void *out_affine) {
-    if (!ctx || !table || m > table_n || (m && !scalars) || table_n + table_extra == 0 ||
+// K commitments over the same tabulated generators in ONE pass: the K scalar vectors are recoded into K * (16 / rows)
+// digit rows, sorted together, accumulated by one bucket launch, reduced by one launch (K x the lanes for the
+// same chain length) and recombined by K workgroups side by side - so the latency chains of the reduction and
+// the Horner recombination are paid once per batch, not once per commitment.  (A_i and B_i of a Protocol-4
+// round, compressed_pivot.py:41-42, are such a pair; so are independent commitments queued by a prover.)
+static int msm_table_batch(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                           const void *const *scalars, size_t m, const void *const *extra_scalars, int K,
+                           void *out_ext, void *out_affine) {
+    if (!ctx || !table || m > table_n || (m && !scalars) || table_n + table_extra == 0 || K < 1 || K > 16 ||
         table_n + table_extra > ((size_t)1 << 26) || !msm_table_rows_ok(rows) || (!out_ext && !out_affine))
         return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t stride = msm_table_stride(table_n + table_extra);
-    // each of the 16 / rows bucket sets is one window of rows * stride entries
+    // each of the 16 / rows bucket sets of a commitment is one row of rows * stride entries
     msm_plan p;
     p.n_main = p.n_total = (size_t)rows * stride;
     p.n_extra = 0;
     p.scalar_bits = 253;
     p.c = MSM_TABLE_C;
-    p.W = MSM_TABLE_W / rows;
+    p.period = MSM_TABLE_W / rows;
+    p.W = K * p.period;
     p.top_row = -1;
     p.top_max_b = 0;
     if (rows == 1) {          // prepared generators: every window is its own row, the top one included
         msm_plan q;
         msm_make_plan(ctx, p.n_total, 0, 253, q, &ED25519_L);
-        if (q.c == p.c && q.W == p.W) {
+        if (q.c == p.c && q.W == p.period) {
             p.top_row = q.top_row;
             p.top_max_b = q.top_max_b;
         }
@@ -694,10 +705,28 @@ extern "C" int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table
     msm_layout(p, w, nullptr, 0, EXT_WORDS * 4);
     VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
     msm_layout(p, w, (char *)ctx->ws, 0, EXT_WORDS * 4);
-    VMPC_CHECK(msm_recode_rows(ctx, scalars, m, extra_scalars, table_n, table_extra, stride, w.digits, MSM_TABLE_C,
-                               MSM_TABLE_W, rows, ED25519_L));
+    for (int k = 0; k < K; k++) {
+        if (m && !scalars[k]) return VMPC_E_INVAL;
+        VMPC_CHECK(msm_recode_rows(ctx, scalars[k], m, extra_scalars ? extra_scalars[k] : nullptr, table_n, table_extra,
+                                   stride, w.digits + (size_t)k * p.period * p.n_pad, MSM_TABLE_C, MSM_TABLE_W, rows,
+                                   ED25519_L));
+    }
     VMPC_CHECK(msm_sort_digits(ctx, p, w));
     return msm_accumulate(ctx, p, w, (const uint32_t *)table, out_ext, out_affine);
+}
+
+extern "C" int vmpc_msm_table_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                                  const void *scalars, size_t m, const void *extra_scalars, void *out_ext,
+                                  void *out_affine) {
+    const void *sc[1] = {scalars}, *ex[1] = {extra_scalars};
+    return msm_table_batch(ctx, table, table_n, table_extra, rows, sc, m, extra_scalars ? ex : nullptr, 1, out_ext,
+                           out_affine);
+}
+
+extern "C" int vmpc_msm_table_batch_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                                        const void *const *scalars, size_t m, const void *const *extra_scalars,
+                                        int batch, void *out_ext, void *out_affine) {
+    return msm_table_batch(ctx, table, table_n, table_extra, rows, scalars, m, extra_scalars, batch, out_ext, out_affine);
 }
 
 // ---- fixed-base batch: out_i = n_i * B for one base B (generator setup, circuit_sat_r1cs.py:64-70,81) --

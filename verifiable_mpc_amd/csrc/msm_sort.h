@@ -26,7 +26,8 @@ struct msm_plan {
     int J;              // chunks of 8192 terms per digit row
     int idx_bits;       // bits of a term index (ceil log2 n_pad)
     int fine_in_entry;  // the 32-bit entry between the two sort passes carries the fine bucket (idx_bits + LB <= 31)
-    int top_row;        // digit row that is the top window alone (-1: none); its bins use LB_top fine bits
+    int period;         // digit rows per commitment: a batch of K commitments has W = K * period rows
+    int top_row;        // rows with (row % period) == top_row are a top window alone (-1: none): LB_top fine bits
     uint32_t top_max_b; // largest bucket index a canonical scalar's top digit reaches
     int LB_top;
     size_t n_pad;       // digit row stride: n_total rounded up to 8 (rows are 16-byte aligned, zero padded)

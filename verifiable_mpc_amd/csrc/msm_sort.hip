@@ -98,11 +98,11 @@ k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__r
 // ---- coarse histogram per (chunk, window) ---------------------------------------------------
 // digit d != 0 lands in bucket b = |d| - 1 in [0, nb); coarse bin = b >> LB, fine bucket = b & (2^LB - 1)
 __global__ void __launch_bounds__(SORT_BLOCK)
-k_sort_hist1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, int top_row, int LB_top, int J,
-             uint32_t *__restrict__ hist1, uint32_t *__restrict__ ctrl) {
+k_sort_hist1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, int top_row, int period, int LB_top,
+             int J, uint32_t *__restrict__ hist1, uint32_t *__restrict__ ctrl) {
     extern __shared__ uint32_t lds[];
     const int j = blockIdx.x, w = blockIdx.y;
-    if (w == top_row) LB = LB_top;
+    if (w % period == top_row) LB = LB_top;      // rows of a batch repeat with period = windows per commitment
     // ctrl[0] = #split buckets, [1] = #tasks, [2] = #partial sums, [16 ..) = tasks per (length class, window)
     if (j == 0 && w == 0)
         for (int i = threadIdx.x; i < 16 + MSM_SEG * (int)gridDim.y; i += SORT_BLOCK) ctrl[i] = 0;
@@ -124,8 +124,8 @@ k_sort_hist1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, i
 
 // ---- partition a chunk by coarse bin in LDS; every bin's run leaves contiguous -----------------
 __global__ void __launch_bounds__(SORT_BLOCK)
-k_sort_part1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, int top_row, int LB_top, int J,
-             int idx_bits, const uint32_t *__restrict__ gbase, uint32_t *__restrict__ out) {
+k_sort_part1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, int top_row, int period, int LB_top,
+             int J, int idx_bits, const uint32_t *__restrict__ gbase, uint32_t *__restrict__ out) {
     extern __shared__ uint32_t lds[];
     uint32_t *cnt = lds;                 // [NC]  run lengths
     uint32_t *lbase = lds + NC;          // [NC]  run starts inside the stage
@@ -134,7 +134,7 @@ k_sort_part1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, i
     uint32_t *stage = lds + 3 * NC + 16; // [SORT_T]
     // (a persistent form - two workgroups per CU walking the items - measured slower: 52 vs 38 us)
     const int j = blockIdx.x, w = blockIdx.y;
-    if (w == top_row) LB = LB_top;
+    if (w % period == top_row) LB = LB_top;
     for (int b = threadIdx.x; b < NC; b += SORT_BLOCK) {
         cnt[b] = 0;
         gb[b] = gbase[((size_t)w * NC + b) * J + j];   // strided 4-byte loads: issued first, used last
@@ -200,9 +200,9 @@ __device__ __forceinline__ uint32_t sort_fine_of(uint32_t e, int idx_bits, uint3
 #define SORT_FINE_REG (SORT_FINE_CAP / SORT_BLOCK)     // entries per thread of a staged bin
 
 // LB of a row, and (top row only) the buckets no digit of a canonical scalar reaches are marked empty
-__device__ __forceinline__ int sort_row_lb(int w, int cb, int NC, int LB, int top_row, int LB_top, int nb1,
-                                           uint32_t *__restrict__ counts, uint32_t *__restrict__ nseg) {
-    if (w != top_row) return LB;
+__device__ __forceinline__ int sort_row_lb(int w, int cb, int NC, int LB, int top_row, int period, int LB_top,
+                                           int nb1, uint32_t *__restrict__ counts, uint32_t *__restrict__ nseg) {
+    if (w % period != top_row) return LB;
     if (counts) {
         const uint32_t covered = (uint32_t)NC << LB_top, nb = (uint32_t)nb1 - 1u;
         for (uint32_t u = covered + cb * SORT_BLOCK + threadIdx.x; u < nb; u += NC * SORT_BLOCK) {
@@ -224,7 +224,7 @@ __device__ __forceinline__ int sort_row_lb(int w, int cb, int NC, int LB, int to
 template <bool FINE_IN_ENTRY>
 __global__ void __launch_bounds__(SORT_BLOCK, 8)      // 8 waves per SIMD = two workgroups per CU (<= 64 VGPRs)
 k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase, int NC, int W, int LB, int top_row,
-            int LB_top, int J, int idx_bits, int nb1, const int16_t *__restrict__ digits, size_t n_pad,
+            int period, int LB_top, int J, int idx_bits, int nb1, const int16_t *__restrict__ digits, size_t n_pad,
             uint32_t *__restrict__ counts, uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
             int seg_shift, uint32_t *__restrict__ nseg, uint32_t *__restrict__ block_hist,
             uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ seg_starts,
@@ -234,7 +234,7 @@ k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase,
     __shared__ uint32_t stage[SORT_FINE_CAP];
     // top window first: under-full, so its bins are the fullest
     const int cb = blockIdx.x % NC, w = W - 1 - blockIdx.x / NC;
-    LB = sort_row_lb(w, cb, NC, LB, top_row, LB_top, nb1, counts, nseg);
+    LB = sort_row_lb(w, cb, NC, LB, top_row, period, LB_top, nb1, counts, nseg);
     const int NF = 1 << LB;
     const size_t slot = (size_t)w * NC + cb;
     const uint32_t lo = gbase[slot * J], hi = gbase[(slot + 1) * J];   // gbase[H] = total
@@ -337,7 +337,7 @@ k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase,
 template <bool FINE_IN_ENTRY>
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_sort_fine_big(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase, int NC, int W, int LB,
-                int top_row, int LB_top, int J, int idx_bits, int nb1, const int16_t *__restrict__ digits,
+                int top_row, int period, int LB_top, int J, int idx_bits, int nb1, const int16_t *__restrict__ digits,
                 size_t n_pad, const uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
                 const uint32_t *__restrict__ ctrl) {
     if (ctrl[3] == 0) return;
@@ -347,7 +347,7 @@ k_sort_fine_big(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gb
     if (hi - lo <= SORT_FINE_CAP) return;
     __shared__ uint32_t tcnt[512], tex[512], cur[512], scratch[16], long_runs[SORT_FINE_CAP / 512 + 1], n_long;
     __shared__ uint32_t stage[SORT_FINE_CAP];
-    LB = sort_row_lb(w, cb, NC, LB, top_row, LB_top, nb1, nullptr, nullptr);
+    LB = sort_row_lb(w, cb, NC, LB, top_row, period, LB_top, nb1, nullptr, nullptr);
     const int NF = 1 << LB;
     const uint32_t fmask = (uint32_t)NF - 1u, imask = FINE_IN_ENTRY ? (1u << idx_bits) - 1u : 0x7fffffffu;
     const int16_t *drow = digits + (size_t)w * n_pad;
@@ -469,7 +469,8 @@ k_msm_classes(uint32_t *__restrict__ ctrl, int W, uint32_t *__restrict__ class_b
 // plan, pass 2 (pass 1 is the tail of k_sort_fine): one block per (window, coarse bin), one thread per
 // bucket: task id = first id of the (length, window) cell + this block's first rank in it + a local rank
 __global__ void __launch_bounds__(512)
-k_msm_plan2(const uint32_t *__restrict__ counts, int NC, int W, int NF, int top_row, int NF_top, int nb1, int seg_shift,
+k_msm_plan2(const uint32_t *__restrict__ counts, int NC, int W, int NF, int top_row, int period, int NF_top, int nb1,
+            int seg_shift,
             const uint32_t *__restrict__ class_base, const uint32_t *__restrict__ block_rank,
             uint2 *__restrict__ tasks) {
     const uint32_t seg_log = MSM_SEG_LOG2 + seg_shift, unit_round = (1u << seg_shift) - 1u;
@@ -482,7 +483,7 @@ k_msm_plan2(const uint32_t *__restrict__ counts, int NC, int W, int NF, int top_
                              block_rank[(size_t)block * MSM_SEG + (threadIdx.x - 1)];
     }
     __syncthreads();
-    if (w == top_row) NF = NF_top;
+    if (w % period == top_row) NF = NF_top;
     if (threadIdx.x >= (unsigned)NF) return;
     const size_t ci = (size_t)w * nb1 + 1 + (size_t)cb * NF + threadIdx.x;
     uint32_t cnt = counts[ci];
@@ -558,6 +559,7 @@ void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits
     }
     p.top_row = -1;
     p.top_max_b = 0;
+    p.period = p.W;
     if (modulus) {
         p.top_row = p.W - 1;
         p.top_max_b = msm_top_max_bucket(*modulus, p.c, p.W);
@@ -567,6 +569,7 @@ void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits
 
 // everything that follows from (n_total, c, W): sort decomposition, segment length, reduce shape
 void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
+    if (p.period <= 0 || p.period > p.W) p.period = p.W;
     p.nb = 1 << (p.c - 1);
     p.nb1 = p.nb + 1;
     p.n_pad = (p.n_total + 7) & ~(size_t)7;
@@ -682,7 +685,7 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
     {
         vmpc_stage_scope s(ctx, "msm_hist");
         k_sort_hist1<<<chunk_grid, SORT_BLOCK, (size_t)p.NC * 4, st>>>(w.digits, p.n_pad, p.NC, p.LB, p.top_row,
-                                                                      p.LB_top, p.J, w.hist1, w.ctrl);
+                                                                      p.period, p.LB_top, p.J, w.hist1, w.ctrl);
         VMPC_KERNEL_CHECK();
         VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint32_t>(st, w.hist1, w.hist1, w.hist1_n, w.scan_ws,
                                                             w.hist1 + w.hist1_n)));    // [H] = #entries
@@ -694,7 +697,7 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
             VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_sort_part1,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         k_sort_part1<<<chunk_grid, SORT_BLOCK, lds_bytes, st>>>(
-            w.digits, p.n_pad, p.NC, p.LB, p.top_row, p.LB_top, p.J, p.fine_in_entry ? p.idx_bits : 31, w.hist1,
+            w.digits, p.n_pad, p.NC, p.LB, p.top_row, p.period, p.LB_top, p.J, p.fine_in_entry ? p.idx_bits : 31, w.hist1,
             w.stage1);
         VMPC_KERNEL_CHECK();
     }
@@ -702,20 +705,20 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
         vmpc_stage_scope s(ctx, "msm_sort");
         const unsigned grid = (unsigned)p.NC * (unsigned)p.W;
         if (p.fine_in_entry) {
-            k_sort_fine<true><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.LB_top, p.J,
-                                                          p.idx_bits, p.nb1, w.digits, p.n_pad, w.counts, w.starts,
+            k_sort_fine<true><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period, p.LB_top,
+                                                          p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.counts, w.starts,
                                                           w.sorted, p.seg_shift, w.nseg, w.block_hist, w.heavy_list,
                                                           w.seg_starts, w.ctrl);
-            k_sort_fine_big<true><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.LB_top,
-                                                              p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.starts,
+            k_sort_fine_big<true><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period,
+                                                              p.LB_top, p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.starts,
                                                               w.sorted, w.ctrl);
         } else {
-            k_sort_fine<false><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.LB_top, p.J,
-                                                           p.idx_bits, p.nb1, w.digits, p.n_pad, w.counts, w.starts,
+            k_sort_fine<false><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period, p.LB_top,
+                                                           p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.counts, w.starts,
                                                            w.sorted, p.seg_shift, w.nseg, w.block_hist, w.heavy_list,
                                                            w.seg_starts, w.ctrl);
-            k_sort_fine_big<false><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.LB_top,
-                                                               p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.starts,
+            k_sort_fine_big<false><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period,
+                                                               p.LB_top, p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.starts,
                                                                w.sorted, w.ctrl);
         }
         VMPC_KERNEL_CHECK();
@@ -726,8 +729,8 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
         VMPC_KERNEL_CHECK();
         k_msm_classes<<<1, 1024, 0, st>>>(w.ctrl, p.W, w.block_base);
         VMPC_KERNEL_CHECK();
-        k_msm_plan2<<<w.plan_blocks, 512, 0, st>>>(w.counts, p.NC, p.W, 1 << p.LB, p.top_row, 1 << p.LB_top, p.nb1,
-                                                  p.seg_shift, w.block_base, w.block_hist, w.tasks);
+        k_msm_plan2<<<w.plan_blocks, 512, 0, st>>>(w.counts, p.NC, p.W, 1 << p.LB, p.top_row, p.period, 1 << p.LB_top,
+                                                  p.nb1, p.seg_shift, w.block_base, w.block_hist, w.tasks);
         VMPC_KERNEL_CHECK();
     }
     return VMPC_OK;

@@ -43,8 +43,10 @@ class HipBackend:
         self.ctxs = [ctx] + [get_aux_context(10 + i) for i in range(max(0, n_slots - 1))]
         # torch's fills run on torch's current stream, which the vmpc streams (hipStreamNonBlocking) are
         # not ordered with: finish them before the first MSM writes into these buffers
-        self.partial_bufs = [torch.zeros(128, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
-        self.combine_bufs = [torch.zeros(128, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
+        self.max_batch = 16
+        self.partial_bufs = [torch.zeros(128 * self.max_batch, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
+        self.combine_bufs = [torch.zeros(128 * self.max_batch, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
+        self.batch_of = [1] * len(self.ctxs)
         torch.cuda.current_stream().synchronize()
 
     @property
@@ -58,6 +60,15 @@ class HipBackend:
         if ctx is not self.ctxs[0]:
             ctx.wait_for(self.ctxs[0])
         table = getattr(points, "_table", None)
+        if isinstance(scalars, (list, tuple)):
+            # a BATCH of commitments over the same prepared generators in one pass (vmpc_msm_table_batch_dev):
+            # the latency chains of the bucket reduction and the recombination are paid once per batch
+            assert table is not None and points._table_tail == 0 and 1 <= len(scalars) <= self.max_batch
+            self.batch_of[slot] = len(scalars)
+            ctx.msm_table_batch(table.ptr, table.n, len(table.extra_bytes), [s.ptr for s in scalars], len(scalars[0]),
+                                None, self.partial_bufs[slot].data_ptr(), None, rows=table.rows)
+            return
+        self.batch_of[slot] = 1
         if table is not None and points._table_tail == 0 and len(scalars) <= table.n:
             # generators held in prepared form (PointVector.precompute): no per-call point preparation
             ctx.msm_table(table.ptr, table.n, len(table.extra_bytes), scalars.ptr, len(scalars), None,
@@ -72,27 +83,31 @@ class HipBackend:
     def ready(self, slot):
         return self.ctxs[slot].done()
 
+    def _points(self, ctx, ptr, b):
+        raw = ctx.download(ptr, 128 * b).tobytes()
+        pts = [Ed25519Point.from_proj_bytes(raw[128 * k:128 * k + 96]).normalize() for k in range(b)]
+        return pts if b > 1 else pts[0]
+
     def affine_result(self, slot):
         self.ctxs[slot].sync()
-        raw = self.ctxs[slot].download(self.partial_bufs[slot].data_ptr(), 96).tobytes()
-        return Ed25519Point.from_proj_bytes(raw).normalize()
+        return self._points(self.ctxs[slot], self.partial_bufs[slot].data_ptr(), self.batch_of[slot])
 
     def partial_tensor(self, slot):
-        return self.partial_bufs[slot]
+        return self.partial_bufs[slot][:128 * self.batch_of[slot]]
 
     def new_gather_buffer(self, world):
-        buf = self.torch.zeros((world, 128), dtype=self.torch.uint8, device="cuda")
+        buf = self.torch.zeros((world, 128 * self.max_batch), dtype=self.torch.uint8, device="cuda")
         self.torch.cuda.current_stream().synchronize()
         return buf
 
     def combine(self, gathered, world, slot=0):
         # on the slot's own (now idle) stream, into its own buffer: never queued behind or
-        # overwriting another commitment in flight
-        ctx = self.ctxs[slot]
-        ctx.points_sum(gathered.data_ptr(), world, self.combine_bufs[slot].data_ptr(), None)
+        # overwriting another commitment in flight.  `gathered` holds world x batch points (rank-major): one
+        # rank-ordered sum per commitment of the batch
+        ctx, b = self.ctxs[slot], self.batch_of[slot]
+        ctx.points_sum_many(gathered.data_ptr(), world, b, self.combine_bufs[slot].data_ptr(), None)
         ctx.sync()
-        raw = ctx.download(self.combine_bufs[slot].data_ptr(), 96).tobytes()
-        return Ed25519Point.from_proj_bytes(raw).normalize()
+        return self._points(ctx, self.combine_bufs[slot].data_ptr(), b)
 
 
 class ShardedMsm:
@@ -126,8 +141,9 @@ class ShardedMsm:
         if not self.collective:
             return self.backend.affine_result(slot)
         self.backend.wait(slot)                     # partial point is complete
-        # the single curve-point exchange: G x 128 B
-        self.dist.all_gather_into_tensor(self.gathered.view(-1), self.backend.partial_tensor(slot))
+        # the single curve-point exchange: G x 128 B (x the number of commitments of a batch)
+        mine = self.backend.partial_tensor(slot)
+        self.dist.all_gather_into_tensor(self.gathered.view(-1)[:self.world * mine.numel()], mine)
         if self.sync_device:
             self.sync_device()                      # RCCL ran on torch's stream, the combine runs on ours
         return self.backend.combine(self.gathered, self.world, slot)

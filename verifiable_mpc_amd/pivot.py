@@ -320,31 +320,42 @@ class _PendingCommitment:
         return Ed25519Point.from_proj_bytes(raw).normalize()
 
 
+def _table_args(xs, gamma, gv, h, ctx):
+    """(table, number of main scalars, extras-scalar buffer) when the commitment can run on gv's fixed-base
+    table: gv is (a prefix of) a tabulated vector, possibly followed by the first `tail` extras of the table
+    (g + [h]), and h is one of the remaining extras.  None otherwise."""
+    import numpy as np
+    table = getattr(gv, "_table", None)
+    if table is None:
+        return None
+    n = len(xs)
+    tail = gv._table_tail
+    n_main = len(gv) - tail
+    slot = table.extra_index(h)
+    used_tail = max(0, n - n_main)
+    if slot is None or slot < used_tail:
+        return None
+    esc = bytearray(32 * len(table.extra_bytes))
+    if not isinstance(gamma, DeviceScalar):
+        esc[32 * slot:32 * slot + 32] = reduce_scalar(_int(gamma)).to_bytes(32, "little")
+    gam = ctx.upload(np.frombuffer(bytes(esc), np.uint8))
+    if isinstance(gamma, DeviceScalar):
+        ctx.copy(gam.ptr + 32 * slot, gamma.ptr, 32)
+    if used_tail:
+        ctx.copy(gam.ptr, xs.ptr + 32 * n_main, 32 * used_tail)
+    return table, min(n, n_main), gam
+
+
 def _commit_launch(xs, gamma, gv, h, ctx):
     """enqueue h^gamma * prod g_i^{x_i} on `ctx` (device vectors in, 64-byte affine out)"""
     import numpy as np
     n = len(xs)
     out = ctx.alloc(128)
-    table = getattr(gv, "_table", None)
-    if table is not None:
-        # fixed-base path: gv is (a prefix of) a tabulated vector, possibly followed by the first
-        # `tail` extras of the table (g + [h]), and h is one of the remaining extras
-        tail = gv._table_tail
-        n_main = len(gv) - tail
-        slot = table.extra_index(h)
-        used_tail = max(0, n - n_main)
-        if slot is not None and slot >= used_tail:
-            esc = bytearray(32 * len(table.extra_bytes))
-            if not isinstance(gamma, DeviceScalar):
-                esc[32 * slot:32 * slot + 32] = reduce_scalar(_int(gamma)).to_bytes(32, "little")
-            gam = ctx.upload(np.frombuffer(bytes(esc), np.uint8))
-            if isinstance(gamma, DeviceScalar):
-                ctx.copy(gam.ptr + 32 * slot, gamma.ptr, 32)
-            if used_tail:
-                ctx.copy(gam.ptr, xs.ptr + 32 * n_main, 32 * used_tail)
-            ctx.msm_table(table.ptr, table.n, len(table.extra_bytes), xs.ptr, min(n, n_main), gam.ptr,
-                          out.ptr, None, rows=table.rows)
-            return _PendingCommitment(ctx, out, (gam, xs, gv, table))
+    targs = _table_args(xs, gamma, gv, h, ctx)
+    if targs is not None:
+        table, m, gam = targs
+        ctx.msm_table(table.ptr, table.n, len(table.extra_bytes), xs.ptr, m, gam.ptr, out.ptr, None, rows=table.rows)
+        return _PendingCommitment(ctx, out, (gam, xs, gv, table))
     if isinstance(gamma, DeviceScalar):
         gam = gamma
     else:
@@ -364,6 +375,20 @@ def vector_commitment_pair(x_a, gamma_a, g_a, x_b, gamma_b, g_b, h):
         # list mode: the proof's A_i, B_i carry the reference's representatives
         return vector_commitment(x_a, gamma_a, gva, h), vector_commitment(x_b, gamma_b, gvb, h)
     xa, xb = _scalars_on_device(x_a), _scalars_on_device(x_b)
+    if getattr(gva, "_table", None) is not None and getattr(gvb, "_table", None) is gva._table:
+        # both over the same tabulated CRS: ONE pass for the pair (vmpc_msm_table_batch_dev) - the bucket
+        # reduction and the window recombination, latency chains, run once instead of twice side by side
+        ctx = gva.ctx
+        ta, tb = _table_args(xa, gamma_a, gva, h, ctx), _table_args(xb, gamma_b, gvb, h, ctx)
+        if ta is not None and tb is not None and ta[1] == tb[1]:
+            table, m = ta[0], ta[1]
+            out = ctx.alloc(256)
+            ctx.msm_table_batch(table.ptr, table.n, len(table.extra_bytes), [xa.ptr, xb.ptr], m,
+                                [ta[2].ptr, tb[2].ptr], out.ptr, None, rows=table.rows)
+            ctx.sync()
+            raw = ctx.download(out.ptr, 256).tobytes()
+            return (Ed25519Point.from_proj_bytes(raw[:96]).normalize(),
+                    Ed25519Point.from_proj_bytes(raw[128:224]).normalize())
     main, aux = gva.ctx, get_aux_context()
     aux.wait_for(main)                 # inputs were produced on the main stream
     try:
