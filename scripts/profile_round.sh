@@ -24,9 +24,10 @@ for MODE in compact reference; do
       python3 "$REPO/scripts/prove_run.py" $MODE 20 3 > "$OUT/prof_${TAG}_prove_$MODE.json" 2> "$OUT/prof_${TAG}_prove_$MODE.err"
 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$TAG" -- \
-    python3 "$REPO/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-prove > /dev/null 2> "$OUT/pmc_fetch_$TAG.err"
+    python3 "$REPO/bench.py" --steps 4 --warmup 2 --batch 1 --no-cpu-baseline --no-prove > /dev/null 2> "$OUT/pmc_fetch_$TAG.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$TAG" -- \
-    python3 "$REPO/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-prove > /dev/null 2> "$OUT/pmc_write_$TAG.err"
+    python3 "$REPO/bench.py" --steps 4 --warmup 2 --batch 1 --no-cpu-baseline --no-prove > /dev/null 2> "$OUT/pmc_write_$TAG.err"
+# (--batch 1 in the PMC passes: every k_msm_bucket launch is then ONE commitment, the unit the roofline figure uses)
 # keep what travels back small: stats + counter csv only
 find "$OUT" -name '*kernel_trace.csv' -delete
 ls "$OUT" | grep "$TAG" | head -40

@@ -58,7 +58,8 @@ def main():
                       "hbm_bytes_per_launch_corrected": (2.0 * f_kib + w_kib) * 1024.0,
                       "launches_FETCH_SIZE": f_n, "launches_WRITE_SIZE": w_n}
     summary = {"command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 4 --warmup 2 "
-                          "--no-cpu-baseline --no-prove (one pass per counter; scripts/profile_round.sh)",
+                          "--batch 1 --no-cpu-baseline --no-prove (one pass per counter, one commitment per launch; "
+                          "scripts/profile_round.sh)",
                "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE tallies 128-B "
                              "requests at 64 B, MI355X_MICROARCH.md HBM section)",
                "kernels": kernels}
