@@ -164,3 +164,38 @@ def test_config4_shard_size_msm_2_21_properties(vm):
         assert vm.pivot.vector_commitment(x1, 0, g, ident) == c1
     finally:
         ctx.set_window(0)
+
+
+def test_config4_total_size_2_24_as_eight_cyclic_shards(vm):
+    """BASELINE config 4 at its TOTAL size on one GPU: the 2^24-term commitment computed whole equals the
+    rank-ordered sum of the eight cyclic shards' partial commitments (2^21 terms each) - the arithmetic of the
+    8-GPU run (parallel.ShardedMsm: cyclic shards, one partial point per rank, vmpc_points_sum_dev in rank order)
+    minus the all-gather, which needs the eight GPUs."""
+    from verifiable_mpc_amd import parallel
+    n, world = 1 << 24, 8
+    rng = np.random.default_rng(224)
+    group = vm.EllipticCurve("Ed25519", "projective")
+    ctx = vm.get_context()
+    exps = rand_scalars(rng, n)
+    g = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(exps), keep_proj=False)
+    sc = rand_scalars(rng, n)
+    x = vm.ScalarVector.from_array(sc)
+    whole = vm.pivot.vector_commitment(x, 0, g, vm.Ed25519Point.identity)
+    pts_host = g.affine_array()
+    gathered = ctx.alloc(128 * world)
+    for rank in range(world):
+        ps = vm.PointVector.from_affine_array(parallel.shard_rows(pts_host, world, rank), validate=False)
+        xs = vm.ScalarVector.from_array(parallel.shard_rows(sc, world, rank))
+        assert len(ps) == n // world
+        ctx.msm(xs.ptr, ps.affine_ptr, len(xs), None, None, 0, gathered.ptr + 128 * rank, None)
+        ctx.sync()
+        del ps, xs
+    out = ctx.alloc(64)
+    ctx.points_sum(gathered.ptr, world, None, out.ptr)
+    ctx.sync()
+    assert vm.Ed25519Point.from_affine_bytes(ctx.download(out.ptr, 64).tobytes()) == whole
+    # and a spot check of the whole against the exponent identity on a 2^16-term slice of the same vectors
+    m = 1 << 16
+    part = vm.pivot.vector_commitment(x[:m], 0, g[:m], vm.Ed25519Point.identity)
+    tot = sum(a * b for a, b in zip(vm._native.array_to_ints(sc[:m]), vm._native.array_to_ints(exps[:m]))) % ELL
+    assert part == vm.Ed25519Point.repeat(group.generator, tot)
