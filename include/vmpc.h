@@ -263,6 +263,34 @@ int vmpc_bn256_table_msm_dev(vmpc_ctx *ctx, int group, const void *table, size_t
 int vmpc_sha256_chunks_dev(vmpc_ctx *ctx, const void *data, size_t nbytes, size_t chunk_bytes,
                            void *out_digests);
 
+/* k halving folds of a tabulated generator vector in one pass (compressed_pivot.py:64 applied k times):
+ *   out[j] = sum_{b < 2^k} scalars[b] * P[j + b * (n_cols >> k)],   j < n_cols >> k,
+ * over the first n_cols columns of `table` (generators, then extras), n_cols a power of two, 1 <= k <= 6.
+ * `scalars`: 2^k canonical 32-byte residues in HOST memory (the challenge products); out: affine x||y.
+ * 64 mixed additions per column instead of a 253-bit scalar multiplication per generator and round. */
+int vmpc_msm_table_fold_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                            size_t n_cols, int k, const uint8_t *scalars, void *out_affine);
+
+/* ---- device-resident Protocol-4 prover rounds (SURVEY.md 8b "vmpc_ctx_round") -----------------------------------
+ * One halving round of compressed_pivot.py:29-86 per call: z_hat, L~ and the per-generator challenge products stay in
+ * HBM for all log N rounds; a round folds z_hat and L~ with the previous challenge (:70-76), computes the two
+ * inner products that are the exponents of k (:41-42), and A_i, B_i as one batched pass over the tabulated CRS
+ * (the generators are not folded: the pending challenge products multiply the scalars).  The Fiat-Shamir hash
+ * stays with the caller.  `table`: vmpc_msm_table_build_dev over table_n generators g followed by table_extra
+ * extras; extras 0 .. h_slots-1 are the tail of g_hat (h), extra k_slot is k (k_affine: the same point, x||y,
+ * host memory).  z_hat / L_tilde: N = table_n + h_slots device scalars each, N a power of two.
+ * On a CRS of 2^18 generators or more the context folds the generators once, after 5 rounds, with
+ * vmpc_msm_table_fold_dev and continues on a table of the 32-times shorter vector (VMPC_P4_JUMP=0: never). */
+typedef struct vmpc_p4 vmpc_p4;
+int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows, int h_slots,
+                   int k_slot, const uint8_t k_affine[64], const void *z_hat, const void *L_tilde, vmpc_p4 **out);
+/* prev_challenge: derived from the previous call's A, B; NULL on the first call.  out_A / out_B: affine x||y.
+ * Valid log2(N) - 1 times. */
+int vmpc_p4_round(vmpc_p4 *p4, const uint8_t prev_challenge[32], uint8_t out_A[64], uint8_t out_B[64]);
+/* after the last round: fold with its challenge and return z' (two 32-byte residues, compressed_pivot.py:77-79) */
+int vmpc_p4_finish(vmpc_p4 *p4, const uint8_t last_challenge[32], uint8_t out_z_prime[64]);
+int vmpc_p4_destroy(vmpc_p4 *p4);
+
 #ifdef __cplusplus
 }
 #endif

@@ -461,10 +461,19 @@ def test_sha256_chunks(nat, ctx, nbytes):
         assert got == want, (nbytes, chunk)
 
 
+@pytest.fixture()
+def table_window(ctx, request):
+    ctx.set_window(request.param)
+    yield request.param
+    ctx.set_window(0)
+
+
+@pytest.mark.parametrize("table_window", [0, 4, 8, 16], indirect=True)
 @pytest.mark.parametrize("rows", [1, 4, 16])
-def test_table_batch_equals_single_commitments(nat, ctx, rows):
+def test_table_batch_equals_single_commitments(nat, ctx, rows, table_window):
     """vmpc_msm_table_batch_dev: K commitments over one table in one pass are the K single results - also
-    with different scalar distributions per commitment (uniform, sparse, all-equal), extras on some only."""
+    with different scalar distributions per commitment (uniform, sparse, all-equal), extras on some only;
+    for every digit width the table path takes (0 = its own choice by size: 8 bits here)."""
     rng = random.Random(700 + rows)
     n, K = 700, 5
     _, pts = make_points(rng, n + 2)
@@ -500,3 +509,59 @@ def test_table_batch_equals_single_commitments(nat, ctx, rows):
     got = dl_aff(ctx, outs.ptr, 2)
     for k, v in zip(range(2), (vecs[0], vecs[4])):
         assert got[k][:2] == ed.pt_affine(ac.vector_commitment(v[:123], 0, g[:123], ed.IDENTITY, signed_exponents=False))
+
+
+@pytest.mark.parametrize("rows,n_main,n_extra,k", [(4, 63, 2, 3), (16, 31, 1, 5), (1, 64, 0, 1), (2, 255, 3, 6),
+                                                   (8, 16, 0, 4), (4, 300, 5, 2)])
+def test_table_fold_equals_k_reference_folds(nat, ctx, rows, n_main, n_extra, k):
+    """vmpc_msm_table_fold_dev: k rounds of g' = g_l^c * g_r (compressed_pivot.py:64, oracle fold_generators
+    applied k times with independent challenges) in one pass over the unfolded table; the columns folded are
+    the generators followed by the first extras (g_hat = g || h), as many as the largest power of two."""
+    rng = random.Random(rows * 1000 + n_main)
+    _, pts = make_points(rng, n_main + n_extra)
+    dp = ctx.upload(aff_bytes(pts[:n_main]))
+    de = ctx.upload(aff_bytes(pts[n_main:])) if n_extra else None
+    table = ctx.msm_table_build(dp.ptr, n_main, de.ptr if de else None, n_extra, rows)
+    n_cols = 1 << ((n_main + n_extra).bit_length() - 1)
+    for trial in range(2):
+        cs = [rng.randrange(ELL) for _ in range(k)] if trial == 0 else [0, 1, ELL - 1, 2, ELL - 2, 3][:k]
+        g = list(pts[:n_cols])
+        for c in cs:
+            half = len(g) // 2
+            g = ac.fold_generators(g[:half], g[half:], c)
+        # s_b = prod over rounds i (first round = top bit of b) of c_i where that bit is 0
+        s = []
+        for b in range(1 << k):
+            v = 1
+            for i, c in enumerate(cs):
+                if not (b >> (k - 1 - i)) & 1:
+                    v = v * c % ELL
+            s.append(v)
+        out = ctx.alloc(64 * (n_cols >> k))
+        ctx.msm_table_fold(table.ptr, n_main, n_extra, rows, n_cols, s, out.ptr)
+        ctx.sync()
+        got = dl_aff(ctx, out.ptr, n_cols >> k)
+        want = [ed.pt_affine(p) for p in g]
+        # an output that is the neutral element normalises to (0, 1); Z = 0 never occurs on a complete curve
+        assert [a[:2] for a in got] == want
+
+
+def test_table_fold_argument_checks(nat, ctx):
+    rng = random.Random(5)
+    _, pts = make_points(rng, 8)
+    dp = ctx.upload(aff_bytes(pts))
+    table = ctx.msm_table_build(dp.ptr, 8, None, 0, 4)
+    out = ctx.alloc(64 * 8)
+    with pytest.raises(nat.VmpcError):
+        ctx.msm_table_fold(table.ptr, 8, 0, 4, 16, [1, 2], out.ptr)          # more columns than the table has
+    with pytest.raises(nat.VmpcError):
+        ctx.msm_table_fold(table.ptr, 8, 0, 4, 6, [1, 2], out.ptr)           # not a power of two
+    with pytest.raises(nat.VmpcError):
+        ctx.msm_table_fold(table.ptr, 8, 0, 3, 8, [1, 2], out.ptr)           # rows
+    with pytest.raises(nat.VmpcError) as e:
+        lib = ctx.lib
+        import ctypes
+        raw = ctypes.create_string_buffer(b"\xff" * 64, 64)                   # non-canonical scalars
+        nat._check(lib.vmpc_msm_table_fold_dev(ctx.handle, ctypes.c_void_p(table.ptr), 8, 0, 4, 8, 1, raw,
+                                               ctypes.c_void_p(out.ptr)), "fold")
+    assert e.value.code == nat.E_NONCANON

@@ -327,6 +327,99 @@ def test_precomputed_generators_give_identical_proofs(vm):
     assert results[0] == results[1] == results[2] == results[3]
 
 
+@pytest.mark.parametrize("log_n", [2, 5, 12])
+def test_native_round_context_equals_python_driven_rounds(vm, monkeypatch, log_n):
+    """vmpc_p4_* (csrc/prover.hip: rounds resident on the device) against the same compact prover with the
+    rounds driven from Python: identical proofs, and the used-up context refuses further rounds."""
+    rng = random.Random(900 + log_n)
+    n = (1 << log_n) - 1
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    h, k = group.generator, vm.Ed25519Point.repeat(group.generator, rng.randrange(1, ELL))
+    g = vm.PointVector.fixed_base(h, [rng.randrange(1, ELL) for _ in range(n)])
+    g.precompute([h, k])
+    gens = {"g": g, "h": h, "k": k}
+    xs = vm.ScalarVector.from_ints([rng.randrange(ELL) for _ in range(n)])
+    Lf = vm.pivot.LinearForm(vm.ScalarVector.from_ints([rng.randrange(ELL) for _ in range(n)]))
+    gamma, rho = rng.randrange(1, ELL), rng.randrange(ELL)
+    r = [rng.randrange(ELL) for _ in range(n)]
+    P = vm.pivot.vector_commitment(xs, gamma, g, h)
+    y = gf(Lf(xs))
+    proofs = []
+    for native in (True, False):
+        monkeypatch.setattr(vm.compressed_pivot, "NATIVE_ROUNDS", native)
+        calls = []
+        real = vm._native.P4Rounds.round
+        monkeypatch.setattr(vm._native.P4Rounds, "round", lambda self, c=None: calls.append(1) or real(self, c))
+        proof = vm.compressed_pivot.protocol_5_prover(gens, P, Lf, y, xs, gamma, gf, transcript="compact",
+                                                      r=list(r), rho=rho)
+        monkeypatch.setattr(vm._native.P4Rounds, "round", real)
+        assert len(calls) == ((log_n - 1) if native else 0)
+        assert vm.compressed_pivot.protocol_5_verifier(gens, P, Lf, y, proof, gf, transcript="compact") is True
+        proofs.append({key: (tuple(v.normalize().coords) if hasattr(v, "normalize") else
+                             [int(e) for e in v] if isinstance(v, list) else int(v)) for key, v in proof.items()})
+    assert proofs[0] == proofs[1]
+
+
+@pytest.mark.parametrize("log_n,jump_k,min_log2", [(8, 5, 6), (8, 2, 4), (9, 6, 7), (6, 1, 3), (12, 5, 5), (7, 3, 7),
+                                                   (5, 3, 5), (12, 4, 12)])
+def test_native_round_context_with_fold_jumps(vm, monkeypatch, log_n, jump_k, min_log2):
+    """The round context applies the pending challenges to the generators after `jump_k` rounds
+    (vmpc_msm_table_fold_dev + a table for the folded vector) - once or repeatedly, down to a 4-element base:
+    the proof does not change."""
+    rng = random.Random(1900 + log_n + jump_k)
+    n = (1 << log_n) - 1
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    h, k = group.generator, vm.Ed25519Point.repeat(group.generator, rng.randrange(1, ELL))
+    g = vm.PointVector.fixed_base(h, [rng.randrange(1, ELL) for _ in range(n)])
+    g.precompute([h, k], rows=rng.choice([1, 4, 16]))
+    gens = {"g": g, "h": h, "k": k}
+    xs = vm.ScalarVector.from_ints([rng.randrange(ELL) for _ in range(n)])
+    Lf = vm.pivot.LinearForm(vm.ScalarVector.from_ints([rng.randrange(ELL) for _ in range(n)]))
+    gamma, rho = rng.randrange(1, ELL), rng.randrange(ELL)
+    r = [rng.randrange(ELL) for _ in range(n)]
+    P = vm.pivot.vector_commitment(xs, gamma, g, h)
+    y = gf(Lf(xs))
+    proofs = []
+    for setting in ((str(jump_k), str(min_log2)), ("0", "30")):
+        monkeypatch.setenv("VMPC_P4_JUMP", setting[0])
+        monkeypatch.setenv("VMPC_P4_JUMP_MIN_LOG2", setting[1])
+        proof = vm.compressed_pivot.protocol_5_prover(gens, P, Lf, y, xs, gamma, gf, transcript="compact",
+                                                      r=list(r), rho=rho)
+        assert vm.compressed_pivot.protocol_5_verifier(gens, P, Lf, y, proof, gf, transcript="compact") is True
+        proofs.append({key: (tuple(v.normalize().coords) if hasattr(v, "normalize") else
+                             [int(e) for e in v] if isinstance(v, list) else int(v)) for key, v in proof.items()})
+    assert proofs[0] == proofs[1]
+
+
+def test_native_round_context_argument_checks(vm):
+    ctx = vm.get_context()
+    group = vm.EllipticCurve("Ed25519", "projective")
+    h = group.generator
+    k = vm.Ed25519Point.repeat(h, 99)
+    g = vm.PointVector.fixed_base(h, list(range(2, 9)))           # 7 generators + h = 8
+    g.precompute([h, k])
+    z = vm.ScalarVector.from_ints(list(range(1, 9)))
+    with pytest.raises(vm._native.VmpcError):                      # k's slot inside the tail of g_hat
+        vm._native.P4Rounds(ctx, g._table, 1, 0, z.ptr, z.ptr)
+    with pytest.raises(vm._native.VmpcError):                      # N = 7 + 0 is not a power of two
+        vm._native.P4Rounds(ctx, g._table, 0, 1, z.ptr, z.ptr)
+    rounds = vm._native.P4Rounds(ctx, g._table, 1, 1, z.ptr, z.ptr)
+    rounds.round(None)
+    rounds.round(5)
+    with pytest.raises(vm._native.VmpcError):                      # log2(8) - 1 = 2 rounds only
+        rounds.round(7)
+    with pytest.raises(vm._native.VmpcError):                      # a later round needs the challenge
+        rounds.round(None)
+    z0, z1 = rounds.finish(7)                                      # z' = z_l + c z_r twice over
+    zs = [(a + 5 * b) % ELL for a, b in zip(range(1, 5), range(5, 9))]
+    assert (z0, z1) == ((zs[0] + 7 * zs[2]) % ELL, (zs[1] + 7 * zs[3]) % ELL)
+    with pytest.raises(vm._native.VmpcError):
+        rounds.finish(7)
+    rounds.close()
+
+
 def test_basic_pivot_fixture(vm, golden_small, monkeypatch, record_hashes):
     """Pi_s (pivot.py:156-205)."""
     case = golden_small["pis"][0]

@@ -35,7 +35,8 @@ SYMBOLS = [
     "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev", "vmpc_fr_tail_scalars_block_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
-    "vmpc_bn256_validate_dev", "vmpc_bn256_fixed_base_dev", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
+    "vmpc_bn256_validate_dev", "vmpc_bn256_fixed_base_dev",
+    "vmpc_msm_table_fold_dev", "vmpc_p4_create", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
 ]
 
 
@@ -119,6 +120,11 @@ def load_library():
         "vmpc_bn256_g2_msm_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_bn256_validate_dev": (i32, [vp, i32, vp, sz, u64p]),
         "vmpc_bn256_fixed_base_dev": (i32, [vp, i32, vp, vp, sz, vp]),
+        "vmpc_msm_table_fold_dev": (i32, [vp, vp, sz, sz, i32, sz, i32, vp, vp]),
+        "vmpc_p4_create": (i32, [vp, vp, sz, sz, i32, i32, i32, vp, vp, vp, ctypes.POINTER(vp)]),
+        "vmpc_p4_round": (i32, [vp, vp, vp, vp]),
+        "vmpc_p4_finish": (i32, [vp, vp, vp]),
+        "vmpc_p4_destroy": (i32, [vp]),
         "vmpc_bn256_table_bytes": (i32, [i32, sz, vp]),
         "vmpc_bn256_table_build_dev": (i32, [vp, i32, vp, sz, vp]),
         "vmpc_bn256_table_msm_dev": (i32, [vp, i32, vp, sz, vp, sz, vp, vp]),
@@ -467,6 +473,15 @@ class Context:
                                                  sc, m, ex, k, ctypes.c_void_p(out_ext_ptr),
                                                  ctypes.c_void_p(out_affine_ptr)), "vmpc_msm_table_batch_dev")
 
+    def msm_table_fold(self, table_ptr, table_n, table_extra, rows, n_cols, scalars, out_affine_ptr):
+        """out[j] = sum_b scalars[b] * P[j + b * (n_cols / len(scalars))]: log2(len(scalars)) folds in one pass"""
+        k = len(scalars).bit_length() - 1
+        assert len(scalars) == 1 << k
+        raw = ctypes.create_string_buffer(b"".join(scalar_to_bytes(v) for v in scalars), 32 << k)
+        _check(self.lib.vmpc_msm_table_fold_dev(self.handle, ctypes.c_void_p(table_ptr), table_n, table_extra, rows,
+                                                n_cols, k, raw, ctypes.c_void_p(out_affine_ptr)),
+               "vmpc_msm_table_fold_dev")
+
     def points_sum(self, ext_ptr, m, out_ext_ptr=None, out_affine_ptr=None):
         _check(self.lib.vmpc_points_sum_dev(self.handle, ctypes.c_void_p(ext_ptr), m,
                                             ctypes.c_void_p(out_ext_ptr),
@@ -623,6 +638,42 @@ class Context:
     def format_scalars(self, sc_ptr, n, is_signed=True):
         return self._format(self.lib.vmpc_format_scalars_dev, "vmpc_format_scalars_dev", sc_ptr, n,
                             78 + 3, 1 if is_signed else 0)
+
+
+class P4Rounds:
+    """vmpc_p4_*: the Protocol-4 prover's rounds with z_hat, L~ and the challenge products resident in HBM."""
+
+    def __init__(self, ctx, table, h_slots, k_slot, z_ptr, l_ptr):
+        self.ctx, self.table = ctx, table
+        h = ctypes.c_void_p()
+        _check(ctx.lib.vmpc_p4_create(ctx.handle, ctypes.c_void_p(table.ptr), table.n, len(table.extra_bytes), table.rows,
+                                      h_slots, k_slot, ctypes.create_string_buffer(table.extra_bytes[k_slot], 64),
+                                      ctypes.c_void_p(z_ptr), ctypes.c_void_p(l_ptr), ctypes.byref(h)),
+               "vmpc_p4_create")
+        self.handle = h
+
+    def round(self, prev_challenge=None):
+        a, b = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+        c = ctypes.create_string_buffer(scalar_to_bytes(prev_challenge), 32) if prev_challenge is not None else None
+        _check(self.ctx.lib.vmpc_p4_round(self.handle, c, a, b), "vmpc_p4_round")
+        return a.raw, b.raw
+
+    def finish(self, last_challenge):
+        z = ctypes.create_string_buffer(64)
+        c = ctypes.create_string_buffer(scalar_to_bytes(last_challenge), 32)
+        _check(self.ctx.lib.vmpc_p4_finish(self.handle, c, z), "vmpc_p4_finish")
+        return int.from_bytes(z.raw[:32], "little"), int.from_bytes(z.raw[32:], "little")
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.vmpc_p4_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- host-buffer one-shots ------------------------------------------------------------------

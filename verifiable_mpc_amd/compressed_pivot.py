@@ -22,6 +22,7 @@ Transcripts: "reference" = str(input_list) as in the reference (default);
 """
 import hashlib
 import logging
+import os
 from random import SystemRandom
 
 from . import pivot
@@ -297,6 +298,35 @@ def _unfold_commitment(Q0, rounds, order, ctx=None):
                                 pv.ctx).result()
 
 
+NATIVE_ROUNDS = os.environ.get("VMPC_NATIVE_ROUNDS", "1") != "0"
+
+
+def _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, transcript):
+    """All halving rounds through the device-resident round context (csrc/prover.hip, vmpc_p4_*): one C call
+    per round, only A_i, B_i (2 x 64 bytes) out and the challenge in; the compact hash chain stays here."""
+    from ._native import P4Rounds
+    table = g_hat._table
+    assert L_tilde.constant == 0, "Next line assumes L_tilde is a linear form, not affine form."
+    Lc = _coeffs_dev(L_tilde)
+    rounds = P4Rounds(g_hat.ctx, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, Lc.ptr)
+    try:
+        c = None
+        m = len(z_hat)
+        while m > 2:
+            a, b = rounds.round(c)
+            A = Ed25519Point.from_affine_bytes(a)
+            B = Ed25519Point.from_affine_bytes(b)
+            proof["A" + str(round_i)] = A
+            proof["B" + str(round_i)] = B
+            c = transcript.round_challenge(round_i, A, B, None, k, None, None)
+            m //= 2
+            round_i += 1
+        proof["z_prime"] = [gf(v) for v in rounds.finish(c)]
+    finally:
+        rounds.close()
+    return proof
+
+
 def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, transcript=None):
     """Non-interactive Protocol 4, prover (compressed_pivot.py:29-86); the reference's
     recursion is a loop here, `round_i` keeps its meaning."""
@@ -315,6 +345,9 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
         half = m // 2
         z_l, z_r, gamma_a, gamma_b = _round_prover_scalars(L_tilde, z_hat, half, gf)
         logger_cp.debug("Calculate A_i, B_i.")
+        if tail_cs is None and NATIVE_ROUNDS and transcript.mode == "compact" and isinstance(z_l, ScalarVector) \
+                and len(g_hat) == m and m >= 4 and m & (m - 1) == 0 and _tabulated(g_hat, k):
+            return _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, transcript)
         if tail_cs is None and transcript.mode == "compact" and isinstance(z_l, ScalarVector) \
                 and len(g_hat) == m and m >= 4 and (len(g_hat) <= TAIL_BASE or _tabulated(g_hat, k)):
             tail_cs = []

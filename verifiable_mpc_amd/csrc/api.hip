@@ -80,6 +80,8 @@ extern "C" int vmpc_ctx_destroy(vmpc_ctx *ctx) {
         }
     for (auto e : ctx->event_pool) VMPC_IGNORE(hipEventDestroy(e));
     if (ctx->xevent) VMPC_IGNORE(hipEventDestroy(ctx->xevent));
+    if (ctx->pin_event) VMPC_IGNORE(hipEventDestroy(ctx->pin_event));
+    if (ctx->pin) VMPC_IGNORE(hipHostFree(ctx->pin));
     if (ctx->ws) VMPC_IGNORE(hipFree(ctx->ws));
     if (ctx->d_status) VMPC_IGNORE(hipFree(ctx->d_status));
     if (ctx->own_stream) VMPC_IGNORE(hipStreamDestroy(ctx->stream));
@@ -148,6 +150,24 @@ extern "C" int vmpc_ctx_wait_for(vmpc_ctx *waiter, vmpc_ctx *other) {
 extern "C" int vmpc_ctx_set_window(vmpc_ctx *ctx, int c_bits) {
     if (!ctx || (c_bits != 0 && (c_bits < 4 || c_bits > 16))) return VMPC_E_INVAL;
     ctx->window_override = c_bits;
+    return VMPC_OK;
+}
+
+int vmpc_stage_h2d(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return VMPC_OK;
+    if (!ctx->pin_event) VMPC_HIP_CHECK(hipEventCreateWithFlags(&ctx->pin_event, hipEventDisableTiming));
+    else VMPC_HIP_CHECK(hipEventSynchronize(ctx->pin_event));     // the previous block has left the buffer
+    if (bytes > ctx->pin_bytes) {
+        if (ctx->pin) VMPC_IGNORE(hipHostFree(ctx->pin));
+        ctx->pin = nullptr;
+        ctx->pin_bytes = 0;
+        const size_t want = (bytes + 65535) & ~(size_t)65535;
+        VMPC_HIP_CHECK(hipHostMalloc(&ctx->pin, want, hipHostMallocDefault));
+        ctx->pin_bytes = want;
+    }
+    memcpy(ctx->pin, src, bytes);
+    VMPC_HIP_CHECK(hipMemcpyAsync(dst, ctx->pin, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VMPC_HIP_CHECK(hipEventRecord(ctx->pin_event, ctx->stream));
     return VMPC_OK;
 }
 

@@ -54,6 +54,10 @@ struct vmpc_ctx {
     int sort_fine_bits = -1;       // fine bits of the two-level bucket sort; -1 = automatic (msm_sort.hip)
     int cu_count = 256;
     hipEvent_t xevent = nullptr;   // cross-context ordering (vmpc_ctx_wait_for)
+    // pinned staging for small host -> device parameter blocks (vmpc_stage_h2d)
+    void *pin = nullptr;
+    size_t pin_bytes = 0;
+    hipEvent_t pin_event = nullptr;
     // profiling
     bool profile = false;
     std::vector<vmpc_stage> stages;
@@ -68,6 +72,8 @@ inline void *vmpc_ws_take(vmpc_ctx *ctx, size_t bytes) {
     ctx->ws_used = off + bytes;
     return (char *)ctx->ws + off;
 }
+// enqueue a copy of a small host block (schedules, parameter tables) to `dst`; `src` may be freed on return
+int vmpc_stage_h2d(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes);
 inline size_t vmpc_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // profiling helpers: bracket a kernel launch with events when ctx->profile is on

@@ -25,6 +25,7 @@
 #include "scan.h"
 #include "quad.h"
 #include "msm_sort.h"
+#include "ptio.h"
 
 // niels record stride in 32-bit words: 24 = packed 96 B, 32 = one 128-B line per gather
 #ifndef MSM_NIELS_STRIDE
@@ -33,110 +34,6 @@
 #ifndef MSM_REDUCE_WAVES
 #define MSM_REDUCE_WAVES 2
 #endif
-
-__device__ __forceinline__ void load_u32x8(uint32_t dst[8], const uint32_t *src) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(src);
-    uint4 a = p[0], b = p[1];
-    dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
-    dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
-}
-// packed 32-byte canonical elements (public buffers)
-__device__ __forceinline__ fe fe_ld8(const uint32_t *src) {
-    uint32_t w[8];
-    load_u32x8(w, src);
-    return fe_unpack(w);
-}
-__device__ __forceinline__ void fe_st8(uint32_t *dst, const fe &a) {
-    fe8 c = fe_pack(a);
-    uint4 *p = reinterpret_cast<uint4 *>(dst);
-    p[0] = make_uint4(c.w[0], c.w[1], c.w[2], c.w[3]);
-    p[1] = make_uint4(c.w[4], c.w[5], c.w[6], c.w[7]);
-}
-// raw limbs (workspace buffers and LDS): 10 words = five 8-byte accesses
-__device__ __forceinline__ fe fe_ld(const uint32_t *src) {
-    const uint2 *p = reinterpret_cast<const uint2 *>(src);
-    fe r;
-#pragma unroll
-    for (int i = 0; i < FE_LIMBS / 2; i++) {
-        uint2 v = p[i];
-        r.v[2 * i] = v.x;
-        r.v[2 * i + 1] = v.y;
-    }
-    return r;
-}
-__device__ __forceinline__ void fe_st(uint32_t *dst, const fe &a) {
-    uint2 *p = reinterpret_cast<uint2 *>(dst);
-#pragma unroll
-    for (int i = 0; i < FE_LIMBS / 2; i++) p[i] = make_uint2(a.v[2 * i], a.v[2 * i + 1]);
-}
-
-#define EXT_WORDS (4 * FE_LIMBS)      // extended point in a workspace buffer / LDS
-// niels entry: 30 limbs padded to one 128-byte line, moved with eight 16-byte accesses
-#ifndef NIELS_WORDS
-#define NIELS_WORDS 32
-#endif
-
-__device__ __forceinline__ ge_niels niels_ld_line(const uint32_t *src) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(src);
-    uint32_t w[32];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint4 v = p[i];
-        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-    }
-    ge_niels q;
-#pragma unroll
-    for (int i = 0; i < FE_LIMBS; i++) {
-        q.ymx.v[i] = w[i];
-        q.ypx.v[i] = w[FE_LIMBS + i];
-        q.t2d.v[i] = w[2 * FE_LIMBS + i];
-    }
-    return q;
-}
-__device__ __forceinline__ void niels_st_line(uint32_t *dst, const ge_niels &q) {
-    uint32_t w[32];
-#pragma unroll
-    for (int i = 0; i < FE_LIMBS; i++) {
-        w[i] = q.ymx.v[i];
-        w[FE_LIMBS + i] = q.ypx.v[i];
-        w[2 * FE_LIMBS + i] = q.t2d.v[i];
-    }
-    w[30] = 0;
-    w[31] = 0;
-    uint4 *p = reinterpret_cast<uint4 *>(dst);
-#pragma unroll
-    for (int i = 0; i < 8; i++) p[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-}
-
-__device__ __forceinline__ ge_ext ext_ld(const uint32_t *p) {
-    ge_ext r;
-    r.X = fe_ld(p);
-    r.Y = fe_ld(p + FE_LIMBS);
-    r.Z = fe_ld(p + 2 * FE_LIMBS);
-    r.T = fe_ld(p + 3 * FE_LIMBS);
-    return r;
-}
-__device__ __forceinline__ void ext_st(uint32_t *p, const ge_ext &a) {
-    fe_st(p, a.X);
-    fe_st(p + FE_LIMBS, a.Y);
-    fe_st(p + 2 * FE_LIMBS, a.Z);
-    fe_st(p + 3 * FE_LIMBS, a.T);
-}
-// packed 128-byte extended point X||Y||Z||T (public: partial sums exchanged between ranks)
-__device__ __forceinline__ ge_ext ext_ld8(const uint32_t *p) {
-    ge_ext r;
-    r.X = fe_ld8(p);
-    r.Y = fe_ld8(p + 8);
-    r.Z = fe_ld8(p + 16);
-    r.T = fe_ld8(p + 24);
-    return r;
-}
-__device__ __forceinline__ void ext_st8(uint32_t *p, const ge_ext &a) {
-    fe_st8(p, a.X);
-    fe_st8(p + 8, a.Y);
-    fe_st8(p + 16, a.Z);
-    fe_st8(p + 24, a.T);
-}
 
 // ---- prep: affine -> niels ------------------------------------------------------------
 __global__ void __launch_bounds__(MSM_BLOCK)
@@ -593,8 +490,16 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
 // preparation is left.  r trades table size (r * 128 bytes per generator) against that chain: the
 // bucket stage gathers table entries at random, so the table should stay Infinity-Cache resident
 // (256 MiB) - PointVector.precompute picks r accordingly.
-#define MSM_TABLE_C 16
-#define MSM_TABLE_W 16
+// The digit width c need not be the 16 bits the rows are spaced for: any c dividing 256 / r works, window w
+// (of 256 / c) then uses row w / (256 / (c r)) and set w % (256 / (c r)).  c = 16 is the throughput choice
+// (fewest entries); a SHORT commitment (the late rounds of the fold-free prover, small circuits) is bound by
+// the latency of reducing 2^15 buckets per set, and c = 8 (128 buckets per set, twice the entries) halves it.
+#define MSM_TABLE_SHORT ((size_t)1 << 17)
+static int msm_table_window(const vmpc_ctx *ctx, size_t terms) {
+    const int o = ctx->window_override;      // vmpc_ctx_set_window / VMPC_MSM_WINDOW: honoured when it divides 16
+    if (o == 4 || o == 8 || o == 16) return o;
+    return terms <= MSM_TABLE_SHORT ? 8 : 16;
+}
 
 static size_t msm_table_stride(size_t n_points) { return (n_points + 7) & ~(size_t)7; }
 static bool msm_table_rows_ok(int rows) { return rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16; }
@@ -618,7 +523,7 @@ k_msm_table_build(const uint32_t *__restrict__ aff, size_t n_main, const uint32_
     a.y = fe_ld8(src + 8);
     niels_st_line(table + NIELS_WORDS * i, ge_niels_from_affine(a));
     ge_ext q = ge_ext_from_affine(a);
-    const int dbl_per_row = MSM_TABLE_C * (MSM_TABLE_W / rows);
+    const int dbl_per_row = 256 / rows;
     // Rows 1 .. rows-1 need the AFFINE form of 2^(k rho) P: one inversion for all of them (Montgomery's
     // trick).  Pass 1 parks (X, Y, Z, Z_1 ... Z_rho) of row rho in the row's own 128-byte slot; pass 2 walks
     // back with the running inverse and overwrites the slot with the niels entry.
@@ -687,8 +592,9 @@ static int msm_table_batch(vmpc_ctx *ctx, const void *table, size_t table_n, siz
     p.n_main = p.n_total = (size_t)rows * stride;
     p.n_extra = 0;
     p.scalar_bits = 253;
-    p.c = MSM_TABLE_C;
-    p.period = MSM_TABLE_W / rows;
+    p.c = msm_table_window(ctx, m + table_extra);
+    const int windows = 256 / p.c;
+    p.period = windows / rows;
     p.W = K * p.period;
     p.top_row = -1;
     p.top_max_b = 0;
@@ -708,7 +614,7 @@ static int msm_table_batch(vmpc_ctx *ctx, const void *table, size_t table_n, siz
     for (int k = 0; k < K; k++) {
         if (m && !scalars[k]) return VMPC_E_INVAL;
         VMPC_CHECK(msm_recode_rows(ctx, scalars[k], m, extra_scalars ? extra_scalars[k] : nullptr, table_n, table_extra,
-                                   stride, w.digits + (size_t)k * p.period * p.n_pad, MSM_TABLE_C, MSM_TABLE_W, rows,
+                                   stride, w.digits + (size_t)k * p.period * p.n_pad, p.c, windows, rows,
                                    ED25519_L));
     }
     VMPC_CHECK(msm_sort_digits(ctx, p, w));

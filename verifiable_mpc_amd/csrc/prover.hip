@@ -1,0 +1,256 @@
+// Device-resident round context of the Protocol-4 prover ("vmpc_ctx_create(generators...),
+// vmpc_ctx_round(ctx, c[32], out_A[64], out_B[64])").
+//
+// One halving round of verifiable_mpc/ac20/compressed_pivot.py:29-86 is
+//     A_i = commit(z_l, L~(0 || z_l), g_r, k)   B_i = commit(z_r, L~(z_r || 0), g_l, k)      (:41-42)
+//     c   = hash(...)                                                                     (host)
+//     z'  = z_l + c z_r     L' = c L_l + L_r     (g' = fold, or - here - challenge products)  (:64-76)
+// This context keeps z_hat, L~ and the per-generator challenge products in HBM across all log N rounds and runs
+// a round as ONE C call: fold z and L~ with the previous challenge, the two inner products straight into the
+// exponent slots of k, the block of commitment scalars (k_fr_tail_scalars_inc), and A_i, B_i as one batched
+// pass over the tabulated CRS (vmpc_msm_table_batch_dev).  Only the 2 x 64 bytes of A_i, B_i come back and the
+// 32-byte challenge goes in; the Fiat-Shamir hash stays with the caller (it defines the transcript).
+// The generators are never folded: round i commits to the UNFOLDED CRS with the pending challenge products in the
+// scalars (same group elements as the fold - tests/test_gpu_protocol.py compares with the round-by-round form).
+//
+// After VMPC_P4_JUMP rounds (default 5) on a large CRS the pending challenge products ARE applied: one pass of
+// vmpc_msm_table_fold_dev (fold_jump.hip) produces the 2^5-times shorter folded vector, which gets its own small
+// table, and the remaining rounds run on that - a round over 2^15 generators is bound by launch latency
+// (0.4 ms), one over the unfolded 2^20 by its 16 M bucket additions (1.7 ms).
+//
+// Built entirely on the public C-ABI of this library (include/vmpc.h) plus the host-callable field code.
+#include <stdlib.h>
+
+#include <array>
+#include <vector>
+
+#include "common.h"
+#include "fe25519.h"
+#include "fr.h"
+#include "ge25519.h"
+
+struct vmpc_p4 {
+    vmpc_ctx *ctx;
+    const void *table;
+    size_t table_n, table_extra;
+    int rows, k_slot, h_slots;
+    int log2_n, round, committed;     // log2_n: of the vector the table holds (the base of the pending products)
+    int total_rounds;
+    size_t m;                         // current length of z_hat / L~
+    char *z[2], *L[2];                // ping-pong
+    char *products, *va, *vb, *ex_a, *ex_b, *out;
+    int cur;
+    // fold jump: challenges not yet applied to the generators, the folded vector and its table
+    std::vector<std::array<uint8_t, 32>> pending;
+    int jump_k;
+    size_t jump_min;
+    char *k_aff, *jump_g, *jump_table;
+};
+
+static void p4_release(vmpc_p4 *p) {
+    if (!p) return;
+    char *bufs[] = {p->z[0], p->z[1], p->L[0], p->L[1], p->products, p->va, p->vb, p->ex_a, p->ex_b, p->out,
+                    p->k_aff, p->jump_g, p->jump_table};
+    for (char *b : bufs)
+        if (b) (void)hipFree(b);
+    delete p;
+}
+
+// table: fixed-base table over table_n generators g followed by table_extra extras, of which extras
+// 0 .. h_slots-1 are the tail of g_hat (g_hat = g || h: h_slots = 1) and extra `k_slot` is k.
+// z_hat, L_tilde: N = table_n + h_slots scalars each (device, 32-byte canonical residues), N a power of two >= 4.
+extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                              int h_slots, int k_slot, const uint8_t k_affine[64], const void *z_hat,
+                              const void *L_tilde, vmpc_p4 **out) {
+    if (!ctx || !table || !z_hat || !L_tilde || !out || !k_affine || h_slots < 0 || k_slot < h_slots ||
+        (size_t)k_slot >= table_extra)
+        return VMPC_E_INVAL;
+    const size_t N = table_n + (size_t)h_slots;
+    if (N < 4 || (N & (N - 1))) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    vmpc_p4 *p = new vmpc_p4();
+    p->z[0] = p->z[1] = p->L[0] = p->L[1] = p->products = p->va = p->vb = p->ex_a = p->ex_b = p->out = nullptr;
+    p->k_aff = p->jump_g = p->jump_table = nullptr;
+    p->round = p->committed = p->cur = p->log2_n = 0;
+    p->jump_k = 5;                               // VMPC_P4_JUMP=0 keeps every round on the unfolded CRS
+    if (const char *e = getenv("VMPC_P4_JUMP")) p->jump_k = atoi(e);
+    if (p->jump_k < 0 || p->jump_k > 6) p->jump_k = 0;
+    p->jump_min = (size_t)1 << 18;
+    if (const char *e = getenv("VMPC_P4_JUMP_MIN_LOG2")) p->jump_min = (size_t)1 << atoi(e);
+    p->ctx = ctx;
+    p->table = table;
+    p->table_n = table_n;
+    p->table_extra = table_extra;
+    p->rows = rows;
+    p->h_slots = h_slots;
+    p->k_slot = k_slot;
+    p->m = N;
+    while (((size_t)1 << p->log2_n) < N) p->log2_n++;
+    p->total_rounds = p->log2_n - 1;
+    char **bufs[] = {&p->z[0], &p->z[1], &p->L[0], &p->L[1], &p->products, &p->va, &p->vb};
+    for (char **b : bufs) {
+        if (hipMalloc((void **)b, 32 * N) != hipSuccess) {
+            p4_release(p);
+            return VMPC_E_NOMEM;
+        }
+    }
+    if (hipMalloc((void **)&p->ex_a, 32 * table_extra) != hipSuccess ||
+        hipMalloc((void **)&p->ex_b, 32 * table_extra) != hipSuccess || hipMalloc((void **)&p->out, 256) != hipSuccess) {
+        p4_release(p);
+        return VMPC_E_NOMEM;
+    }
+    if (hipMalloc((void **)&p->k_aff, 64) != hipSuccess) {
+        p4_release(p);
+        return VMPC_E_NOMEM;
+    }
+    int rc = vmpc_memcpy_h2d(ctx, p->k_aff, k_affine, 64);
+    if (rc == VMPC_OK) rc = vmpc_memcpy_d2d(ctx, p->z[0], z_hat, 32 * N);
+    if (rc == VMPC_OK) rc = vmpc_memcpy_d2d(ctx, p->L[0], L_tilde, 32 * N);
+    if (rc != VMPC_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        p4_release(p);
+        return rc;
+    }
+    *out = p;
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_p4_destroy(vmpc_p4 *p) {
+    if (!p) return VMPC_E_INVAL;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    p4_release(p);
+    return VMPC_OK;
+}
+
+// z' = z_l + c z_r, L' = c L_l + L_r with the challenge of the round just hashed
+static int p4_fold(vmpc_p4 *p, const uint8_t c[32]) {
+    const size_t half = p->m / 2;
+    const int nx = p->cur ^ 1;
+    VMPC_CHECK(vmpc_fr_axpy_dev(p->ctx, c, p->z[p->cur] + 32 * half, p->z[p->cur], half, p->z[nx]));
+    VMPC_CHECK(vmpc_fr_axpy_dev(p->ctx, c, p->L[p->cur], p->L[p->cur] + 32 * half, half, p->L[nx]));
+    p->cur = nx;
+    p->m = half;
+    p->round++;
+    std::array<uint8_t, 32> a;
+    memcpy(a.data(), c, 32);
+    p->pending.push_back(a);
+    return VMPC_OK;
+}
+
+// Apply the pending challenges to the generators: g' = k folds of the table's vector, then a table for g' || k.
+static int p4_jump(vmpc_p4 *p) {
+    vmpc_ctx *ctx = p->ctx;
+    const int k = (int)p->pending.size();
+    const size_t N = (size_t)1 << p->log2_n, m_out = N >> k;
+    // s_b = prod_i (c_i if bit (k - i) of b is 0), i = 1..k: the products k_fr_tail_scalars_inc keeps per generator
+    std::vector<uint8_t> s((size_t)32 << k);
+    for (int b = 0; b < (1 << k); b++) {
+        fr v = fr_zero();
+        v.v[0] = 1;
+        for (int i = 0; i < k; i++)
+            if (!((b >> (k - 1 - i)) & 1)) v = fr_mul(v, fr_load((const uint32_t *)p->pending[i].data()));
+        fr_store((uint32_t *)(s.data() + 32 * b), v);
+    }
+    int rows = 16;
+    while (rows > 1 && (size_t)rows * 128 * (m_out + 1) > ((size_t)512 << 20)) rows /= 2;
+    size_t bytes = 0;
+    VMPC_CHECK(vmpc_msm_table_bytes(m_out, 1, rows, &bytes));
+    char *g = nullptr, *t = nullptr;
+    if (hipMalloc((void **)&g, 64 * m_out) != hipSuccess) return VMPC_E_NOMEM;
+    if (hipMalloc((void **)&t, bytes) != hipSuccess) {
+        (void)hipFree(g);
+        return VMPC_E_NOMEM;
+    }
+    int rc = vmpc_msm_table_fold_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, N, k, s.data(), g);
+    if (rc == VMPC_OK) rc = vmpc_msm_table_build_dev(ctx, g, m_out, p->k_aff, 1, rows, t);
+    if (rc != VMPC_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(g);
+        (void)hipFree(t);
+        return rc;
+    }
+    if (p->jump_table) {        // a second jump: the first one's table may still be read by queued work
+        VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(p->jump_table);
+        (void)hipFree(p->jump_g);
+    }
+    p->jump_g = g;
+    p->jump_table = t;
+    p->table = t;
+    p->table_n = m_out;
+    p->table_extra = 1;
+    p->rows = rows;
+    p->h_slots = 0;
+    p->k_slot = 0;
+    p->log2_n -= k;
+    p->pending.clear();
+    return VMPC_OK;
+}
+
+static void p4_affine(const uint8_t ext[128], uint8_t out[64]) {
+    ge_ext q;
+    uint32_t w[32];
+    memcpy(w, ext, 128);
+    q.X = fe_unpack(w);
+    q.Y = fe_unpack(w + 8);
+    q.Z = fe_unpack(w + 16);
+    q.T = fe_unpack(w + 24);
+    ge_aff a = ge_ext_to_affine(q);          // the one inversion per point: ~25 us on a host core
+    fe8 x = fe_pack(a.x), y = fe_pack(a.y);
+    memcpy(out, x.w, 32);
+    memcpy(out + 32, y.w, 32);
+}
+
+// One round: prev_challenge = the challenge derived from the PREVIOUS call's A, B (NULL on the first call).
+// Returns A_i, B_i as 64-byte affine points.  Synchronises the context's stream (the results are needed
+// for the next hash).
+extern "C" int vmpc_p4_round(vmpc_p4 *p, const uint8_t prev_challenge[32], uint8_t out_A[64], uint8_t out_B[64]) {
+    // the first call has no challenge yet, every later one needs the previous round's; log2(N) - 1 rounds in all
+    if (!p || !out_A || !out_B || (p->committed == 0) != (prev_challenge == nullptr) ||
+        (prev_challenge && p->m / 2 < 4))
+        return VMPC_E_INVAL;
+    vmpc_ctx *ctx = p->ctx;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    if (prev_challenge) VMPC_CHECK(p4_fold(p, prev_challenge));
+    if (p->jump_k && (int)p->pending.size() == p->jump_k && ((size_t)1 << p->log2_n) >= p->jump_min &&
+        p->log2_n - p->jump_k >= 2)
+        VMPC_CHECK(p4_jump(p));
+    const int t = (int)p->pending.size();                   // challenges the table's generators have not seen
+    const size_t half = p->m / 2, N = (size_t)1 << p->log2_n;
+    const char *z = p->z[p->cur], *L = p->L[p->cur];
+    hipStream_t st = ctx->stream;
+    VMPC_HIP_CHECK(hipMemsetAsync(p->ex_a, 0, 32 * p->table_extra, st));
+    VMPC_HIP_CHECK(hipMemsetAsync(p->ex_b, 0, 32 * p->table_extra, st));
+    // exponents of k: L~(0 || z_l) and L~(z_r || 0) (compressed_pivot.py:41-42), straight into k's slot
+    VMPC_CHECK(vmpc_fr_dot_to_dev(ctx, L + 32 * half, z, half, p->ex_a + 32 * p->k_slot));
+    VMPC_CHECK(vmpc_fr_dot_to_dev(ctx, L, z + 32 * half, half, p->ex_b + 32 * p->k_slot));
+    // commitment scalars over the unfolded g_hat: challenge products x the (shifted) witness halves
+    static const uint8_t zero[32] = {0};
+    VMPC_CHECK(vmpc_fr_tail_scalars_block_dev(ctx, t ? p->pending.back().data() : zero, t, p->log2_n, z, 0, N,
+                                              p->products, p->va, p->vb));
+    // the tail of g_hat (h) lives among the table's extras
+    for (int s = 0; s < p->h_slots; s++) {
+        VMPC_CHECK(vmpc_memcpy_d2d(ctx, p->ex_a + 32 * s, p->va + 32 * (p->table_n + s), 32));
+        VMPC_CHECK(vmpc_memcpy_d2d(ctx, p->ex_b + 32 * s, p->vb + 32 * (p->table_n + s), 32));
+    }
+    const void *sc[2] = {p->va, p->vb}, *ex[2] = {p->ex_a, p->ex_b};
+    VMPC_CHECK(vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
+                                        p->out, nullptr));
+    uint8_t ext[256];
+    VMPC_HIP_CHECK(hipMemcpyAsync(ext, p->out, 256, hipMemcpyDeviceToHost, st));
+    VMPC_CHECK(vmpc_ctx_sync(ctx));
+    p->committed++;
+    p4_affine(ext, out_A);
+    p4_affine(ext + 128, out_B);
+    return VMPC_OK;
+}
+
+// After the last round's challenge: fold once more and hand back z' (2 x 32 bytes, compressed_pivot.py:77-79).
+extern "C" int vmpc_p4_finish(vmpc_p4 *p, const uint8_t last_challenge[32], uint8_t out_z_prime[64]) {
+    if (!p || !last_challenge || !out_z_prime || p->m != 4 || p->committed != p->total_rounds) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
+    VMPC_CHECK(p4_fold(p, last_challenge));
+    VMPC_HIP_CHECK(hipMemcpyAsync(out_z_prime, p->z[p->cur], 64, hipMemcpyDeviceToHost, p->ctx->stream));
+    return vmpc_ctx_sync(p->ctx);
+}
