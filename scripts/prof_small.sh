@@ -4,7 +4,7 @@ k=${1:-12}; out=${2:-gpurun_out/small}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/$out
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof -o p -- python3 $R/scripts/prove_run.py compact $k 20 2>/dev/null | grep "^{" > $R/$out/run.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof -o p -- python3 $R/scripts/prove_run.py compact $k ${REPS:-20} 2>/dev/null | grep "^{" > $R/$out/run.log
 f=$(find $R/$out/prof -name '*kernel_stats.csv' | head -1)
 python3 - "$f" > $R/$out/stats.txt <<'PY'
 import csv, sys

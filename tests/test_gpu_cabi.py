@@ -473,7 +473,7 @@ def table_window(ctx, request):
 def test_table_batch_equals_single_commitments(nat, ctx, rows, table_window):
     """vmpc_msm_table_batch_dev: K commitments over one table in one pass are the K single results - also
     with different scalar distributions per commitment (uniform, sparse, all-equal), extras on some only;
-    for every digit width the table path takes (0 = its own choice by size: 8 bits here)."""
+    for every digit width the table path takes (0 = its own choice, 16 bits)."""
     rng = random.Random(700 + rows)
     n, K = 700, 5
     _, pts = make_points(rng, n + 2)

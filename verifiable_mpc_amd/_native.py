@@ -630,6 +630,16 @@ class Context:
         out.free()
         return res
 
+    def sha256_chunks_begin(self, data_ptr, nbytes, chunk_bytes=4096, keepalive=None):
+        """enqueue the chunk digests on this context; .result() synchronises it and returns the bytes"""
+        n_chunks = (nbytes + chunk_bytes - 1) // chunk_bytes
+        out = DeviceBuffer(self, 32 * max(1, n_chunks))
+        if n_chunks:
+            _check(self.lib.vmpc_sha256_chunks_dev(self.handle, ctypes.c_void_p(data_ptr), nbytes,
+                                                   chunk_bytes, ctypes.c_void_p(out.ptr)),
+                   "vmpc_sha256_chunks_dev")
+        return PendingDigests(self, out, n_chunks, keepalive)
+
     def format_points(self, proj_ptr, n):
         """uint8 array 'item0, item1, ..., ' for n projective points."""
         return self._format(self.lib.vmpc_format_points_dev, "vmpc_format_points_dev", proj_ptr, n,
@@ -638,6 +648,17 @@ class Context:
     def format_scalars(self, sc_ptr, n, is_signed=True):
         return self._format(self.lib.vmpc_format_scalars_dev, "vmpc_format_scalars_dev", sc_ptr, n,
                             78 + 3, 1 if is_signed else 0)
+
+
+class PendingDigests:
+    def __init__(self, ctx, out, n_chunks, keepalive):
+        self.ctx, self.out, self.n_chunks, self.keepalive = ctx, out, n_chunks, keepalive
+
+    def result(self):
+        res = self.ctx.download(self.out.ptr, 32 * self.n_chunks).tobytes() if self.n_chunks else b""
+        self.out.free()
+        self.keepalive = None
+        return res
 
 
 class P4Rounds:

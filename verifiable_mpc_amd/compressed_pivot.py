@@ -159,8 +159,22 @@ def generators_digest(generators):
     return d
 
 
+def _form_digest_begin(L):
+    """start hashing the form's coefficients on a side stream (the prover's announcement MSM runs meanwhile)"""
+    c = L.coeffs
+    if isinstance(c, ScalarVector) and len(c):
+        from .device import get_aux_context
+        side = get_aux_context(2)
+        side.wait_for(c.ctx)
+        L._pending_leaves = side.sha256_chunks_begin(c.ptr, 32 * len(c), CHUNK, keepalive=c)
+
+
 def _form_digest(L):
     c = L.coeffs
+    pending = getattr(L, "_pending_leaves", None)
+    if pending is not None:
+        L._pending_leaves = None
+        return hashlib.sha256(b"vmpc-ac20/form/v1" + (32 * len(c)).to_bytes(8, "little") + pending.result()).digest()
     if isinstance(c, ScalarVector):
         return _chunked_digest_dev(b"vmpc-ac20/form/v1", c.ctx, c.ptr, 32 * len(c))
     else:
@@ -547,6 +561,8 @@ def protocol_5_prover(generators, P, L, y, x, gamma, gf, transcript=None, r=None
         gv.text_begin()
         L.coeffs.text_begin()
 
+    if mode == "compact" and device_mode:
+        _form_digest_begin(L)
     logger_cp.debug("Calculate t.")
     t = L(r)
     if device_mode and isinstance(t, int):

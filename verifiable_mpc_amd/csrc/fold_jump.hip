@@ -28,8 +28,12 @@
 
 int vmpc_normalize_launch(vmpc_ctx *ctx, const void *proj, size_t n, void *out_affine);   // exact.hip
 
-// schedule entry: bits 0..7 = b, 8..12 = row, 15 = negate, 16..19 = |digit|; sched[o * e1] = #entries of offset o
-__global__ void __launch_bounds__(FJ_BLOCK, 2)
+// schedule entry: bits 0..7 = b, 8..12 = row, 15 = negate, 16..19 = |digit|; sched[o * e1] = #entries of offset o,
+// followed by the entries and a closing entry with |digit| = 0.
+// Registers: the running sum and one table entry live in VGPRs (as in k_msm_bucket: 4 waves per SIMD); the
+// outer accumulator is touched only at the <= 8 steps down in |digit|, so it lives in its output slot in memory.
+// (A first version with both accumulators in registers and a prefetched entry needed 255 VGPRs + 68 spilled.)
+__global__ void __launch_bounds__(FJ_BLOCK, 4)
 k_fold_jump(const uint32_t *__restrict__ table, size_t stride, size_t m_out, int O, int e1,
             const uint32_t *__restrict__ sched, unsigned n_blocks, uint32_t *__restrict__ partial) {
     const unsigned per_xcd = (n_blocks + 7) / 8;
@@ -38,39 +42,28 @@ k_fold_jump(const uint32_t *__restrict__ table, size_t stride, size_t m_out, int
     const unsigned og = (unsigned)O / FJ_WAVES;
     const int o = __builtin_amdgcn_readfirstlane((int)((l % og) * FJ_WAVES + (threadIdx.x >> 6)));
     const size_t j = (size_t)(l / og) * 64 + (threadIdx.x & 63);
-    const size_t jj = j < m_out ? j : m_out - 1;                          // idle lanes shadow the last output
+    if (j >= m_out) return;                                               // whole waves only when m_out < 64
     const uint32_t *sc = sched + (size_t)o * e1;
     const uint32_t cnt = sc[0];
-    const uint32_t *col = table + NIELS_WORDS * jj;
-    ge_ext acc = ge_ext_identity(), run = ge_ext_identity();
-    bool have = false, acc_set = false;
+    const uint32_t *col = table + NIELS_WORDS * j;
+    uint32_t *slot = partial + EXT_WORDS * (j * (size_t)O + o);
+    ge_ext run = ge_ext_identity();
+    ext_st(slot, run);
+    bool have = false;
     uint32_t cur = 8;
-    uint32_t ent = cnt ? sc[1] : 0;
-    ge_niels q = niels_ld_line(col + NIELS_WORDS * (((ent >> 8) & 0x1f) * stride + (size_t)(ent & 0xff) * m_out));
-    for (uint32_t e = 0; e < cnt; e++) {
-        const uint32_t en = sc[1 + (e + 1 < cnt ? e + 1 : e)];
-        ge_niels qn = niels_ld_line(col + NIELS_WORDS * (((en >> 8) & 0x1f) * stride + (size_t)(en & 0xff) * m_out));
+    for (uint32_t e = 0; e <= cnt; e++) {
+        const uint32_t ent = sc[1 + e];
         const uint32_t v = ent >> 16;
-        while (cur > v) {               // entries of |digit| = cur are all in: they count cur times in total
-            if (have) {
-                acc = acc_set ? ge_add(acc, run) : run;
-                acc_set = true;
-            }
-            cur--;
+        if (cur > v) {                  // entries of |digit| >= cur are all in `run`: it counts once per level
+            if (have)
+                for (; cur > v; cur--) ext_st(slot, ge_add(ext_ld(slot), run));
+            cur = v;
         }
+        if (e == cnt) break;
+        const ge_niels q = niels_ld_line(col + NIELS_WORDS * (((ent >> 8) & 0x1f) * stride + (size_t)(ent & 0xff) * m_out));
         run = ge_madd(run, ge_niels_select_neg(q, ((ent >> 15) & 1) != 0));
         have = true;
-        ent = en;
-        q = qn;
     }
-    while (cur > 0) {
-        if (have) {
-            acc = acc_set ? ge_add(acc, run) : run;
-            acc_set = true;
-        }
-        cur--;
-    }
-    if (j < m_out) ext_st(partial + EXT_WORDS * (j * (size_t)O + o), acc);
 }
 
 __global__ void __launch_bounds__(FJ_BLOCK)
@@ -98,7 +91,7 @@ extern "C" int vmpc_msm_table_fold_dev(vmpc_ctx *ctx, const void *table, size_t 
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t stride = (table_n + table_extra + 7) & ~(size_t)7;       // msm.hip: msm_table_stride
     const size_t m_out = n_cols >> k;
-    const int B = 1 << k, O = 64 / rows, e1 = rows * B + 1;
+    const int B = 1 << k, O = 64 / rows, e1 = rows * B + 2;
     // the shared schedule: signed 4-bit digits of the 2^k scalars, per offset sorted by |digit| descending
     std::vector<uint32_t> sched((size_t)O * e1, 0);
     {

@@ -159,6 +159,10 @@ k_msm_bucket_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__r
 // (8 Hillis-Steele steps) with the workgroup offsets 256 L g A_g left to the recombination kernel.  This kernel
 // went from 160 to 130 us, the single-wave recombination from 240 to 340 us, and the step time with three
 // commitments in flight did not move (1.12 ms): the VALU work saved here is not what bounds the pipeline.
+// Also tried for the prover's latency (one or two bucket sets, every bucket its own lane): a QUAD of lanes per
+// bucket (quad.h: 2 dependent multiplications per point operation instead of 8-9).  A/B on one box, compact
+// prover: 23.6-24.5 ms with it, 23.3-24.4 ms without at N = 2^20; 6.6 / 6.6 ms at 2^15.  2^16 weights b * B_b of
+// 15 bits are 1.5 M point operations - the stage is bound by that work, not by the length of one lane's chain.
 __global__ void __launch_bounds__(MSM_BLOCK, MSM_REDUCE_WAVES)
 k_msm_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ counts, int nb,
              int chunks, int chunk_len, int log2_chunk_len, int red_blocks,
@@ -491,16 +495,14 @@ extern "C" int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affi
 // bucket stage gathers table entries at random, so the table should stay Infinity-Cache resident
 // (256 MiB) - PointVector.precompute picks r accordingly.
 // The digit width c need not be the 16 bits the rows are spaced for: any c dividing 256 / r works, window w
-// (of 256 / c) then uses row w / (256 / (c r)) and set w % (256 / (c r)).  c = 16 is the throughput choice
-// (fewest entries); a SHORT commitment (the late rounds of the fold-free prover, small circuits) is bound by
-// the latency of reducing 2^15 buckets per set, and c = 8 (128 buckets per set, twice the entries) halves it.
-#define MSM_TABLE_SHORT ((size_t)1 << 17)
-static int msm_table_window(const vmpc_ctx *ctx, size_t terms) {
+// (of 256 / c) then uses row w / (256 / (c r)) and set w % (256 / (c r)).  c = 16 has the fewest entries and is
+// what every size uses; narrower digits (vmpc_ctx_set_window 4 or 8) were tried for SHORT commitments, whose
+// time is the latency of reducing 2^15 buckets per set - they lose: 2^7 buckets with 2^8+ entries each turn the
+// bucket stage into long serial runs (N = 2^12 prover: 8.0 ms at c = 8 against 6.1 ms at c = 16).
+static int msm_table_window(const vmpc_ctx *ctx) {
     const int o = ctx->window_override;      // vmpc_ctx_set_window / VMPC_MSM_WINDOW: honoured when it divides 16
-    if (o == 4 || o == 8 || o == 16) return o;
-    return terms <= MSM_TABLE_SHORT ? 8 : 16;
+    return (o == 4 || o == 8 || o == 16) ? o : 16;
 }
-
 static size_t msm_table_stride(size_t n_points) { return (n_points + 7) & ~(size_t)7; }
 static bool msm_table_rows_ok(int rows) { return rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16; }
 
@@ -592,7 +594,7 @@ static int msm_table_batch(vmpc_ctx *ctx, const void *table, size_t table_n, siz
     p.n_main = p.n_total = (size_t)rows * stride;
     p.n_extra = 0;
     p.scalar_bits = 253;
-    p.c = msm_table_window(ctx, m + table_extra);
+    p.c = msm_table_window(ctx);
     const int windows = 256 / p.c;
     p.period = windows / rows;
     p.W = K * p.period;
