@@ -613,12 +613,10 @@ static int msm_table_batch(vmpc_ctx *ctx, const void *table, size_t table_n, siz
     msm_layout(p, w, nullptr, 0, EXT_WORDS * 4);
     VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
     msm_layout(p, w, (char *)ctx->ws, 0, EXT_WORDS * 4);
-    for (int k = 0; k < K; k++) {
+    for (int k = 0; k < K; k++)
         if (m && !scalars[k]) return VMPC_E_INVAL;
-        VMPC_CHECK(msm_recode_rows(ctx, scalars[k], m, extra_scalars ? extra_scalars[k] : nullptr, table_n, table_extra,
-                                   stride, w.digits + (size_t)k * p.period * p.n_pad, p.c, windows, rows,
-                                   ED25519_L));
-    }
+    VMPC_CHECK(msm_recode_rows_batch(ctx, scalars, m, extra_scalars, K, table_n, table_extra, stride, w.digits,
+                                     (size_t)p.period * p.n_pad, p.c, windows, rows, ED25519_L));
     VMPC_CHECK(msm_sort_digits(ctx, p, w));
     return msm_accumulate(ctx, p, w, (const uint32_t *)table, out_ext, out_affine);
 }

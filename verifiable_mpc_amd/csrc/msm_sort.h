@@ -74,6 +74,10 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w);   // the same 
 int msm_recode_rows(vmpc_ctx *ctx, const void *scalars, size_t n_main, const void *extra_scalars,
                     size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *digits, int c, int W, int rows,
                     const msm_modulus &modulus);
+// the K commitments of one pass in one launch: commitment k writes its digit rows at digits + k * digits_per_commitment
+int msm_recode_rows_batch(vmpc_ctx *ctx, const void *const *scalars, size_t n_main, const void *const *extra_scalars,
+                          int K, size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *digits,
+                          size_t digits_per_commitment, int c, int W, int rows, const msm_modulus &modulus);
 
 static inline int msm_ilog2(int v) {
     int r = 0;

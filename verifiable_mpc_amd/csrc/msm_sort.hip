@@ -39,10 +39,15 @@ __device__ __forceinline__ void load_u32x8(uint32_t dst[8], const uint32_t *src)
 // ---- recode: scalar -> signed digits ----------------------------------------------------
 // Row w of `digits` holds window w of every term: main terms at [0, n_main), extra terms at
 // [extra_pos, extra_pos + n_extra), zeros (= no entry) everywhere else up to the row stride n_pad.
-__global__ void __launch_bounds__(MSM_BLOCK)
-k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__restrict__ sc_extra,
-             size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *__restrict__ digits, int c, int W,
-             int wpr, size_t set_stride, msm_modulus mod, uint32_t *__restrict__ status) {
+struct msm_recode_batch {          // scalar vectors of the commitments of one pass (vmpc_msm_table_batch_dev)
+    const uint32_t *sc[16];
+    const uint32_t *sc_extra[16];
+};
+
+__device__ __forceinline__ void
+msm_recode_term(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__restrict__ sc_extra,
+                size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *__restrict__ digits, int c, int W,
+                int wpr, size_t set_stride, const msm_modulus &mod, uint32_t *__restrict__ status) {
     // digit w of term i goes to digits[(w % wpr) * set_stride + (w / wpr) * n_pad + i]: plain MSMs have
     // wpr = W and set_stride = n_pad (row w = window w); fixed-base tables of r rows have wpr = W / r
     // bucket sets, each a row of r * n_pad entries whose index is the table position (w / wpr, i)
@@ -93,6 +98,22 @@ k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__r
         for (int k = 0; k < 7; k++) s[k] = (s[k] >> c) | (s[k + 1] << (32 - c));
         s[7] >>= c;
     }
+}
+
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_recode(const uint32_t *__restrict__ sc, size_t n_main, const uint32_t *__restrict__ sc_extra,
+             size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *__restrict__ digits, int c, int W,
+             int wpr, size_t set_stride, msm_modulus mod, uint32_t *__restrict__ status) {
+    msm_recode_term(sc, n_main, sc_extra, extra_pos, n_extra, n_pad, digits, c, W, wpr, set_stride, mod, status);
+}
+
+// blockIdx.y = commitment of the batch: its own scalar vectors, its own wpr digit rows
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_recode_batch(msm_recode_batch b, size_t n_main, size_t extra_pos, size_t n_extra, size_t n_pad,
+                   int16_t *__restrict__ digits, size_t digits_per_commitment, int c, int W, int wpr,
+                   size_t set_stride, msm_modulus mod, uint32_t *__restrict__ status) {
+    msm_recode_term(b.sc[blockIdx.y], n_main, b.sc_extra[blockIdx.y], extra_pos, n_extra, n_pad,
+                    digits + (size_t)blockIdx.y * digits_per_commitment, c, W, wpr, set_stride, mod, status);
 }
 
 // ---- coarse histogram per (chunk, window) ---------------------------------------------------
@@ -674,6 +695,24 @@ int msm_recode_rows(vmpc_ctx *ctx, const void *scalars, size_t n_main, const voi
     k_msm_recode<<<(unsigned)((n_pad + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
         (const uint32_t *)scalars, n_main, (const uint32_t *)extra_scalars, extra_pos, n_extra, n_pad, digits, c,
         W, wpr, (size_t)rows * n_pad, modulus, ctx->d_status);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+int msm_recode_rows_batch(vmpc_ctx *ctx, const void *const *scalars, size_t n_main, const void *const *extra_scalars,
+                          int K, size_t extra_pos, size_t n_extra, size_t n_pad, int16_t *digits,
+                          size_t digits_per_commitment, int c, int W, int rows, const msm_modulus &modulus) {
+    vmpc_stage_scope s(ctx, "msm_recode");
+    msm_recode_batch b;
+    memset(&b, 0, sizeof b);
+    for (int k = 0; k < K; k++) {
+        b.sc[k] = (const uint32_t *)scalars[k];
+        b.sc_extra[k] = extra_scalars ? (const uint32_t *)extra_scalars[k] : nullptr;
+    }
+    const int wpr = W / rows;
+    k_msm_recode_batch<<<dim3((unsigned)((n_pad + MSM_BLOCK - 1) / MSM_BLOCK), K), MSM_BLOCK, 0, ctx->stream>>>(
+        b, n_main, extra_pos, n_extra, n_pad, digits, digits_per_commitment, c, W, wpr, (size_t)rows * n_pad, modulus,
+        ctx->d_status);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }

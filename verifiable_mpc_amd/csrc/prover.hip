@@ -29,6 +29,107 @@
 #include "fr.h"
 #include "ge25519.h"
 
+
+// ---- the scalar side of one round in two launches ------------------------------------------------
+#define P4_BLOCK 256
+#define P4_MAX_GRID 1024
+
+struct p4_scalar {
+    uint32_t v[8];
+};
+
+__device__ __forceinline__ fr p4_ld(const uint32_t *src) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(src);
+    const uint4 a = q[0], b = q[1];
+    fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void p4_st(uint32_t *dst, const fr &a) {
+    uint4 *q = reinterpret_cast<uint4 *>(dst);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+// Fold with the previous challenge (z' = z_l + c z_r, L' = c L_l + L_r; compressed_pivot.py:70-76) and, in the
+// same pass, the inner products of the NEW vectors that are the exponents of k in the next A_i, B_i (:41-42):
+//   gamma_a = <L'[h:], z'[:h]>,   gamma_b = <L'[:h], z'[h:]>,   h = len(z') / 2.
+// Lane i < h produces elements i and h + i of both new vectors.  fold = 0: first round, nothing to fold.
+__global__ void __launch_bounds__(P4_BLOCK)
+k_p4_fold_dots(p4_scalar c, int fold, const uint32_t *__restrict__ z_in, const uint32_t *__restrict__ L_in,
+               size_t m_out, uint32_t *__restrict__ z_out, uint32_t *__restrict__ L_out,
+               uint32_t *__restrict__ partials /* [2][gridDim.x] */) {
+    __shared__ uint32_t lds[2 * P4_BLOCK * 8];
+    fr cc;
+#pragma unroll
+    for (int i = 0; i < 8; i++) cc.v[i] = c.v[i];
+    const size_t h = m_out / 2;
+    fr pa = fr_zero(), pb = fr_zero();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < h; i += (size_t)gridDim.x * blockDim.x) {
+        fr z0, z1, l0, l1;
+        if (fold) {
+            z0 = fr_add(p4_ld(z_in + 8 * i), fr_mul(cc, p4_ld(z_in + 8 * (m_out + i))));
+            z1 = fr_add(p4_ld(z_in + 8 * (h + i)), fr_mul(cc, p4_ld(z_in + 8 * (m_out + h + i))));
+            l0 = fr_add(fr_mul(cc, p4_ld(L_in + 8 * i)), p4_ld(L_in + 8 * (m_out + i)));
+            l1 = fr_add(fr_mul(cc, p4_ld(L_in + 8 * (h + i))), p4_ld(L_in + 8 * (m_out + h + i)));
+            p4_st(z_out + 8 * i, z0);
+            p4_st(z_out + 8 * (h + i), z1);
+            p4_st(L_out + 8 * i, l0);
+            p4_st(L_out + 8 * (h + i), l1);
+        } else {
+            z0 = p4_ld(z_in + 8 * i);
+            z1 = p4_ld(z_in + 8 * (h + i));
+            l0 = p4_ld(L_in + 8 * i);
+            l1 = p4_ld(L_in + 8 * (h + i));
+        }
+        pa = fr_add(pa, fr_mul(l1, z0));
+        pb = fr_add(pb, fr_mul(l0, z1));
+    }
+    p4_st(lds + 8 * threadIdx.x, pa);
+    p4_st(lds + 8 * (P4_BLOCK + threadIdx.x), pb);
+    __syncthreads();
+    for (int stride = P4_BLOCK / 2; stride >= 1; stride >>= 1) {
+        if ((int)threadIdx.x < stride) {
+            p4_st(lds + 8 * threadIdx.x, fr_add(p4_ld(lds + 8 * threadIdx.x), p4_ld(lds + 8 * (threadIdx.x + stride))));
+            p4_st(lds + 8 * (P4_BLOCK + threadIdx.x), fr_add(p4_ld(lds + 8 * (P4_BLOCK + threadIdx.x)),
+                                                             p4_ld(lds + 8 * (P4_BLOCK + threadIdx.x + stride))));
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        p4_st(partials + 8 * blockIdx.x, p4_ld(lds));
+        p4_st(partials + 8 * (gridDim.x + blockIdx.x), p4_ld(lds + 8 * P4_BLOCK));
+    }
+}
+
+// The extras' scalars of A_i (block 0) and B_i (block 1): zero everywhere, the tail of g_hat (h) from the
+// commitment scalars, the sum of the inner-product partials at k's slot.
+__global__ void __launch_bounds__(P4_BLOCK)
+k_p4_extras(const uint32_t *__restrict__ partials, int n_partials, const uint32_t *__restrict__ va,
+            const uint32_t *__restrict__ vb, size_t table_n, int h_slots, int k_slot, int n_extra,
+            uint32_t *__restrict__ ex_a, uint32_t *__restrict__ ex_b) {
+    __shared__ uint32_t lds[P4_BLOCK * 8];
+    const uint32_t *part = partials + 8 * (size_t)blockIdx.x * n_partials;
+    const uint32_t *v = blockIdx.x ? vb : va;
+    uint32_t *ex = blockIdx.x ? ex_b : ex_a;
+    fr acc = fr_zero();
+    for (int i = threadIdx.x; i < n_partials; i += P4_BLOCK) acc = fr_add(acc, p4_ld(part + 8 * i));
+    p4_st(lds + 8 * threadIdx.x, acc);
+    __syncthreads();
+    for (int stride = P4_BLOCK / 2; stride >= 1; stride >>= 1) {
+        if ((int)threadIdx.x < stride)
+            p4_st(lds + 8 * threadIdx.x, fr_add(p4_ld(lds + 8 * threadIdx.x), p4_ld(lds + 8 * (threadIdx.x + stride))));
+        __syncthreads();
+    }
+    for (int s = threadIdx.x; s < n_extra; s += P4_BLOCK) {
+        fr e = fr_zero();
+        if (s < h_slots) e = p4_ld(v + 8 * (table_n + s));
+        else if (s == k_slot) e = p4_ld(lds);
+        p4_st(ex + 8 * s, e);
+    }
+}
+
 struct vmpc_p4 {
     vmpc_ctx *ctx;
     const void *table;
@@ -38,8 +139,9 @@ struct vmpc_p4 {
     int total_rounds;
     size_t m;                         // current length of z_hat / L~
     char *z[2], *L[2];                // ping-pong
-    char *products, *va, *vb, *ex_a, *ex_b, *out;
+    char *products, *va, *vb, *ex_a, *ex_b, *out, *partials;
     int cur;
+    unsigned dots_grid;               // workgroups of the last k_p4_fold_dots = partial sums per inner product
     // fold jump: challenges not yet applied to the generators, the folded vector and its table
     std::vector<std::array<uint8_t, 32>> pending;
     int jump_k;
@@ -50,7 +152,7 @@ struct vmpc_p4 {
 static void p4_release(vmpc_p4 *p) {
     if (!p) return;
     char *bufs[] = {p->z[0], p->z[1], p->L[0], p->L[1], p->products, p->va, p->vb, p->ex_a, p->ex_b, p->out,
-                    p->k_aff, p->jump_g, p->jump_table};
+                    p->partials, p->k_aff, p->jump_g, p->jump_table};
     for (char *b : bufs)
         if (b) (void)hipFree(b);
     delete p;
@@ -70,7 +172,8 @@ extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, 
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     vmpc_p4 *p = new vmpc_p4();
     p->z[0] = p->z[1] = p->L[0] = p->L[1] = p->products = p->va = p->vb = p->ex_a = p->ex_b = p->out = nullptr;
-    p->k_aff = p->jump_g = p->jump_table = nullptr;
+    p->k_aff = p->jump_g = p->jump_table = p->partials = nullptr;
+    p->dots_grid = 0;
     p->round = p->committed = p->cur = p->log2_n = 0;
     p->jump_k = 5;                               // VMPC_P4_JUMP=0 keeps every round on the unfolded CRS
     if (const char *e = getenv("VMPC_P4_JUMP")) p->jump_k = atoi(e);
@@ -99,7 +202,8 @@ extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, 
         p4_release(p);
         return VMPC_E_NOMEM;
     }
-    if (hipMalloc((void **)&p->k_aff, 64) != hipSuccess) {
+    if (hipMalloc((void **)&p->k_aff, 64) != hipSuccess ||
+        hipMalloc((void **)&p->partials, (size_t)2 * P4_MAX_GRID * 32) != hipSuccess) {
         p4_release(p);
         return VMPC_E_NOMEM;
     }
@@ -123,18 +227,34 @@ extern "C" int vmpc_p4_destroy(vmpc_p4 *p) {
     return VMPC_OK;
 }
 
-// z' = z_l + c z_r, L' = c L_l + L_r with the challenge of the round just hashed
-static int p4_fold(vmpc_p4 *p, const uint8_t c[32]) {
-    const size_t half = p->m / 2;
-    const int nx = p->cur ^ 1;
-    VMPC_CHECK(vmpc_fr_axpy_dev(p->ctx, c, p->z[p->cur] + 32 * half, p->z[p->cur], half, p->z[nx]));
-    VMPC_CHECK(vmpc_fr_axpy_dev(p->ctx, c, p->L[p->cur], p->L[p->cur] + 32 * half, half, p->L[nx]));
-    p->cur = nx;
-    p->m = half;
-    p->round++;
-    std::array<uint8_t, 32> a;
-    memcpy(a.data(), c, 32);
-    p->pending.push_back(a);
+// z' = z_l + c z_r, L' = c L_l + L_r with the challenge of the round just hashed (c = NULL: first round, no fold),
+// and the two inner products of the resulting vectors as partial sums (k_p4_fold_dots)
+static int p4_fold_dots(vmpc_p4 *p, const uint8_t *c) {
+    p4_scalar cs;
+    memset(&cs, 0, sizeof cs);
+    if (c) {
+        memcpy(cs.v, c, 32);
+        if (fr_geq_l(cs.v)) return VMPC_E_NONCANON;
+    }
+    const size_t m_out = c ? p->m / 2 : p->m, h = m_out / 2;
+    const int nx = c ? p->cur ^ 1 : p->cur;
+    size_t g = (h + P4_BLOCK - 1) / P4_BLOCK;
+    if (g > P4_MAX_GRID) g = P4_MAX_GRID;
+    if (g == 0) g = 1;
+    vmpc_stage_scope s(p->ctx, "p4_fold_dots");
+    k_p4_fold_dots<<<(unsigned)g, P4_BLOCK, 0, p->ctx->stream>>>(
+        cs, c ? 1 : 0, (const uint32_t *)p->z[p->cur], (const uint32_t *)p->L[p->cur], m_out, (uint32_t *)p->z[nx],
+        (uint32_t *)p->L[nx], (uint32_t *)p->partials);
+    VMPC_KERNEL_CHECK();
+    p->dots_grid = (unsigned)g;
+    if (c) {
+        p->cur = nx;
+        p->m = m_out;
+        p->round++;
+        std::array<uint8_t, 32> a;
+        memcpy(a.data(), c, 32);
+        p->pending.push_back(a);
+    }
     return VMPC_OK;
 }
 
@@ -212,27 +332,26 @@ extern "C" int vmpc_p4_round(vmpc_p4 *p, const uint8_t prev_challenge[32], uint8
         return VMPC_E_INVAL;
     vmpc_ctx *ctx = p->ctx;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
-    if (prev_challenge) VMPC_CHECK(p4_fold(p, prev_challenge));
+    // fold with the previous challenge; exponents of k: L~(0 || z_l) and L~(z_r || 0) (compressed_pivot.py:41-42)
+    VMPC_CHECK(p4_fold_dots(p, prev_challenge));
     if (p->jump_k && (int)p->pending.size() == p->jump_k && ((size_t)1 << p->log2_n) >= p->jump_min &&
         p->log2_n - p->jump_k >= 2)
         VMPC_CHECK(p4_jump(p));
     const int t = (int)p->pending.size();                   // challenges the table's generators have not seen
-    const size_t half = p->m / 2, N = (size_t)1 << p->log2_n;
-    const char *z = p->z[p->cur], *L = p->L[p->cur];
+    const size_t N = (size_t)1 << p->log2_n;
+    const char *z = p->z[p->cur];
     hipStream_t st = ctx->stream;
-    VMPC_HIP_CHECK(hipMemsetAsync(p->ex_a, 0, 32 * p->table_extra, st));
-    VMPC_HIP_CHECK(hipMemsetAsync(p->ex_b, 0, 32 * p->table_extra, st));
-    // exponents of k: L~(0 || z_l) and L~(z_r || 0) (compressed_pivot.py:41-42), straight into k's slot
-    VMPC_CHECK(vmpc_fr_dot_to_dev(ctx, L + 32 * half, z, half, p->ex_a + 32 * p->k_slot));
-    VMPC_CHECK(vmpc_fr_dot_to_dev(ctx, L, z + 32 * half, half, p->ex_b + 32 * p->k_slot));
     // commitment scalars over the unfolded g_hat: challenge products x the (shifted) witness halves
     static const uint8_t zero[32] = {0};
     VMPC_CHECK(vmpc_fr_tail_scalars_block_dev(ctx, t ? p->pending.back().data() : zero, t, p->log2_n, z, 0, N,
                                               p->products, p->va, p->vb));
-    // the tail of g_hat (h) lives among the table's extras
-    for (int s = 0; s < p->h_slots; s++) {
-        VMPC_CHECK(vmpc_memcpy_d2d(ctx, p->ex_a + 32 * s, p->va + 32 * (p->table_n + s), 32));
-        VMPC_CHECK(vmpc_memcpy_d2d(ctx, p->ex_b + 32 * s, p->vb + 32 * (p->table_n + s), 32));
+    // extras: the tail of g_hat (h) lives among them, and k with the inner products as exponents
+    {
+        vmpc_stage_scope s(ctx, "p4_extras");
+        k_p4_extras<<<2, P4_BLOCK, 0, st>>>((const uint32_t *)p->partials, (int)p->dots_grid, (const uint32_t *)p->va,
+                                           (const uint32_t *)p->vb, p->table_n, p->h_slots, p->k_slot,
+                                           (int)p->table_extra, (uint32_t *)p->ex_a, (uint32_t *)p->ex_b);
+        VMPC_KERNEL_CHECK();
     }
     const void *sc[2] = {p->va, p->vb}, *ex[2] = {p->ex_a, p->ex_b};
     VMPC_CHECK(vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
@@ -250,7 +369,7 @@ extern "C" int vmpc_p4_round(vmpc_p4 *p, const uint8_t prev_challenge[32], uint8
 extern "C" int vmpc_p4_finish(vmpc_p4 *p, const uint8_t last_challenge[32], uint8_t out_z_prime[64]) {
     if (!p || !last_challenge || !out_z_prime || p->m != 4 || p->committed != p->total_rounds) return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
-    VMPC_CHECK(p4_fold(p, last_challenge));
+    VMPC_CHECK(p4_fold_dots(p, last_challenge));
     VMPC_HIP_CHECK(hipMemcpyAsync(out_z_prime, p->z[p->cur], 64, hipMemcpyDeviceToHost, p->ctx->stream));
     return vmpc_ctx_sync(p->ctx);
 }
