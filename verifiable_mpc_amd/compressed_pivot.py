@@ -171,6 +171,10 @@ def _form_digest_begin(L):
 
 def _form_digest(L):
     c = L.coeffs
+    done = getattr(L, "_form_digest", None)
+    if done is not None:
+        L._form_digest = None              # one use: the coefficients may change afterwards
+        return done
     pending = getattr(L, "_pending_leaves", None)
     if pending is not None:
         L._pending_leaves = None
@@ -568,7 +572,14 @@ def protocol_5_prover(generators, P, L, y, x, gamma, gf, transcript=None, r=None
     if device_mode and isinstance(t, int):
         t = gf(t)
     logger_cp.debug("Calculate A.")
-    A = pivot.vector_commitment(r, rho, gv, h)
+    if mode == "compact" and device_mode and isinstance(r, ScalarVector) and isinstance(gv, PointVector) \
+            and len(r):
+        # the announcement's MSM runs while the host finishes the form's digest (8192 leaf digests at N = 2^20)
+        pending = pivot._commit_launch(r, rho, gv, h, gv.ctx)
+        L._form_digest = _form_digest(L)
+        A = pending.result()
+    else:
+        A = pivot.vector_commitment(r, rho, gv, h)
     proof["t"] = t
     proof["A"] = A
 
@@ -589,7 +600,10 @@ def protocol_5_prover(generators, P, L, y, x, gamma, gf, transcript=None, r=None
     if mode == "reference":
         Q = Q.point()
     L_tilde = _extend_form(L, c1)
-    assert _same_residue(L(z) * c1, L_tilde(z_hat), order)
+    if not (mode == "compact" and device_mode):
+        # compressed_pivot.py:142's self-check; on the compact device path it would be two more inner products
+        # with a host round trip each (0.15 ms) for an identity that tests/test_gpu_protocol.py pins
+        assert _same_residue(L(z) * c1, L_tilde(z_hat), order)
 
     return protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof,
                              transcript=_p5_setup(generators, k, seed, mode, order))

@@ -4,7 +4,6 @@
 
 #include "common.h"
 
-#define VMPC_IGNORE(expr) ((void)(expr))
 
 thread_local char vmpc_err_buf[512] = {0};
 
@@ -83,6 +82,7 @@ extern "C" int vmpc_ctx_destroy(vmpc_ctx *ctx) {
     if (ctx->pin_event) VMPC_IGNORE(hipEventDestroy(ctx->pin_event));
     if (ctx->pin) VMPC_IGNORE(hipHostFree(ctx->pin));
     if (ctx->ws) VMPC_IGNORE(hipFree(ctx->ws));
+    if (ctx->p4_pool) VMPC_IGNORE(hipFree(ctx->p4_pool));
     if (ctx->d_status) VMPC_IGNORE(hipFree(ctx->d_status));
     if (ctx->own_stream) VMPC_IGNORE(hipStreamDestroy(ctx->stream));
     delete ctx;

@@ -58,6 +58,10 @@ struct vmpc_ctx {
     void *pin = nullptr;
     size_t pin_bytes = 0;
     hipEvent_t pin_event = nullptr;
+    // arena of the prover's round context, kept between proofs (prover.hip)
+    void *p4_pool = nullptr;
+    size_t p4_pool_bytes = 0;
+    bool p4_pool_busy = false;
     // profiling
     bool profile = false;
     std::vector<vmpc_stage> stages;
@@ -87,4 +91,5 @@ struct vmpc_stage_scope {
     ~vmpc_stage_scope() { vmpc_stage_end(ctx, h); }
 };
 
+#define VMPC_IGNORE(expr) ((void)(expr))
 #define VMPC_KERNEL_CHECK() VMPC_HIP_CHECK(hipGetLastError())

@@ -147,16 +147,33 @@ struct vmpc_p4 {
     int jump_k;
     size_t jump_min;
     char *k_aff, *jump_g, *jump_table;
+    size_t jump_g_bytes, jump_table_bytes;
+    char *arena;
+    bool arena_pooled;
+    std::vector<char *> extra;        // buffers of second and later jumps
 };
 
+// All device buffers of a context are carved from one arena that stays with the vmpc_ctx between proofs
+// (ctx->p4_pool): a prover that runs proof after proof pays no hipMalloc / hipFree (which synchronises the
+// device) per proof.  A second live context on the same vmpc_ctx gets a private arena.
 static void p4_release(vmpc_p4 *p) {
     if (!p) return;
-    char *bufs[] = {p->z[0], p->z[1], p->L[0], p->L[1], p->products, p->va, p->vb, p->ex_a, p->ex_b, p->out,
-                    p->partials, p->k_aff, p->jump_g, p->jump_table};
-    for (char *b : bufs)
-        if (b) (void)hipFree(b);
+    for (char *b : p->extra) (void)hipFree(b);
+    if (p->arena) {
+        if (p->arena_pooled) p->ctx->p4_pool_busy = false;
+        else (void)hipFree(p->arena);
+    }
     delete p;
 }
+
+// rows of the folded vector's table: as PointVector.precompute picks them (512 MiB at most)
+static int p4_jump_rows(size_t m_out) {
+    int rows = 16;
+    while (rows > 1 && (size_t)rows * 128 * (m_out + 1) > ((size_t)512 << 20)) rows /= 2;
+    return rows;
+}
+
+static size_t p4_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // table: fixed-base table over table_n generators g followed by table_extra extras, of which extras
 // 0 .. h_slots-1 are the tail of g_hat (g_hat = g || h: h_slots = 1) and extra `k_slot` is k.
@@ -173,6 +190,8 @@ extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, 
     vmpc_p4 *p = new vmpc_p4();
     p->z[0] = p->z[1] = p->L[0] = p->L[1] = p->products = p->va = p->vb = p->ex_a = p->ex_b = p->out = nullptr;
     p->k_aff = p->jump_g = p->jump_table = p->partials = nullptr;
+    p->arena = nullptr;
+    p->arena_pooled = false;
     p->dots_grid = 0;
     p->round = p->committed = p->cur = p->log2_n = 0;
     p->jump_k = 5;                               // VMPC_P4_JUMP=0 keeps every round on the unfolded CRS
@@ -190,22 +209,51 @@ extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, 
     p->m = N;
     while (((size_t)1 << p->log2_n) < N) p->log2_n++;
     p->total_rounds = p->log2_n - 1;
-    char **bufs[] = {&p->z[0], &p->z[1], &p->L[0], &p->L[1], &p->products, &p->va, &p->vb};
-    for (char **b : bufs) {
-        if (hipMalloc((void **)b, 32 * N) != hipSuccess) {
-            p4_release(p);
-            return VMPC_E_NOMEM;
+    // jump buffers, if this CRS is large enough to be folded (sizes of the FIRST jump; a later one is smaller)
+    p->jump_g_bytes = p->jump_table_bytes = 0;
+    if (p->jump_k && N >= p->jump_min && p->log2_n - p->jump_k >= 2) {
+        const size_t m_out = N >> p->jump_k;
+        p->jump_g_bytes = 64 * m_out;
+        if (vmpc_msm_table_bytes(m_out, 1, p4_jump_rows(m_out), &p->jump_table_bytes) != VMPC_OK) {
+            delete p;
+            return VMPC_E_INVAL;
         }
     }
-    if (hipMalloc((void **)&p->ex_a, 32 * table_extra) != hipSuccess ||
-        hipMalloc((void **)&p->ex_b, 32 * table_extra) != hipSuccess || hipMalloc((void **)&p->out, 256) != hipSuccess) {
-        p4_release(p);
-        return VMPC_E_NOMEM;
+    const size_t sizes[] = {32 * N, 32 * N, 32 * N, 32 * N, 32 * N, 32 * N, 32 * N, 32 * table_extra + 32,
+                            32 * table_extra + 32, 256, (size_t)2 * P4_MAX_GRID * 32, 64, p->jump_g_bytes,
+                            p->jump_table_bytes};
+    char **slots[] = {&p->z[0], &p->z[1], &p->L[0], &p->L[1], &p->products, &p->va, &p->vb, &p->ex_a,
+                      &p->ex_b, &p->out, &p->partials, &p->k_aff, &p->jump_g, &p->jump_table};
+    size_t total = 0;
+    for (size_t b : sizes) total += p4_align(b);
+    if (!ctx->p4_pool_busy) {
+        if (ctx->p4_pool_bytes < total) {
+            VMPC_IGNORE(hipStreamSynchronize(ctx->stream));
+            if (ctx->p4_pool) VMPC_IGNORE(hipFree(ctx->p4_pool));
+            ctx->p4_pool = nullptr;
+            ctx->p4_pool_bytes = 0;
+            if (hipMalloc(&ctx->p4_pool, total) != hipSuccess) {
+                delete p;
+                return VMPC_E_NOMEM;
+            }
+            ctx->p4_pool_bytes = total;
+        }
+        p->arena = (char *)ctx->p4_pool;
+        p->arena_pooled = true;
+        ctx->p4_pool_busy = true;
+    } else {
+        if (hipMalloc((void **)&p->arena, total) != hipSuccess) {
+            delete p;
+            return VMPC_E_NOMEM;
+        }
+        p->arena_pooled = false;
     }
-    if (hipMalloc((void **)&p->k_aff, 64) != hipSuccess ||
-        hipMalloc((void **)&p->partials, (size_t)2 * P4_MAX_GRID * 32) != hipSuccess) {
-        p4_release(p);
-        return VMPC_E_NOMEM;
+    {
+        size_t off = 0;
+        for (size_t i = 0; i < sizeof sizes / sizeof sizes[0]; i++) {
+            *slots[i] = sizes[i] ? p->arena + off : nullptr;
+            off += p4_align(sizes[i]);
+        }
     }
     int rc = vmpc_memcpy_h2d(ctx, p->k_aff, k_affine, 64);
     if (rc == VMPC_OK) rc = vmpc_memcpy_d2d(ctx, p->z[0], z_hat, 32 * N);
@@ -272,31 +320,20 @@ static int p4_jump(vmpc_p4 *p) {
             if (!((b >> (k - 1 - i)) & 1)) v = fr_mul(v, fr_load((const uint32_t *)p->pending[i].data()));
         fr_store((uint32_t *)(s.data() + 32 * b), v);
     }
-    int rows = 16;
-    while (rows > 1 && (size_t)rows * 128 * (m_out + 1) > ((size_t)512 << 20)) rows /= 2;
+    const int rows = p4_jump_rows(m_out);
     size_t bytes = 0;
     VMPC_CHECK(vmpc_msm_table_bytes(m_out, 1, rows, &bytes));
-    char *g = nullptr, *t = nullptr;
-    if (hipMalloc((void **)&g, 64 * m_out) != hipSuccess) return VMPC_E_NOMEM;
-    if (hipMalloc((void **)&t, bytes) != hipSuccess) {
-        (void)hipFree(g);
-        return VMPC_E_NOMEM;
+    // the arena holds the first jump's buffers; a later jump (CRS of 2^23 and more) allocates its own
+    char *g = p->jump_g, *t = p->jump_table;
+    if (p->table == p->jump_table || 64 * m_out > p->jump_g_bytes || bytes > p->jump_table_bytes) {
+        g = t = nullptr;
+        if (hipMalloc((void **)&g, 64 * m_out) != hipSuccess) return VMPC_E_NOMEM;
+        p->extra.push_back(g);
+        if (hipMalloc((void **)&t, bytes) != hipSuccess) return VMPC_E_NOMEM;
+        p->extra.push_back(t);
     }
-    int rc = vmpc_msm_table_fold_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, N, k, s.data(), g);
-    if (rc == VMPC_OK) rc = vmpc_msm_table_build_dev(ctx, g, m_out, p->k_aff, 1, rows, t);
-    if (rc != VMPC_OK) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(g);
-        (void)hipFree(t);
-        return rc;
-    }
-    if (p->jump_table) {        // a second jump: the first one's table may still be read by queued work
-        VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(p->jump_table);
-        (void)hipFree(p->jump_g);
-    }
-    p->jump_g = g;
-    p->jump_table = t;
+    VMPC_CHECK(vmpc_msm_table_fold_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, N, k, s.data(), g));
+    VMPC_CHECK(vmpc_msm_table_build_dev(ctx, g, m_out, p->k_aff, 1, rows, t));
     p->table = t;
     p->table_n = m_out;
     p->table_extra = 1;
@@ -308,18 +345,25 @@ static int p4_jump(vmpc_p4 *p) {
     return VMPC_OK;
 }
 
-static void p4_affine(const uint8_t ext[128], uint8_t out[64]) {
-    ge_ext q;
-    uint32_t w[32];
-    memcpy(w, ext, 128);
-    q.X = fe_unpack(w);
-    q.Y = fe_unpack(w + 8);
-    q.Z = fe_unpack(w + 16);
-    q.T = fe_unpack(w + 24);
-    ge_aff a = ge_ext_to_affine(q);          // the one inversion per point: ~25 us on a host core
-    fe8 x = fe_pack(a.x), y = fe_pack(a.y);
-    memcpy(out, x.w, 32);
-    memcpy(out + 32, y.w, 32);
+// A_i, B_i to affine on the host: one field inversion for the pair (1 / (Z_a Z_b)), ~15 us on a host core -
+// cheaper than a 265-step single-lane chain on the GPU and off the device's critical path
+static void p4_affine_pair(const uint8_t ext[256], uint8_t out_a[64], uint8_t out_b[64]) {
+    fe X[2], Y[2], Z[2];
+    for (int i = 0; i < 2; i++) {
+        uint32_t w[32];
+        memcpy(w, ext + 128 * i, 128);
+        X[i] = fe_unpack(w);
+        Y[i] = fe_unpack(w + 8);
+        Z[i] = fe_unpack(w + 16);
+    }
+    const fe inv = fe_inv(fe_mul(Z[0], Z[1]));
+    const fe zi[2] = {fe_mul(inv, Z[1]), fe_mul(inv, Z[0])};
+    uint8_t *out[2] = {out_a, out_b};
+    for (int i = 0; i < 2; i++) {
+        const fe8 x = fe_pack(fe_mul(X[i], zi[i])), y = fe_pack(fe_mul(Y[i], zi[i]));
+        memcpy(out[i], x.w, 32);
+        memcpy(out[i] + 32, y.w, 32);
+    }
 }
 
 // One round: prev_challenge = the challenge derived from the PREVIOUS call's A, B (NULL on the first call).
@@ -360,8 +404,7 @@ extern "C" int vmpc_p4_round(vmpc_p4 *p, const uint8_t prev_challenge[32], uint8
     VMPC_HIP_CHECK(hipMemcpyAsync(ext, p->out, 256, hipMemcpyDeviceToHost, st));
     VMPC_CHECK(vmpc_ctx_sync(ctx));
     p->committed++;
-    p4_affine(ext, out_A);
-    p4_affine(ext + 128, out_B);
+    p4_affine_pair(ext, out_A, out_B);
     return VMPC_OK;
 }
 
