@@ -289,6 +289,11 @@ int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, size_t tabl
 int vmpc_p4_round(vmpc_p4 *p4, const uint8_t prev_challenge[32], uint8_t out_A[64], uint8_t out_B[64]);
 /* after the last round: fold with its challenge and return z' (two 32-byte residues, compressed_pivot.py:77-79) */
 int vmpc_p4_finish(vmpc_p4 *p4, const uint8_t last_challenge[32], uint8_t out_z_prime[64]);
+/* every round and the finish behind one call, with the COMPACT transcript's challenge chain (verifiable_mpc_amd/
+ * compressed_pivot.py, _Transcript): state_i = SHA-256(state_{i-1} || round index, 4 bytes LE || A_i || B_i),
+ * c_i = state_i (little-endian integer) mod l.  state: in = the chain value before the first round, out = after the
+ * last.  out_AB: (log2(N) - 1) x 128 bytes, A_i || B_i affine.  The context must not have run a round yet. */
+int vmpc_p4_run_compact(vmpc_p4 *p4, uint8_t state[32], int first_round_index, uint8_t *out_AB, uint8_t out_z_prime[64]);
 int vmpc_p4_destroy(vmpc_p4 *p4);
 
 #ifdef __cplusplus

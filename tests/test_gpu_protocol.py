@@ -346,18 +346,24 @@ def test_native_round_context_equals_python_driven_rounds(vm, monkeypatch, log_n
     P = vm.pivot.vector_commitment(xs, gamma, g, h)
     y = gf(Lf(xs))
     proofs = []
-    for native in (True, False):
+    # the chain of challenges inside the C call / one C call per round / every round driven from Python
+    for native, chain in ((True, True), (True, False), (False, False)):
         monkeypatch.setattr(vm.compressed_pivot, "NATIVE_ROUNDS", native)
+        monkeypatch.setattr(vm.compressed_pivot, "NATIVE_CHAIN", chain)
         calls = []
-        real = vm._native.P4Rounds.round
+        real, real_run = vm._native.P4Rounds.round, vm._native.P4Rounds.run_compact
         monkeypatch.setattr(vm._native.P4Rounds, "round", lambda self, c=None: calls.append(1) or real(self, c))
+        monkeypatch.setattr(vm._native.P4Rounds, "run_compact",
+                            lambda self, *a: calls.append(100) or real_run(self, *a))
         proof = vm.compressed_pivot.protocol_5_prover(gens, P, Lf, y, xs, gamma, gf, transcript="compact",
                                                       r=list(r), rho=rho)
         monkeypatch.setattr(vm._native.P4Rounds, "round", real)
-        assert len(calls) == ((log_n - 1) if native else 0)
+        monkeypatch.setattr(vm._native.P4Rounds, "run_compact", real_run)
+        assert sum(calls) == (100 if chain else (log_n - 1) if native else 0)
         assert vm.compressed_pivot.protocol_5_verifier(gens, P, Lf, y, proof, gf, transcript="compact") is True
         proofs.append({key: (tuple(v.normalize().coords) if hasattr(v, "normalize") else
                              [int(e) for e in v] if isinstance(v, list) else int(v)) for key, v in proof.items()})
+    assert proofs[0] == proofs[1] == proofs[2]
     assert proofs[0] == proofs[1]
 
 

@@ -36,7 +36,7 @@ SYMBOLS = [
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev", "vmpc_fr_tail_scalars_block_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
     "vmpc_bn256_validate_dev", "vmpc_bn256_fixed_base_dev",
-    "vmpc_msm_table_fold_dev", "vmpc_p4_create", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
+    "vmpc_msm_table_fold_dev", "vmpc_p4_create", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_run_compact", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
 ]
 
 
@@ -124,6 +124,7 @@ def load_library():
         "vmpc_p4_create": (i32, [vp, vp, sz, sz, i32, i32, i32, vp, vp, vp, ctypes.POINTER(vp)]),
         "vmpc_p4_round": (i32, [vp, vp, vp, vp]),
         "vmpc_p4_finish": (i32, [vp, vp, vp]),
+        "vmpc_p4_run_compact": (i32, [vp, vp, i32, vp, vp]),
         "vmpc_p4_destroy": (i32, [vp]),
         "vmpc_bn256_table_bytes": (i32, [i32, sz, vp]),
         "vmpc_bn256_table_build_dev": (i32, [vp, i32, vp, sz, vp]),
@@ -684,6 +685,16 @@ class P4Rounds:
         c = ctypes.create_string_buffer(scalar_to_bytes(last_challenge), 32)
         _check(self.ctx.lib.vmpc_p4_finish(self.handle, c, z), "vmpc_p4_finish")
         return int.from_bytes(z.raw[:32], "little"), int.from_bytes(z.raw[32:], "little")
+
+    def run_compact(self, state, first_round_index, rounds):
+        """all rounds + finish with the compact challenge chain: (new state, [(A, B) bytes], (z0, z1))"""
+        st = ctypes.create_string_buffer(bytes(state), 32)
+        ab = ctypes.create_string_buffer(128 * rounds)
+        z = ctypes.create_string_buffer(64)
+        _check(self.ctx.lib.vmpc_p4_run_compact(self.handle, st, first_round_index, ab, z), "vmpc_p4_run_compact")
+        raw = ab.raw
+        return (st.raw, [(raw[128 * i:128 * i + 64], raw[128 * i + 64:128 * i + 128]) for i in range(rounds)],
+                (int.from_bytes(z.raw[:32], "little"), int.from_bytes(z.raw[32:], "little")))
 
     def close(self):
         if self.handle:

@@ -317,6 +317,7 @@ def _unfold_commitment(Q0, rounds, order, ctx=None):
 
 
 NATIVE_ROUNDS = os.environ.get("VMPC_NATIVE_ROUNDS", "1") != "0"
+NATIVE_CHAIN = os.environ.get("VMPC_NATIVE_CHAIN", "1") != "0"      # the compact challenge chain inside the C call
 
 
 def _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, transcript):
@@ -328,18 +329,22 @@ def _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, tran
     Lc = _coeffs_dev(L_tilde)
     rounds = P4Rounds(g_hat.ctx, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, Lc.ptr)
     try:
-        c = None
-        m = len(z_hat)
-        while m > 2:
-            a, b = rounds.round(c)
-            A = Ed25519Point.from_affine_bytes(a)
-            B = Ed25519Point.from_affine_bytes(b)
-            proof["A" + str(round_i)] = A
-            proof["B" + str(round_i)] = B
-            c = transcript.round_challenge(round_i, A, B, None, k, None, None)
-            m //= 2
-            round_i += 1
-        proof["z_prime"] = [gf(v) for v in rounds.finish(c)]
+        n_rounds = len(z_hat).bit_length() - 2
+        if NATIVE_CHAIN:
+            transcript.state, pairs, z_prime = rounds.run_compact(transcript.state, round_i, n_rounds)
+            for i, (a, b) in enumerate(pairs):
+                proof["A" + str(round_i + i)] = Ed25519Point.from_affine_bytes(a)
+                proof["B" + str(round_i + i)] = Ed25519Point.from_affine_bytes(b)
+        else:
+            c = None
+            for i in range(n_rounds):
+                a, b = rounds.round(c)
+                A, B = Ed25519Point.from_affine_bytes(a), Ed25519Point.from_affine_bytes(b)
+                proof["A" + str(round_i + i)] = A
+                proof["B" + str(round_i + i)] = B
+                c = transcript.round_challenge(round_i + i, A, B, None, k, None, None)
+            z_prime = rounds.finish(c)
+        proof["z_prime"] = [gf(v) for v in z_prime]
     finally:
         rounds.close()
     return proof
@@ -361,11 +366,12 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
             z_hat = pivot._as_device(z_hat)
         m = len(z_hat)
         half = m // 2
+        if tail_cs is None and NATIVE_ROUNDS and transcript.mode == "compact" and isinstance(z_hat, ScalarVector) \
+                and isinstance(L_tilde.coeffs, ScalarVector) and len(g_hat) == m and m >= 4 and m & (m - 1) == 0 \
+                and _tabulated(g_hat, k):
+            return _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, transcript)
         z_l, z_r, gamma_a, gamma_b = _round_prover_scalars(L_tilde, z_hat, half, gf)
         logger_cp.debug("Calculate A_i, B_i.")
-        if tail_cs is None and NATIVE_ROUNDS and transcript.mode == "compact" and isinstance(z_l, ScalarVector) \
-                and len(g_hat) == m and m >= 4 and m & (m - 1) == 0 and _tabulated(g_hat, k):
-            return _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, transcript)
         if tail_cs is None and transcript.mode == "compact" and isinstance(z_l, ScalarVector) \
                 and len(g_hat) == m and m >= 4 and (len(g_hat) <= TAIL_BASE or _tabulated(g_hat, k)):
             tail_cs = []

@@ -416,3 +416,87 @@ extern "C" int vmpc_p4_finish(vmpc_p4 *p, const uint8_t last_challenge[32], uint
     VMPC_HIP_CHECK(hipMemcpyAsync(out_z_prime, p->z[p->cur], 64, hipMemcpyDeviceToHost, p->ctx->stream));
     return vmpc_ctx_sync(p->ctx);
 }
+
+// ---- all rounds behind one call, compact transcript ------------------------------------------------------
+// verifiable_mpc_amd/compressed_pivot.py (_Transcript, mode "compact") chains the challenges as
+//     state_i = SHA-256(state_{i-1} || round index (4 bytes LE) || A_i (x||y) || B_i (x||y)),   c_i = state_i mod l
+// (state as a little-endian integer).  With that chain on this side of the C-ABI the rounds need no interpreter
+// between them: the host work per round is the pair's inversion and one 164-byte hash.
+namespace {
+struct host_sha256 {
+    uint32_t h[8];
+    static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    void block(const uint8_t *p) {
+        static const uint32_t K[64] = {
+            0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98,
+            0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786,
+            0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8,
+            0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+            0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819,
+            0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a,
+            0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7,
+            0xc67178f2};
+        uint32_t w[64];
+        for (int i = 0; i < 16; i++)
+            w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+        for (int i = 16; i < 64; i++) {
+            const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+            const uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; i++) {
+            const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    // digest of a message of `len` < 2^29 bytes
+    static void digest(const uint8_t *msg, size_t len, uint8_t out[32]) {
+        host_sha256 s;
+        static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
+                                       0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+        memcpy(s.h, iv, 32);
+        size_t off = 0;
+        for (; off + 64 <= len; off += 64) s.block(msg + off);
+        uint8_t tail[128] = {0};
+        const size_t rem = len - off;
+        memcpy(tail, msg + off, rem);
+        tail[rem] = 0x80;
+        const size_t blocks = rem < 56 ? 1 : 2;
+        const uint64_t bits = (uint64_t)len * 8;
+        for (int i = 0; i < 8; i++) tail[64 * blocks - 1 - i] = (uint8_t)(bits >> (8 * i));
+        for (size_t b = 0; b < blocks; b++) s.block(tail + 64 * b);
+        for (int i = 0; i < 8; i++) {
+            out[4 * i] = (uint8_t)(s.h[i] >> 24);
+            out[4 * i + 1] = (uint8_t)(s.h[i] >> 16);
+            out[4 * i + 2] = (uint8_t)(s.h[i] >> 8);
+            out[4 * i + 3] = (uint8_t)s.h[i];
+        }
+    }
+};
+}  // namespace
+
+// state: the chain value before the first round (in), after the last (out).  out_AB: log2(N) - 1 rounds x
+// (A_i || B_i) = 128 bytes each; out_z_prime: the two final residues.  The context must be fresh.
+extern "C" int vmpc_p4_run_compact(vmpc_p4 *p, uint8_t state[32], int first_round_index, uint8_t *out_AB,
+                                   uint8_t out_z_prime[64]) {
+    if (!p || !state || !out_AB || !out_z_prime || p->committed != 0 || first_round_index < 0) return VMPC_E_INVAL;
+    uint8_t challenge[32];
+    const int rounds = p->total_rounds;
+    for (int i = 0; i < rounds; i++) {
+        uint8_t *ab = out_AB + 128 * (size_t)i;
+        VMPC_CHECK(vmpc_p4_round(p, i ? challenge : nullptr, ab, ab + 64));
+        uint8_t msg[32 + 4 + 128];
+        memcpy(msg, state, 32);
+        const uint32_t ri = (uint32_t)(first_round_index + i);
+        for (int b = 0; b < 4; b++) msg[32 + b] = (uint8_t)(ri >> (8 * b));
+        memcpy(msg + 36, ab, 128);
+        host_sha256::digest(msg, sizeof msg, state);
+        uint32_t w[8];
+        memcpy(w, state, 32);
+        fr_store((uint32_t *)challenge, fr_from_u256(w));
+    }
+    return vmpc_p4_finish(p, challenge, out_z_prime);
+}
