@@ -271,6 +271,13 @@ int vmpc_sha256_chunks_dev(vmpc_ctx *ctx, const void *data, size_t nbytes, size_
 int vmpc_msm_table_fold_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
                             size_t n_cols, int k, const uint8_t *scalars, void *out_affine);
 
+/* the same fold, leaving the folded vector's own fixed-base table (out_rows rows, the n_extra device points
+ * extra_affine_points as its extras; size: vmpc_msm_table_bytes(n_cols >> k, n_extra, out_rows)) instead of the
+ * vector - what a prover that keeps committing to the folded generators wants (vmpc_p4_round uses it) */
+int vmpc_msm_table_fold_table_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                                  size_t n_cols, int k, const uint8_t *scalars, const void *extra_affine_points,
+                                  size_t n_extra, int out_rows, void *out_table);
+
 /* ---- device-resident Protocol-4 prover rounds (SURVEY.md 8b "vmpc_ctx_round") -----------------------------------
  * One halving round of compressed_pivot.py:29-86 per call: z_hat, L~ and the per-generator challenge products stay in
  * HBM for all log N rounds; a round folds z_hat and L~ with the previous challenge (:70-76), computes the two

@@ -546,6 +546,29 @@ def test_table_fold_equals_k_reference_folds(nat, ctx, rows, n_main, n_extra, k)
         assert [a[:2] for a in got] == want
 
 
+@pytest.mark.parametrize("rows,n_main,n_extra,k,out_rows", [(4, 63, 2, 3, 16), (8, 127, 1, 5, 4), (16, 256, 0, 2, 1),
+                                                            (1, 31, 1, 1, 8), (8, 1023, 2, 5, 16)])
+def test_table_fold_table_equals_fold_then_build(nat, ctx, rows, n_main, n_extra, k, out_rows):
+    """vmpc_msm_table_fold_table_dev (fold, Horner, row doublings and normalisation fused, a quad of lanes per
+    output) leaves byte for byte the table vmpc_msm_table_build_dev makes from vmpc_msm_table_fold_dev's vector."""
+    rng = random.Random(rows * 77 + n_main)
+    _, pts = make_points(rng, n_main + n_extra + 2)
+    dp = ctx.upload(aff_bytes(pts[:n_main]))
+    de = ctx.upload(aff_bytes(pts[n_main:n_main + n_extra])) if n_extra else None
+    table = ctx.msm_table_build(dp.ptr, n_main, de.ptr if de else None, n_extra, rows)
+    n_cols = 1 << ((n_main + n_extra).bit_length() - 1)
+    m_out = n_cols >> k
+    s = [rng.randrange(ELL) for _ in range(1 << k)]
+    new_extras = ctx.upload(aff_bytes(pts[-2:]))
+    folded = ctx.alloc(64 * m_out)
+    ctx.msm_table_fold(table.ptr, n_main, n_extra, rows, n_cols, s, folded.ptr)
+    want = ctx.msm_table_build(folded.ptr, m_out, new_extras.ptr, 2, out_rows)
+    got = ctx.msm_table_fold_table(table.ptr, n_main, n_extra, rows, n_cols, s, new_extras.ptr, 2, out_rows)
+    ctx.sync()
+    nbytes = out_rows * ((m_out + 2 + 7) // 8 * 8) * 128
+    assert ctx.download(got.ptr, nbytes).tobytes() == ctx.download(want.ptr, nbytes).tobytes()
+
+
 def test_table_fold_argument_checks(nat, ctx):
     rng = random.Random(5)
     _, pts = make_points(rng, 8)

@@ -36,7 +36,7 @@ SYMBOLS = [
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev", "vmpc_fr_tail_scalars_block_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
     "vmpc_bn256_validate_dev", "vmpc_bn256_fixed_base_dev",
-    "vmpc_msm_table_fold_dev", "vmpc_p4_create", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_run_compact", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
+    "vmpc_msm_table_fold_dev", "vmpc_msm_table_fold_table_dev", "vmpc_p4_create", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_run_compact", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
 ]
 
 
@@ -121,6 +121,7 @@ def load_library():
         "vmpc_bn256_validate_dev": (i32, [vp, i32, vp, sz, u64p]),
         "vmpc_bn256_fixed_base_dev": (i32, [vp, i32, vp, vp, sz, vp]),
         "vmpc_msm_table_fold_dev": (i32, [vp, vp, sz, sz, i32, sz, i32, vp, vp]),
+        "vmpc_msm_table_fold_table_dev": (i32, [vp, vp, sz, sz, i32, sz, i32, vp, vp, sz, i32, vp]),
         "vmpc_p4_create": (i32, [vp, vp, sz, sz, i32, i32, i32, vp, vp, vp, ctypes.POINTER(vp)]),
         "vmpc_p4_round": (i32, [vp, vp, vp, vp]),
         "vmpc_p4_finish": (i32, [vp, vp, vp]),
@@ -482,6 +483,19 @@ class Context:
         _check(self.lib.vmpc_msm_table_fold_dev(self.handle, ctypes.c_void_p(table_ptr), table_n, table_extra, rows,
                                                 n_cols, k, raw, ctypes.c_void_p(out_affine_ptr)),
                "vmpc_msm_table_fold_dev")
+
+    def msm_table_fold_table(self, table_ptr, table_n, table_extra, rows, n_cols, scalars, extras_ptr, n_extra, out_rows):
+        """msm_table_fold, leaving the folded vector's fixed-base table (a DeviceBuffer) instead of the vector"""
+        k = len(scalars).bit_length() - 1
+        assert len(scalars) == 1 << k
+        nbytes = ctypes.c_size_t()
+        _check(self.lib.vmpc_msm_table_bytes(n_cols >> k, n_extra, out_rows, ctypes.byref(nbytes)), "vmpc_msm_table_bytes")
+        out = DeviceBuffer(self, nbytes.value)
+        raw = ctypes.create_string_buffer(b"".join(scalar_to_bytes(v) for v in scalars), 32 << k)
+        _check(self.lib.vmpc_msm_table_fold_table_dev(self.handle, ctypes.c_void_p(table_ptr), table_n, table_extra, rows,
+                                                      n_cols, k, raw, ctypes.c_void_p(extras_ptr), n_extra, out_rows,
+                                                      ctypes.c_void_p(out.ptr)), "vmpc_msm_table_fold_table_dev")
+        return out
 
     def points_sum(self, ext_ptr, m, out_ext_ptr=None, out_affine_ptr=None):
         _check(self.lib.vmpc_points_sum_dev(self.handle, ctypes.c_void_p(ext_ptr), m,

@@ -83,6 +83,7 @@ extern "C" int vmpc_ctx_destroy(vmpc_ctx *ctx) {
     if (ctx->pin) VMPC_IGNORE(hipHostFree(ctx->pin));
     if (ctx->ws) VMPC_IGNORE(hipFree(ctx->ws));
     if (ctx->p4_pool) VMPC_IGNORE(hipFree(ctx->p4_pool));
+    if (ctx->p4_kblock) VMPC_IGNORE(hipFree(ctx->p4_kblock));
     if (ctx->d_status) VMPC_IGNORE(hipFree(ctx->d_status));
     if (ctx->own_stream) VMPC_IGNORE(hipStreamDestroy(ctx->stream));
     delete ctx;

@@ -62,6 +62,9 @@ struct vmpc_ctx {
     void *p4_pool = nullptr;
     size_t p4_pool_bytes = 0;
     bool p4_pool_busy = false;
+    void *p4_kblock = nullptr;         // the columns of k in a folded vector's table (a single-lane chain of 240
+    int p4_kblock_rows = 0;            // doublings, 0.7 ms): k belongs to the CRS, so they are made once
+    uint8_t p4_kblock_key[64] = {0};
     // profiling
     bool profile = false;
     std::vector<vmpc_stage> stages;

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "fr.h"
 #include "ptio.h"
+#include "quad.h"
 
 #define FJ_BLOCK 256
 #define FJ_WAVES (FJ_BLOCK / 64)
@@ -81,10 +82,62 @@ k_fold_jump_combine(const uint32_t *__restrict__ partial, size_t m_out, int O, u
     fe_st8(out_proj + 24 * j + 16, acc.Z);
 }
 
-extern "C" int vmpc_msm_table_fold_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
-                                       size_t n_cols, int k, const uint8_t *scalars /* 2^k x 32, host */,
-                                       void *out_affine) {
-    if (!ctx || !table || !scalars || !out_affine || k < 1 || k > 6 || n_cols < ((size_t)1 << k) ||
+// The same recombination for the prover's round context, which wants the folded vector's fixed-base TABLE
+// (msm.hip: row r = 2^(256 r / rows) * g', affine, niels form) and nothing else: Horner, the rows' doublings and
+// the normalisation in one kernel, a QUAD of lanes per output (quad.h: two dependent multiplications per point
+// operation instead of eight).  At 2^15 outputs these are 35 + 240 point operations in a row on an almost empty
+// chip - per-lane they took 0.11 + 0.12 (normalise) + 0.66 ms (k_msm_table_build), the time of two rounds.
+// One inversion per output covers all its rows, row 0 included (Montgomery's trick, as in k_msm_table_build):
+// pass 1 parks (X, Y, Z, Z_0 ... Z_r) in the row's own 128-byte slot, pass 2 (lane 0 of the quad) walks back.
+__global__ void __launch_bounds__(FJ_BLOCK)
+k_fold_jump_table(const uint32_t *__restrict__ partial, size_t m_out, int O, size_t stride, int rows,
+                  uint32_t *__restrict__ table) {
+    const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int q = threadIdx.x & 3;
+    if (j >= m_out) return;                                   // whole quads
+    const uint32_t *src = partial + EXT_WORDS * j * (size_t)O;
+    fe P = fe_ld(src + EXT_WORDS * (size_t)(O - 1) + FE_LIMBS * q);
+    for (int o = O - 2; o >= 0; o--) {
+        for (int d = 0; d < 4; d++) P = quadD_dbl(P, q);
+        P = quadD_add_cached(P, quadD_to_cached(fe_ld(src + EXT_WORDS * (size_t)o + FE_LIMBS * q), q), q);
+    }
+    const int dbl_per_row = 256 / rows;
+    fe run = quad_perm<0xaa>(P);                              // Z_0 on every lane
+    {
+        uint32_t *slot = table + NIELS_WORDS * j;
+        fe_st8(slot + 8 * q, quad_sel(P, run, q == 3));
+    }
+    for (int r = 1; r < rows; r++) {
+        for (int d = 0; d < dbl_per_row; d++) P = quadD_dbl(P, q);
+        run = fe_mul(run, quad_perm<0xaa>(P));
+        uint32_t *slot = table + NIELS_WORDS * ((size_t)r * stride + j);
+        fe_st8(slot + 8 * q, quad_sel(P, run, q == 3));
+    }
+    __threadfence_block();                                    // lane 0 reads what its three neighbours stored
+    if (q != 0) return;
+    fe inv = fe_inv(run);
+    for (int r = rows - 1; r >= 0; r--) {
+        uint32_t *slot = table + NIELS_WORDS * ((size_t)r * stride + j);
+        const fe Z = fe_ld8(slot + 16);
+        const fe prev = r > 0 ? fe_ld8(table + NIELS_WORDS * ((size_t)(r - 1) * stride + j) + 24) : fe_one();
+        const fe zi = fe_mul(inv, prev);
+        inv = fe_mul(inv, Z);
+        ge_aff b;
+        b.x = fe_canon(fe_mul(fe_ld8(slot), zi));
+        b.y = fe_canon(fe_mul(fe_ld8(slot + 8), zi));
+        niels_st_line(slot, ge_niels_from_affine(b));
+    }
+}
+
+int vmpc_msm_table_build_extras(vmpc_ctx *ctx, size_t n, const void *extra_affine_points, size_t n_extra, int rows,
+                                void *table);   // msm.hip
+
+// out_affine != NULL: the folded vector, affine.  Otherwise: its fixed-base table of `out_rows` rows with the
+// `out_extra` points (device, affine) as extras, written to `out_table`.
+static int table_fold(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows, size_t n_cols,
+                      int k, const uint8_t *scalars, void *out_affine, void *out_table, int out_rows,
+                      const void *out_extra, size_t out_n_extra, const void *extras_block = nullptr) {
+    if (!ctx || !table || !scalars || (!out_affine && !out_table) || k < 1 || k > 6 || n_cols < ((size_t)1 << k) ||
         (n_cols & (n_cols - 1)) || n_cols > table_n + table_extra ||
         !(rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16))
         return VMPC_E_INVAL;
@@ -137,8 +190,52 @@ extern "C" int vmpc_msm_table_fold_dev(vmpc_ctx *ctx, const void *table, size_t 
     k_fold_jump<<<grid, FJ_BLOCK, 0, ctx->stream>>>((const uint32_t *)table, stride, m_out, O, e1, d_sched, n_blocks,
                                                     d_partial);
     VMPC_KERNEL_CHECK();
-    k_fold_jump_combine<<<(unsigned)((m_out + FJ_BLOCK - 1) / FJ_BLOCK), FJ_BLOCK, 0, ctx->stream>>>(d_partial, m_out, O,
-                                                                                                 d_proj);
+    if (out_affine) {
+        k_fold_jump_combine<<<(unsigned)((m_out + FJ_BLOCK - 1) / FJ_BLOCK), FJ_BLOCK, 0, ctx->stream>>>(d_partial, m_out,
+                                                                                                     O, d_proj);
+        VMPC_KERNEL_CHECK();
+        return vmpc_normalize_launch(ctx, d_proj, m_out, out_affine);
+    }
+    const size_t out_stride = (m_out + out_n_extra + 7) & ~(size_t)7;
+    k_fold_jump_table<<<(unsigned)((4 * m_out + FJ_BLOCK - 1) / FJ_BLOCK), FJ_BLOCK, 0, ctx->stream>>>(
+        d_partial, m_out, O, out_stride, out_rows, (uint32_t *)out_table);
     VMPC_KERNEL_CHECK();
-    return vmpc_normalize_launch(ctx, d_proj, m_out, out_affine);
+    if (extras_block) {     // the extras' columns as an (out_stride - m_out)-column table of their own: copy, row by row
+        const size_t cols = out_stride - m_out;
+        VMPC_HIP_CHECK(hipMemcpy2DAsync((char *)out_table + m_out * NIELS_WORDS * 4, out_stride * NIELS_WORDS * 4,
+                                        extras_block, cols * NIELS_WORDS * 4, cols * NIELS_WORDS * 4, (size_t)out_rows,
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+        return VMPC_OK;
+    }
+    return vmpc_msm_table_build_extras(ctx, m_out, out_extra, out_n_extra, out_rows, out_table);
+}
+
+extern "C" int vmpc_msm_table_fold_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                                       size_t n_cols, int k, const uint8_t *scalars /* 2^k x 32, host */,
+                                       void *out_affine) {
+    if (!out_affine) return VMPC_E_INVAL;
+    return table_fold(ctx, table, table_n, table_extra, rows, n_cols, k, scalars, out_affine, nullptr, 0, nullptr, 0);
+}
+
+// prover.hip: the extras (k) do not change between proofs - their columns come prebuilt (a table over no
+// generators and the same extras: vmpc_msm_table_build_dev(ctx, NULL, 0, extras, n_extra, out_rows, block)),
+// valid when (n_cols >> k) is a multiple of 8 so that the block's columns line up
+int vmpc_table_fold_table_with_block(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                                     size_t n_cols, int k, const uint8_t *scalars, size_t n_extra, int out_rows,
+                                     const void *extras_block, void *out_table) {
+    return table_fold(ctx, table, table_n, table_extra, rows, n_cols, k, scalars, nullptr, out_table, out_rows, nullptr,
+                      n_extra, extras_block);
+}
+
+// The fold, then the folded vector's own table (rows x (n_cols >> k + n_extra) entries, vmpc_msm_table_bytes) in
+// one go - what the prover's round context continues on.  extra_affine_points: device, n_extra x 64 bytes.
+extern "C" int vmpc_msm_table_fold_table_dev(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra,
+                                             int rows, size_t n_cols, int k, const uint8_t *scalars,
+                                             const void *extra_affine_points, size_t n_extra, int out_rows,
+                                             void *out_table) {
+    if (!out_table || (n_extra && !extra_affine_points) ||
+        !(out_rows == 1 || out_rows == 2 || out_rows == 4 || out_rows == 8 || out_rows == 16))
+        return VMPC_E_INVAL;
+    return table_fold(ctx, table, table_n, table_extra, rows, n_cols, k, scalars, nullptr, out_table, out_rows,
+                      extra_affine_points, n_extra);
 }

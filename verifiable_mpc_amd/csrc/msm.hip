@@ -221,38 +221,6 @@ k_msm_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ 
 // lane 3: E*H = T3 - two-way operand selections, and the products land where the next operation reads
 // them.  Sums stay lazy as in ge25519.h (only F is carried).  448 instructions per doubling instead
 // of 733 for the replicated form with four-way picks and carried sums.
-__device__ __forceinline__ fe quadD_level2(const fe &E, const fe &F, const fe &G, const fe &H, int q) {
-    fe u = quad_sel(G, E, q == 0 || q == 3);
-    fe v = quad_sel(H, F, (q & 1) == 0);
-    return fe_mul(u, v);
-}
-
-__device__ __forceinline__ fe quadD_dbl(const fe &P, int q) {
-    fe x = quad_perm<0x00>(P), y = quad_perm<0x55>(P);
-    fe in = quad_sel(P, fe_add_lazy(x, y), q == 3);          // X, Y, Z, X+Y
-    fe sq = fe_sqr(in);
-    fe A = quad_perm<0x00>(sq), B = quad_perm<0x55>(sq), C = quad_perm<0xaa>(sq), S = quad_perm<0xff>(sq);
-    fe H = fe_add_lazy(A, B);
-    fe E = fe_sub_lazy(H, S);
-    fe G = fe_sub_lazy(A, B);
-    fe F = fe_add(fe_add_lazy(C, C), G);                      // carried
-    return quadD_level2(E, F, G, H, q);
-}
-
-// P += r, lane q given its own first-level partner v_q of r = (Y-X, Y+X, 2d*T, 2*Z) (all reduced)
-__device__ __forceinline__ fe quadD_add_cached(const fe &P, const fe &vq, int q) {
-    fe x = quad_perm<0x00>(P);
-    fe t = quad_perm<0xb5>(P);                                // lanes: Y, Y, T, Z
-    fe u = quad_sel(quad_sel(t, fe_add_lazy(t, x), q == 1), fe_sub_lazy(t, x), q == 0);
-    fe prod = fe_mul(u, vq);                                  // A, B, C, D
-    fe A = quad_perm<0x00>(prod), B = quad_perm<0x55>(prod), C = quad_perm<0xaa>(prod), D = quad_perm<0xff>(prod);
-    fe E = fe_sub_lazy(B, A);
-    fe H = fe_add_lazy(B, A);
-    fe F = fe_sub(D, C);                                      // carried
-    fe G = fe_add_lazy(D, C);
-    return quadD_level2(E, F, G, H, q);
-}
-
 __global__ void __launch_bounds__(64)
 k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
             uint32_t *__restrict__ out_ext, uint32_t *__restrict__ out_aff) {
@@ -508,8 +476,8 @@ static bool msm_table_rows_ok(int rows) { return rows == 1 || rows == 2 || rows 
 
 __global__ void __launch_bounds__(MSM_BLOCK, 2)
 k_msm_table_build(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__restrict__ aff_extra,
-                  size_t n_total, size_t stride, int rows, uint32_t *__restrict__ table) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                  size_t n_total, size_t stride, int rows, size_t col_begin, uint32_t *__restrict__ table) {
+    size_t i = col_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // columns [col_begin, stride)
     if (i >= stride) return;
     if (i >= n_total) {     // padding columns are never referenced (their digits are zero); keep them defined
         ge_niels z;
@@ -570,8 +538,18 @@ extern "C" int vmpc_msm_table_build_dev(vmpc_ctx *ctx, const void *affine_points
     const size_t stride = msm_table_stride(n + n_extra);
     vmpc_stage_scope s(ctx, "msm_table_build");
     k_msm_table_build<<<(unsigned)((stride + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
-        (const uint32_t *)affine_points, n, (const uint32_t *)extra_affine_points, n + n_extra, stride, rows,
+        (const uint32_t *)affine_points, n, (const uint32_t *)extra_affine_points, n + n_extra, stride, rows, 0,
         (uint32_t *)table);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+// the extras' columns (and the padding) of a table whose generator columns another kernel fills (fold_jump.hip)
+int vmpc_msm_table_build_extras(vmpc_ctx *ctx, size_t n, const void *extra_affine_points, size_t n_extra, int rows,
+                                void *table) {
+    const size_t stride = msm_table_stride(n + n_extra);
+    k_msm_table_build<<<(unsigned)((stride - n + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
+        nullptr, n, (const uint32_t *)extra_affine_points, n + n_extra, stride, rows, n, (uint32_t *)table);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }

@@ -130,6 +130,10 @@ k_p4_extras(const uint32_t *__restrict__ partials, int n_partials, const uint32_
     }
 }
 
+int vmpc_table_fold_table_with_block(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                                     size_t n_cols, int k, const uint8_t *scalars, size_t n_extra, int out_rows,
+                                     const void *extras_block, void *out_table);   // fold_jump.hip
+
 struct vmpc_p4 {
     vmpc_ctx *ctx;
     const void *table;
@@ -151,6 +155,7 @@ struct vmpc_p4 {
     char *arena;
     bool arena_pooled;
     std::vector<char *> extra;        // buffers of second and later jumps
+    uint8_t k_host[64];
 };
 
 // All device buffers of a context are carved from one arena that stays with the vmpc_ctx between proofs
@@ -166,10 +171,10 @@ static void p4_release(vmpc_p4 *p) {
     delete p;
 }
 
-// rows of the folded vector's table: as PointVector.precompute picks them (512 MiB at most)
+// rows of the folded vector's table: as PointVector.precompute picks them (1 GiB at most)
 static int p4_jump_rows(size_t m_out) {
     int rows = 16;
-    while (rows > 1 && (size_t)rows * 128 * (m_out + 1) > ((size_t)512 << 20)) rows /= 2;
+    while (rows > 1 && (size_t)rows * 128 * (m_out + 1) > ((size_t)1 << 30)) rows /= 2;
     return rows;
 }
 
@@ -255,6 +260,7 @@ extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, 
             off += p4_align(sizes[i]);
         }
     }
+    memcpy(p->k_host, k_affine, 64);
     int rc = vmpc_memcpy_h2d(ctx, p->k_aff, k_affine, 64);
     if (rc == VMPC_OK) rc = vmpc_memcpy_d2d(ctx, p->z[0], z_hat, 32 * N);
     if (rc == VMPC_OK) rc = vmpc_memcpy_d2d(ctx, p->L[0], L_tilde, 32 * N);
@@ -332,8 +338,22 @@ static int p4_jump(vmpc_p4 *p) {
         if (hipMalloc((void **)&t, bytes) != hipSuccess) return VMPC_E_NOMEM;
         p->extra.push_back(t);
     }
-    VMPC_CHECK(vmpc_msm_table_fold_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, N, k, s.data(), g));
-    VMPC_CHECK(vmpc_msm_table_build_dev(ctx, g, m_out, p->k_aff, 1, rows, t));
+    (void)g;
+    if (m_out % 8 == 0) {
+        // k's columns of the new table: the same for every proof over this CRS
+        if (!ctx->p4_kblock || ctx->p4_kblock_rows != rows || memcmp(ctx->p4_kblock_key, p->k_host, 64) != 0) {
+            if (!ctx->p4_kblock && hipMalloc(&ctx->p4_kblock, (size_t)16 * 8 * 128) != hipSuccess) return VMPC_E_NOMEM;
+            ctx->p4_kblock_rows = 0;
+            VMPC_CHECK(vmpc_msm_table_build_dev(ctx, nullptr, 0, p->k_aff, 1, rows, ctx->p4_kblock));
+            ctx->p4_kblock_rows = rows;
+            memcpy(ctx->p4_kblock_key, p->k_host, 64);
+        }
+        VMPC_CHECK(vmpc_table_fold_table_with_block(ctx, p->table, p->table_n, p->table_extra, p->rows, N, k, s.data(), 1,
+                                                    rows, ctx->p4_kblock, t));
+    } else {
+        VMPC_CHECK(vmpc_msm_table_fold_table_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, N, k, s.data(),
+                                                 p->k_aff, 1, rows, t));
+    }
     p->table = t;
     p->table_n = m_out;
     p->table_extra = 1;

@@ -192,7 +192,9 @@ class ScalarVector:
         return "[" + body[:-2] + "]"
 
 
-TABLE_BUDGET_BYTES = 512 << 20      # twice the MI355X Infinity Cache: measured optimum at 2^20 generators
+# Measured at 2^20 generators with the round-context prover (5 rounds + one multi-round fold on this table, the
+# rest on the folded vector's own): 24.2 / 21.3 / 20.7 / 20.0 / 21.0 ms per proof for 1 / 2 / 4 / 8 / 16 rows.
+TABLE_BUDGET_BYTES = 1 << 30
 
 
 class FixedBaseTable:
@@ -353,10 +355,10 @@ class PointVector:
         the `extras` (the commitment bases h, k of the CRS).  Commitments over this vector or a
         prefix of it, with one of `extras` as base point, then need no point preparation and only
         (16/rows - 1) * 16 doublings of window recombination.  `rows` in {1, 2, 4, 8, 16} (128 bytes
-        of HBM per generator and row); by default the largest with a table of at most 512 MiB: the
-        bucket stage gathers table entries at random, and past the Infinity Cache that costs what
+        of HBM per generator and row); by default the largest with a table of at most 1 GiB: the
+        bucket stage gathers table entries at random, and far past the Infinity Cache that costs what
         the shorter recombination saves (at 2^20 generators every choice is within 3 % for one
-        commitment; 4 rows is the best for the fold-free prover)."""
+        commitment; 8 rows is the best for the prover, see TABLE_BUDGET_BYTES)."""
         extras = list(extras)
         if rows is None and os.environ.get("VMPC_TABLE_ROWS"):
             rows = int(os.environ["VMPC_TABLE_ROWS"])          # tuning knob
