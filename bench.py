@@ -182,7 +182,9 @@ def prove_timing(vm, ctx, n_pow, rng):
         out[f"roofline_{mode}"] = {
             "bound": "hbm", "algorithmic_bytes": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9,
             "peak_GBps": HBM_PEAK_GBPS, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "dominant": ("k_msm_bucket: 2 N-term table commitments per round (profiles/*_prove_compact_kernel_stats.csv)"
+            "dominant": ("k_msm_bucket (the announcement and 5 rounds of two N-term table commitments) and k_fold_jump "
+                         "(those 5 rounds' generator folds in one pass); the other 14 rounds run on the folded "
+                         "vector's table (profiles/*_prove_compact_kernel_stats.csv)"
                          if mode == "compact" else
                          "host SHA-256 of ~1 GB of decimal pre-image text on one core (~85 % of the wall time); on "
                          "the GPU k_fold, the exact replay of (g_l ** c) * g_r "
