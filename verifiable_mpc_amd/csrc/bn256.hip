@@ -266,7 +266,7 @@ static int bn_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uint
         vmpc_stage_scope s(ctx, "bn_bucket");
         gk_bucket<C><<<(unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
             entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
-            MSM_SEG << p.seg_shift, w.buckets, w.seg_partial);
+            (int)msm_seg_len(p), w.buckets, w.seg_partial);
         VMPC_KERNEL_CHECK();
         gk_finish_light<C, F><<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg,
                                                                       w.seg_starts, w.seg_partial, p.nb1,

@@ -386,7 +386,7 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
             grid = (unsigned)(ctx->bucket_wgs_per_cu * ctx->cu_count);
         k_msm_bucket<<<grid, MSM_BLOCK, 0, st>>>(
             entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
-            MSM_SEG << p.seg_shift, w.buckets, w.seg_partial);
+            (int)msm_seg_len(p), w.buckets, w.seg_partial);
         VMPC_KERNEL_CHECK();
     }
     {

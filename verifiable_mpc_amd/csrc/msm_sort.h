@@ -20,7 +20,7 @@ struct msm_plan {
     size_t n_main, n_extra, n_total;
     int scalar_bits;    // scalars are < 2^scalar_bits
     int c, W, nb, nb1;  // nb = 2^(c-1) buckets per window, nb1 = nb + 1 (bucket 0 unused)
-    int seg_shift;      // segments of MSM_SEG << seg_shift entries
+    int seg_shift;      // segments of MSM_SEG << seg_shift entries (negative: MSM_SEG >> -seg_shift), msm_seg_len()
     int LB;             // fine bits: bucket b = coarse << LB | fine, 2^LB <= 512 fine buckets per coarse bin
     int NC;             // coarse bins per window = nb >> LB
     int J;              // chunks of 8192 terms per digit row
@@ -35,6 +35,8 @@ struct msm_plan {
     int chunk_len;      // buckets per chunk (power of two)
     int red_blocks;     // blocks per window in the reduce kernel
 };
+inline size_t msm_seg_len(const msm_plan &p) { return (size_t)1 << (MSM_SEG_LOG2 + p.seg_shift); }
+
 
 struct msm_ws {
     uint32_t *entries;      // prepared points, entry_bytes each

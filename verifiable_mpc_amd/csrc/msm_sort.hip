@@ -29,6 +29,12 @@
 #define SORT_WAVES (SORT_BLOCK / 64)
 #define SORT_FINE_CAP 12288    // entries of a coarse bin staged in LDS (48 KiB): 1.5 x the 8 K target
 
+// length class of a bucket's last, partial segment: 1 .. MSM_SEG - 1 in units of 2^seg_shift entries (segments of
+// more than MSM_SEG entries) or of one entry (seg_shift <= 0: segments of MSM_SEG >> -seg_shift entries)
+__device__ __forceinline__ uint32_t msm_seg_class(uint32_t rem, int seg_shift) {
+    return seg_shift > 0 ? (rem + (1u << seg_shift) - 1u) >> seg_shift : rem;
+}
+
 __device__ __forceinline__ void load_u32x8(uint32_t dst[8], const uint32_t *src) {
     const uint4 *p = reinterpret_cast<const uint4 *>(src);
     uint4 a = p[0], b = p[1];
@@ -309,14 +315,14 @@ k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase,
             starts[(size_t)w * nb1] = lo;
             nseg[(size_t)w * nb1] = 0;
         }
-        const uint32_t seg_log = MSM_SEG_LOG2 + seg_shift, unit_round = (1u << seg_shift) - 1u;
+        const uint32_t seg_log = (uint32_t)(MSM_SEG_LOG2 + seg_shift);
         const uint32_t full = v >> seg_log, rem = v & ((1u << seg_log) - 1u);
         const uint32_t ns = full + (rem ? 1u : 0u);
         uint32_t my_heavy = 0, my_seg = 0;
         if (threadIdx.x < (unsigned)NF) {
             nseg[ci] = ns;
             if (full) atomicAdd(&lh[MSM_SEG], full);
-            if (rem) atomicAdd(&lh[(rem + unit_round) >> seg_shift], 1u);
+            if (rem) atomicAdd(&lh[msm_seg_class(rem, seg_shift)], 1u);
             if (ns > 1) {
                 my_heavy = atomicAdd(&heavy_n, 1u);
                 my_seg = atomicAdd(&heavy_segs, ns);
@@ -494,7 +500,7 @@ k_msm_plan2(const uint32_t *__restrict__ counts, int NC, int W, int NF, int top_
             int seg_shift,
             const uint32_t *__restrict__ class_base, const uint32_t *__restrict__ block_rank,
             uint2 *__restrict__ tasks) {
-    const uint32_t seg_log = MSM_SEG_LOG2 + seg_shift, unit_round = (1u << seg_shift) - 1u;
+    const uint32_t seg_log = (uint32_t)(MSM_SEG_LOG2 + seg_shift);
     __shared__ uint32_t cur[MSM_SEG + 1], first[MSM_SEG + 1];
     const uint32_t block = blockIdx.x;
     const int w = block / NC, cb = block % NC;
@@ -510,7 +516,7 @@ k_msm_plan2(const uint32_t *__restrict__ counts, int NC, int W, int NF, int top_
     uint32_t cnt = counts[ci];
     uint32_t full = cnt >> seg_log, rem = cnt & ((1u << seg_log) - 1u);
     if (rem) {
-        uint32_t bin = (rem + unit_round) >> seg_shift;
+        uint32_t bin = msm_seg_class(rem, seg_shift);
         uint32_t r = atomicAdd(&cur[bin], 1u);
         tasks[first[bin] + r] = make_uint2((uint32_t)ci, full);
     }
@@ -623,6 +629,12 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
     // 160-byte partial sums) costs 14 %
     p.seg_shift = 0;
     while (p.seg_shift < 4 && (((size_t)MSM_SEG << p.seg_shift) << 18) < (size_t)p.W * p.n_total) p.seg_shift++;
+    // ... and SHORTER ones for short inputs: with fewer tasks than lanes the stage lasts as long as its longest
+    // chain, i.e. the fullest bucket (Poisson tail: 22 entries at a mean of 8 = 93 us in the prover's late
+    // rounds).  Halving the segments keeps >= 2^18 tasks down to 8-entry segments; the partial sums of split
+    // buckets go through the finish kernels.
+    while (p.seg_shift > ctx->seg_shift_min && (((size_t)MSM_SEG >> -(p.seg_shift - 1)) << 18) >= (size_t)p.W * p.n_total)
+        p.seg_shift--;
     // reduce: chunk-lanes per window (chunk length a power of two): the per-lane work is a
     // dependency chain, so shorter chunks on more lanes cut the latency
     // (with few windows - fixed-base tables - more chunk-lanes per window keep the same ~64 K lanes busy)
@@ -655,7 +667,7 @@ void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, si
     // segment planning: at most M/SEG full segments plus one remainder per non-empty bucket
     size_t m_max = (size_t)p.W * p.n_total;
     size_t nonempty_max = m_max < (size_t)p.W * p.nb ? m_max : (size_t)p.W * p.nb;
-    w.t_max = m_max / ((size_t)MSM_SEG << p.seg_shift) + nonempty_max;
+    w.t_max = m_max / msm_seg_len(p) + nonempty_max;
     w.plan_blocks = (uint32_t)(p.W * p.NC);                  // one block of the task table per (window, coarse bin)
     size_t hist_n = (size_t)MSM_SEG * w.plan_blocks;
     w.block_hist = (uint32_t *)take(hist_n * 4);              // [block][length class]: the block's first rank in the cell
