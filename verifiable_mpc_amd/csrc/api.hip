@@ -64,6 +64,8 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
     if (bw && atoi(bw) >= 0) c->bucket_wgs_per_cu = atoi(bw);
     const char *sf = getenv("VMPC_SORT_FINE_BITS");   // tuning knob: fine bits of the two-level bucket sort
     if (sf && atoi(sf) >= 0) c->sort_fine_bits = atoi(sf);
+    const char *rc = getenv("VMPC_REDUCE_MAX_CHUNKS");
+    if (rc && atoi(rc) >= 256 && atoi(rc) <= 32768) c->reduce_max_chunks = atoi(rc);
     const char *ss = getenv("VMPC_SEG_SHIFT_MIN");
     if (ss && atoi(ss) <= 0 && atoi(ss) >= -5) c->seg_shift_min = atoi(ss);
     *out = c;

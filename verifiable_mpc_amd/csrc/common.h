@@ -51,6 +51,7 @@ struct vmpc_ctx {
     uint32_t *d_status = nullptr;
     int window_override = 0;
     int bucket_wgs_per_cu = 0;     // > 0: persistent bucket kernel with this many 256-thread workgroups per CU
+    int reduce_max_chunks = 32768; // most chunk-lanes per bucket set in the bucket reduction (msm_sort.hip)
     int seg_shift_min = -3;        // shortest bucket segments the plan may choose: 64 >> 3 entries (msm_sort.hip)
     int sort_fine_bits = -1;       // fine bits of the two-level bucket sort; -1 = automatic (msm_sort.hip)
     int cu_count = 256;

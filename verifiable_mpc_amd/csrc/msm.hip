@@ -128,6 +128,7 @@ k_msm_bucket_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__r
                     const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
                     const uint32_t *__restrict__ partial, int nb1, uint32_t *__restrict__ buckets) {
     __shared__ uint32_t lds[MSM_BLOCK * EXT_WORDS];
+    if (ctrl[4] == 0) return;                      // no heavily split bucket: nothing for the workgroup trees
     const uint32_t n_heavy = ctrl[0];
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         uint32_t ci = heavy_list[h];

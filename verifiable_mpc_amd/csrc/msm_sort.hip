@@ -130,7 +130,8 @@ k_sort_hist1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, i
     extern __shared__ uint32_t lds[];
     const int j = blockIdx.x, w = blockIdx.y;
     if (w % period == top_row) LB = LB_top;      // rows of a batch repeat with period = windows per commitment
-    // ctrl[0] = #split buckets, [1] = #tasks, [2] = #partial sums, [16 ..) = tasks per (length class, window)
+    // ctrl[0] = #split buckets, [1] = #tasks, [2] = #partial sums, [3] = #big bins, [4] = #buckets split into more
+    // than MSM_FINISH_SERIAL segments, [16 ..) = tasks per (length class, window)
     if (j == 0 && w == 0)
         for (int i = threadIdx.x; i < 16 + MSM_SEG * (int)gridDim.y; i += SORT_BLOCK) ctrl[i] = 0;
     for (int b = threadIdx.x; b < NC; b += SORT_BLOCK) lds[b] = 0;
@@ -326,6 +327,7 @@ k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase,
             if (ns > 1) {
                 my_heavy = atomicAdd(&heavy_n, 1u);
                 my_seg = atomicAdd(&heavy_segs, ns);
+                if (ns > MSM_FINISH_SERIAL) atomicAdd(&ctrl[4], 1u);     // rare: skewed scalars only
             }
         }
         __syncthreads();
@@ -639,7 +641,7 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
     // dependency chain, so shorter chunks on more lanes cut the latency
     // (with few windows - fixed-base tables - more chunk-lanes per window keep the same ~64 K lanes busy)
     int chunks = MSM_REDUCE_CHUNKS;
-    while (chunks * 2 * p.W <= MSM_REDUCE_CHUNKS * 16 && chunks * 2 <= 32768) chunks *= 2;
+    while (chunks * 2 * p.W <= MSM_REDUCE_CHUNKS * 16 && chunks * 2 <= ctx->reduce_max_chunks) chunks *= 2;
     if (chunks > p.nb) chunks = p.nb;
     p.chunks = chunks;
     p.chunk_len = p.nb / chunks;
