@@ -132,6 +132,13 @@ k_fold_jump_table(const uint32_t *__restrict__ partial, size_t m_out, int O, siz
 int vmpc_msm_table_build_extras(vmpc_ctx *ctx, size_t n, const void *extra_affine_points, size_t n_extra, int rows,
                                 void *table);   // msm.hip
 
+// row blockIdx.y of a narrow table (row_vecs 16-byte vectors per row) into the same row of a wide one
+__global__ void k_copy_columns(const uint4 *__restrict__ src, size_t row_vecs, uint4 *__restrict__ dst,
+                               size_t dst_row_vecs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < row_vecs) dst[(size_t)blockIdx.y * dst_row_vecs + i] = src[(size_t)blockIdx.y * row_vecs + i];
+}
+
 // out_affine != NULL: the folded vector, affine.  Otherwise: its fixed-base table of `out_rows` rows with the
 // `out_extra` points (device, affine) as extras, written to `out_table`.
 static int table_fold(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows, size_t n_cols,
@@ -202,9 +209,10 @@ static int table_fold(vmpc_ctx *ctx, const void *table, size_t table_n, size_t t
     VMPC_KERNEL_CHECK();
     if (extras_block) {     // the extras' columns as an (out_stride - m_out)-column table of their own: copy, row by row
         const size_t cols = out_stride - m_out;
-        VMPC_HIP_CHECK(hipMemcpy2DAsync((char *)out_table + m_out * NIELS_WORDS * 4, out_stride * NIELS_WORDS * 4,
-                                        extras_block, cols * NIELS_WORDS * 4, cols * NIELS_WORDS * 4, (size_t)out_rows,
-                                        hipMemcpyDeviceToDevice, ctx->stream));
+        k_copy_columns<<<dim3((unsigned)((cols * NIELS_WORDS / 4 + 63) / 64), (unsigned)out_rows), 64, 0, ctx->stream>>>(
+            (const uint4 *)extras_block, cols * NIELS_WORDS / 4, (uint4 *)out_table + m_out * NIELS_WORDS / 4,
+            out_stride * NIELS_WORDS / 4);
+        VMPC_KERNEL_CHECK();
         return VMPC_OK;
     }
     return vmpc_msm_table_build_extras(ctx, m_out, out_extra, out_n_extra, out_rows, out_table);
