@@ -158,18 +158,27 @@ extern "C" int vmpc_ctx_set_window(vmpc_ctx *ctx, int c_bits) {
     return VMPC_OK;
 }
 
+int vmpc_pinned_reserve(vmpc_ctx *ctx, size_t bytes) {
+    if (ctx->pin && bytes <= ctx->pin_bytes) return VMPC_OK;
+    // growing: nothing may still be using the old block (its last H2D is awaited by the caller through pin_event;
+    // pin_out is only written by kernels whose results the host has already consumed)
+    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->pin) VMPC_IGNORE(hipHostFree(ctx->pin));
+    ctx->pin = ctx->pin_out = ctx->pin_out_dev = nullptr;
+    ctx->pin_bytes = 0;
+    const size_t want = ((bytes > 65536 ? bytes : 65536) + 4095) & ~(size_t)4095;
+    VMPC_HIP_CHECK(hipHostMalloc(&ctx->pin, want + 4096, hipHostMallocDefault));
+    ctx->pin_bytes = want;
+    ctx->pin_out = (char *)ctx->pin + want;
+    VMPC_HIP_CHECK(hipHostGetDevicePointer(&ctx->pin_out_dev, ctx->pin_out, 0));
+    return VMPC_OK;
+}
+
 int vmpc_stage_h2d(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return VMPC_OK;
     if (!ctx->pin_event) VMPC_HIP_CHECK(hipEventCreateWithFlags(&ctx->pin_event, hipEventDisableTiming));
     else VMPC_HIP_CHECK(hipEventSynchronize(ctx->pin_event));     // the previous block has left the buffer
-    if (bytes > ctx->pin_bytes) {
-        if (ctx->pin) VMPC_IGNORE(hipHostFree(ctx->pin));
-        ctx->pin = nullptr;
-        ctx->pin_bytes = 0;
-        const size_t want = (bytes + 65535) & ~(size_t)65535;
-        VMPC_HIP_CHECK(hipHostMalloc(&ctx->pin, want, hipHostMallocDefault));
-        ctx->pin_bytes = want;
-    }
+    VMPC_CHECK(vmpc_pinned_reserve(ctx, bytes));
     memcpy(ctx->pin, src, bytes);
     VMPC_HIP_CHECK(hipMemcpyAsync(dst, ctx->pin, bytes, hipMemcpyHostToDevice, ctx->stream));
     VMPC_HIP_CHECK(hipEventRecord(ctx->pin_event, ctx->stream));

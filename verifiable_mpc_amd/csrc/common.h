@@ -60,6 +60,8 @@ struct vmpc_ctx {
     void *pin = nullptr;
     size_t pin_bytes = 0;
     hipEvent_t pin_event = nullptr;
+    void *pin_out = nullptr;       // 4 KiB of pinned, device-mapped host memory behind `pin` (same allocation): small
+    void *pin_out_dev = nullptr;   // results a kernel writes for the host every round (prover.hip); its device address
     // arena of the prover's round context, kept between proofs (prover.hip)
     void *p4_pool = nullptr;
     size_t p4_pool_bytes = 0;
@@ -83,6 +85,10 @@ inline void *vmpc_ws_take(vmpc_ctx *ctx, size_t bytes) {
 }
 // enqueue a copy of a small host block (schedules, parameter tables) to `dst`; `src` may be freed on return
 int vmpc_stage_h2d(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes);
+// make sure ctx->pin holds `bytes` (>= 64 KiB) and ctx->pin_out / pin_out_dev exist.  ONE allocation for both:
+// on this stack a second hipHostMalloc was seen to drop the GPU mapping of an earlier 4-KiB one (memory access
+// fault on the first kernel write after it).
+int vmpc_pinned_reserve(vmpc_ctx *ctx, size_t bytes);
 inline size_t vmpc_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // profiling helpers: bracket a kernel launch with events when ctx->profile is on

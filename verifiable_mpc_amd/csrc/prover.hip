@@ -418,10 +418,12 @@ extern "C" int vmpc_p4_round(vmpc_p4 *p, const uint8_t prev_challenge[32], uint8
         VMPC_KERNEL_CHECK();
     }
     const void *sc[2] = {p->va, p->vb}, *ex[2] = {p->ex_a, p->ex_b};
+    // the recombination kernel writes the 2 x 128 bytes straight into pinned host memory: no copy command at all
+    // (a pageable destination costs a staged copy, 20 us a round)
+    VMPC_CHECK(vmpc_pinned_reserve(ctx, 0));
     VMPC_CHECK(vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
-                                        p->out, nullptr));
-    uint8_t ext[256];
-    VMPC_HIP_CHECK(hipMemcpyAsync(ext, p->out, 256, hipMemcpyDeviceToHost, st));
+                                        ctx->pin_out_dev, nullptr));
+    const uint8_t *ext = (const uint8_t *)ctx->pin_out;
     VMPC_CHECK(vmpc_ctx_sync(ctx));
     p->committed++;
     p4_affine_pair(ext, out_A, out_B);
