@@ -114,13 +114,17 @@ extern "C" int vmpc_ctx_set_stream(vmpc_ctx *ctx, void *hip_stream) {
 extern "C" int vmpc_ctx_sync(vmpc_ctx *ctx) {
     if (!ctx) return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
-    uint32_t st[VMPC_ST_WORDS];
-    VMPC_HIP_CHECK(hipMemcpyAsync(st, ctx->d_status, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    // the status words land in pinned memory (behind the 256 bytes kernels write there): a pageable destination
+    // would make this a staged copy, 20 us on every synchronisation
+    VMPC_CHECK(vmpc_pinned_reserve(ctx, 0));
+    volatile uint32_t *st = (volatile uint32_t *)((char *)ctx->pin_out + 2048);
+    VMPC_HIP_CHECK(hipMemcpyAsync((void *)st, ctx->d_status, VMPC_ST_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                  ctx->stream));
     VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (st[VMPC_ST_NONCANON]) {
         snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "%u non-canonical scalar(s) (>= l) seen on device",
-                 st[VMPC_ST_NONCANON]);
-        VMPC_HIP_CHECK(hipMemsetAsync(ctx->d_status, 0, sizeof st, ctx->stream));
+                 (unsigned)st[VMPC_ST_NONCANON]);
+        VMPC_HIP_CHECK(hipMemsetAsync(ctx->d_status, 0, VMPC_ST_WORDS * sizeof(uint32_t), ctx->stream));
         VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         return VMPC_E_NONCANON;
     }
