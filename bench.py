@@ -171,10 +171,11 @@ def prove_timing(vm, ctx, n_pow, rng):
         out[f"prove_ms_{mode}_first_call"] = runs[0]
         out[f"prove_ms_{mode}"] = sorted(runs[1:])[1]            # median of the three steady runs
         out[f"prove_ms_{mode}_min"] = min(runs[1:])
-        t0 = time.perf_counter()
-        ok = vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, proof, gf, transcript=mode)
-        out[f"verify_ms_{mode}"] = (time.perf_counter() - t0) * 1e3
-        assert ok is True
+        for key in (f"verify_ms_{mode}_first_call", f"verify_ms_{mode}"):     # second call: contexts and buffers exist
+            t0 = time.perf_counter()
+            ok = vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, proof, gf, transcript=mode)
+            out[key] = (time.perf_counter() - t0) * 1e3
+            assert ok is True
         # a Protocol-5 prove moves ~768 * N algorithmic bytes (two N-term commitments + per round
         # two half-size commitments, the fold and the scalar folds); Fiat-Shamir text excluded
         alg = 768 * N

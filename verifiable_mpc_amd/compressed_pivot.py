@@ -68,39 +68,61 @@ def _same_residue(a, b, order):
     return (pivot._residue(a) - pivot._residue(b)) % order == 0
 
 
+class _GroupCheck:
+    """The order-l ladder of _valid_group_elements in flight on a side stream; result() joins it."""
+
+    def __init__(self, verdict=None, ctx=None, out=None, raw=None, keepalive=None):
+        self.verdict, self.ctx, self.out, self.raw, self.keepalive = verdict, ctx, out, raw, keepalive
+
+    def result(self):
+        if self.verdict is None:
+            from .groups import P as FIELD_P
+            raw, n = self.raw, len(self.raw) // 64
+            got = self.ctx.download(self.out.ptr, 64 * n).tobytes()        # synchronises the side stream
+            self.verdict = True
+            for i in range(n):
+                x = int.from_bytes(raw[64 * i:64 * i + 32], "little")
+                want = ((FIELD_P - x) % FIELD_P).to_bytes(32, "little") + raw[64 * i + 32:64 * i + 64]
+                if got[64 * i:64 * i + 64] != want:
+                    self.verdict = False
+                    break
+            self.keepalive = self.out = None
+        return self.verdict
+
+
+def _valid_group_elements_begin(points):
+    """_valid_group_elements with the 253-step ladder (0.9 ms of single-lane latency for the 40 points of a
+    2^20 proof) left running on a side stream: the caller goes on and joins the verdict before it accepts."""
+    import numpy as np
+    from .device import get_aux_context
+    from .groups import ORDER
+    try:
+        pts = [_pt(p) for p in points]
+        raw = b"".join(p.to_affine_bytes() for p in pts)
+    except Exception:
+        return _GroupCheck(False)
+    n = len(pts)
+    if n == 0:
+        return _GroupCheck(True)
+    ctx = get_aux_context(3)
+    buf = ctx.upload(np.frombuffer(raw, np.uint8))
+    if ctx.validate_points(buf.ptr, n):
+        return _GroupCheck(False)
+    sc = ctx.upload(np.frombuffer((ORDER - 1).to_bytes(32, "little") * n, np.uint8))
+    out = ctx.alloc(64 * n)
+    ctx.repeat(buf.ptr, n, True, sc.ptr, n, False, None, out.ptr)
+    return _GroupCheck(None, ctx, out, raw, (buf, sc))
+
+
 def _valid_group_elements(points, ctx=None):
     """True iff every point is a canonical element of the order-l subgroup of Ed25519.
 
     The verifier's inputs from the prover (P, A, A_i, B_i) are untrusted.  The kernels assume curve
     points (the niels mixed addition absorbs (0, 0)) and reduce exponents mod l, which equals the
     reference's unreduced `B ** (c ** 2)` (compressed_pivot.py:66,180) only on the order-l subgroup -
-    so anything else is rejected up front: on-curve + canonical coordinates (vmpc_points_validate_dev),
-    then (l - 1) * X == -X for all of them in one launch of the ladder kernel (vmpc_repeat_dev)."""
-    import numpy as np
-    from .device import get_context
-    from .groups import ORDER, P as FIELD_P
-    ctx = ctx or get_context()
-    try:
-        pts = [_pt(p) for p in points]
-        raw = b"".join(p.to_affine_bytes() for p in pts)
-    except Exception:
-        return False
-    n = len(pts)
-    if n == 0:
-        return True
-    buf = ctx.upload(np.frombuffer(raw, np.uint8))
-    if ctx.validate_points(buf.ptr, n):
-        return False
-    sc = ctx.upload(np.frombuffer((ORDER - 1).to_bytes(32, "little") * n, np.uint8))
-    out = ctx.alloc(64 * n)
-    ctx.repeat(buf.ptr, n, True, sc.ptr, n, False, None, out.ptr)
-    got = ctx.download(out.ptr, 64 * n).tobytes()
-    for i in range(n):
-        x = int.from_bytes(raw[64 * i:64 * i + 32], "little")
-        want = ((FIELD_P - x) % FIELD_P).to_bytes(32, "little") + raw[64 * i + 32:64 * i + 64]
-        if got[64 * i:64 * i + 64] != want:
-            return False
-    return True
+    so anything else is rejected: on-curve + canonical coordinates (vmpc_points_validate_dev), then
+    (l - 1) * X == -X for all of them in one launch of the ladder kernel (vmpc_repeat_dev)."""
+    return _valid_group_elements_begin(points).result()
 
 
 def _proof_points(proof):
@@ -619,13 +641,17 @@ def protocol_5_verifier(generators, P, L, y, proof, gf, transcript=None):
     """Compressed Sigma-protocol Pi_c, verifier (compressed_pivot.py:205-239)."""
     mode = transcript or TRANSCRIPT
     g, h, k = generators["g"], _pt(generators["h"]), _pt(generators["k"])
-    if not _valid_group_elements([P] + _proof_points(proof),
-                                 g.ctx if isinstance(g, PointVector) else None):
+    # on-curve / canonical now; the order-l ladder runs beside the rest and is joined before accepting (a proof
+    # with a point outside the group gives garbage below, never an accept: the verdict is ANDed in)
+    membership = _valid_group_elements_begin([P] + _proof_points(proof))
+    if membership.verdict is False:
         return False
     P = _pt(P)
     order = gf.order
     n = len(g)
     L, y = pivot.affine_to_linear(L, y, n)
+    if mode == "compact" and isinstance(L.coeffs, ScalarVector):
+        _form_digest_begin(L)
     t = proof["t"]
     A = _pt(proof["A"])
     gens_for_hash = {"g": g if isinstance(g, PointVector) or mode == "compact" else list(g),
@@ -636,5 +662,9 @@ def protocol_5_verifier(generators, P, L, y, proof, gf, transcript=None):
     if mode == "reference":
         Q = Q.point()
     L_tilde = _extend_form(L, c1)
-    return protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof,
-                               transcript=_p5_setup(generators, k, seed, mode, order), _checked=True)
+    try:
+        verdict = protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof,
+                                      transcript=_p5_setup(generators, k, seed, mode, order), _checked=True)
+    finally:
+        in_group = membership.result()
+    return bool(verdict) and in_group
