@@ -399,6 +399,42 @@ def test_native_round_context_with_fold_jumps(vm, monkeypatch, log_n, jump_k, mi
     assert proofs[0] == proofs[1]
 
 
+def test_two_round_contexts_on_one_vmpc_ctx(vm):
+    """The first context takes the arena pooled in the vmpc_ctx, a second one alive at the same time gets a
+    private one (csrc/prover.hip); interleaved rounds give what each gives alone, and the pool is free again
+    afterwards."""
+    ctx = vm.get_context()
+    group = vm.EllipticCurve("Ed25519", "projective")
+    h = group.generator
+    k = vm.Ed25519Point.repeat(h, 4242)
+    g = vm.PointVector.fixed_base(h, list(range(3, 34)))           # 31 generators + h = 32
+    g.precompute([h, k])
+    z1 = vm.ScalarVector.from_ints(list(range(1, 33)))
+    z2 = vm.ScalarVector.from_ints(list(range(101, 133)))
+    L = vm.ScalarVector.from_ints(list(range(7, 39)))
+
+    def alone(z):
+        r = vm._native.P4Rounds(ctx, g._table, 1, 1, z.ptr, L.ptr)
+        out = [r.round(None), r.round(11), r.round(12), r.round(13)]
+        out.append(r.finish(14))
+        r.close()
+        return out
+
+    want1, want2 = alone(z1), alone(z2)
+    a = vm._native.P4Rounds(ctx, g._table, 1, 1, z1.ptr, L.ptr)
+    b = vm._native.P4Rounds(ctx, g._table, 1, 1, z2.ptr, L.ptr)
+    got1, got2 = [], []
+    for c in (None, 11, 12, 13):
+        got1.append(a.round(c))
+        got2.append(b.round(c))
+    got2.append(b.finish(14))
+    got1.append(a.finish(14))
+    b.close()
+    a.close()
+    assert got1 == want1 and got2 == want2 and want1 != want2
+    assert alone(z1) == want1
+
+
 def test_native_round_context_argument_checks(vm):
     ctx = vm.get_context()
     group = vm.EllipticCurve("Ed25519", "projective")
