@@ -593,21 +593,24 @@ def protocol_5_prover(generators, P, L, y, x, gamma, gf, transcript=None, r=None
         gv.text_begin()
         L.coeffs.text_begin()
 
-    if mode == "compact" and device_mode:
-        _form_digest_begin(L)
-    logger_cp.debug("Calculate t.")
-    t = L(r)
-    if device_mode and isinstance(t, int):
-        t = gf(t)
-    logger_cp.debug("Calculate A.")
+    logger_cp.debug("Calculate t, A.")
     if mode == "compact" and device_mode and isinstance(r, ScalarVector) and isinstance(gv, PointVector) \
             and len(r):
-        # the announcement's MSM runs while the host finishes the form's digest (8192 leaf digests at N = 2^20)
+        # the announcement's MSM first, everything the host can do without A behind it: the form's digest
+        # (leaves hashed on a side stream, 8192 of them rehashed here at N = 2^20) and t = L(r), whose inner
+        # product queues behind the MSM
+        _form_digest_begin(L)
         pending = pivot._commit_launch(r, rho, gv, h, gv.ctx)
         L._form_digest = _form_digest(L)
+        t = L(r)
         A = pending.result()
     else:
+        if mode == "compact" and device_mode:
+            _form_digest_begin(L)
+        t = L(r)
         A = pivot.vector_commitment(r, rho, gv, h)
+    if device_mode and isinstance(t, int):
+        t = gf(t)
     proof["t"] = t
     proof["A"] = A
 
