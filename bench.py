@@ -36,19 +36,37 @@ def rand_scalars(rng, n):
     return a
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the latest committed PMC summary (collected with
-    rocprofv3 --pmc in separate passes, profiles/*_pmc_summary.json); None if absent."""
+def pmc_traffic_calibrated(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_summary.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this bench, scripts/profile_round.sh).  The
+    FETCH_SIZE factor is the one measured IN THE SAME PASS on a gather of known size in this kernel's access
+    pattern (vmpc_gather_probe_dev: one lane per random 128-byte line; scripts/traffic_calibration.py), not the
+    guide's 2x for wide streaming reads.  The summary names the code revision it was taken on."""
     import glob
+    out = {"bytes": None, "source": None, "detail": None}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     if not files:
-        return None, None
+        return out
     try:
         with open(files[-1]) as f:
-            k = json.load(f)["kernels"].get(kernel)
-        return (k["hbm_bytes_per_launch_corrected"], os.path.basename(files[-1])) if k else (None, None)
-    except Exception:
-        return None, None
+            d = json.load(f)
+        k = d["kernels"].get(kernel)
+        if not k:
+            return out
+        out["source"] = os.path.basename(files[-1])
+        cal = d.get("calibrated", {}).get(kernel)
+        if cal:
+            out["bytes"] = cal["hbm_bytes_per_launch"]
+            out["detail"] = {"FETCH_SIZE_KiB": k["FETCH_SIZE_KiB_avg"], "WRITE_SIZE_KiB": k["WRITE_SIZE_KiB_avg"],
+                             "fetch_factor": cal["fetch_factor"], "factor_from": cal["factor_from"],
+                             "structural_bytes": cal.get("structural_bytes"),
+                             "revision": d.get("revision")}
+        else:       # summaries of earlier rounds: the guide's streaming-read factor, uncalibrated for a gather
+            out["bytes"] = k["hbm_bytes_per_launch_corrected"]
+            out["detail"] = {"note": "2 x FETCH_SIZE (streaming-read correction), not calibrated for this pattern"}
+    except Exception as e:
+        out["detail"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def cpu_baseline(log2_sample, seed):
@@ -101,11 +119,11 @@ def strong_cpu_baseline(log2n, seed):
     return out
 
 
-def python_reference_baseline(seed, budget_s=12.0):
+def python_reference_baseline(seed, budget_s=40.0):
     """The pure-Python statement of the REFERENCE algorithm (oracle/ac20_ref.vector_commitment: per-term
     right-to-left double-and-add on Python big ints + the reduce tree; the stand-in for the MPyC-based
     reference, which is installable on neither machine), one core, timed at n = 2^10 and - budget
-    permitting - 2^12.  The algorithm is exactly linear in n (n independent ladders + n - 1 additions), so
+    permitting - 2^12 and 2^14.  The algorithm is exactly linear in n (n independent ladders + n - 1 additions), so
     the rate extrapolates to 2^20; the line says which sizes were measured."""
     import random
     from oracle import ac20_ref as ac
@@ -115,9 +133,9 @@ def python_reference_baseline(seed, budget_s=12.0):
     out = {"algorithm": "per-term 253-bit double-and-add + product tree (pivot.py:143-144), Python big ints",
            "cores": 1, "measured": {}}
     spent = 0.0
-    for lg in (10, 12):
+    for lg in (10, 12, 14):
         n = 1 << lg
-        if lg > 10 and spent * 4.5 > budget_s:
+        if lg > 10 and spent * 5.5 > budget_s:     # the next size costs ~4x everything measured so far
             break
         g = [small[i % 16] for i in range(n)]
         x = [rng.randrange(ed.ELL) for _ in range(n)]
@@ -191,7 +209,10 @@ def prove_timing(vm, ctx, n_pow, rng):
                          "the GPU k_fold, the exact replay of (g_l ** c) * g_r "
                          "(profiles/*_prove_reference_kernel_stats.csv)"),
             "transcript": ("build-defined compact byte transcript: NOT the reference's challenges" if mode == "compact"
-                           else "the reference's str(input_list) transcript: proofs bit-identical to the CPU reference")}
+                           else "the reference's str(input_list) transcript, byte formats as recalled from MPyC ([mpyc-recall]): "
+                                "proofs bit-identical to the reference's own modules run over the build-written MPyC "
+                                "stand-in (tests/golden/mpyc_shim), not to a run over real MPyC "
+                                "(scripts/check_against_mpyc.py pins that on a machine that has it)")}
     return out
 
 
@@ -278,9 +299,10 @@ def other_sizes_timing(vm, ctx, pows):
     return out
 
 
-def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch):
+def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch, comm=None):
     """AC20 Protocol 5 (compact transcript) with g_hat in `world` blocks, one per rank
-    (verifiable_mpc_amd/sharded.py): one all-gather of two 128-byte points per rank and round."""
+    (verifiable_mpc_amd/sharded.py): one exchange of two 128-byte points per rank and round.  With `comm` the
+    rounds run inside the C library's sharded round context (vmpc_p4_create_sharded)."""
     from verifiable_mpc_amd import sharded
     N = 1 << n_pow
     n = N - 1
@@ -291,7 +313,7 @@ def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch):
     exps[:, 0] |= 1
     h, k = group.generator, vm.Ed25519Point.repeat(group.generator, 0x1234567)
     t0 = time.perf_counter()
-    crs = sharded.ShardedCrs.from_exponents(h, k, exps, world, [rank], dist, torch, ctx)
+    crs = sharded.ShardedCrs.from_exponents(h, k, exps, world, [rank], dist, torch, ctx, comm=comm)
     crs.digest()
     ctx.sync()
     out = {"crs_block_ms": (time.perf_counter() - t0) * 1e3}
@@ -301,8 +323,10 @@ def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch):
     y = gf(L(x))
     P = crs.commit([(x.concat([gamma]), None)])[0]
     out["blocks"] = world
-    out["scalars_per_rank_and_round"] = 3 * (N // world)
-    for attempt in ("first_call", "steady"):
+    out["rounds_in"] = "libvmpc_hip (vmpc_p4_create_sharded)" if comm is not None else "python (sharded.py)"
+    out["transport"] = comm.kind if comm is not None else "torch.distributed"
+    runs = []
+    for attempt in range(4):
         r = vm.ScalarVector.from_array(rand_scalars(rng, n))
         ctx.sync()
         dist.barrier()
@@ -310,13 +334,63 @@ def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch):
         proof = sharded.protocol_5_prover(crs, P, L, y, x, gamma, gf, r, 0x1111)
         ctx.sync()
         dist.barrier()
-        out["prove_ms_compact" + ("_first_call" if attempt == "first_call" else "")] = (time.perf_counter() - t0) * 1e3
+        runs.append((time.perf_counter() - t0) * 1e3)
+    out["prove_ms_compact_first_call"] = runs[0]
+    out["prove_ms_compact"] = sorted(runs[1:])[1]
+    out["prove_ms_compact_min"] = min(runs[1:])
     mine = b"".join(proof[key].to_affine_bytes() for key in sorted(proof) if key[0] in "AB")
     every = [None] * world
     dist.all_gather_object(every, mine)
     assert all(e == mine for e in every), "ranks disagree on the proof"
+    out["ranks_agree"] = True
+    if rank == 0:
+        # the sharded proof is an ordinary compact proof: the single-GPU verifier accepts it over the whole CRS
+        g = vm.PointVector.fixed_base(h, vm.ScalarVector.from_array(exps), keep_proj=False)
+        ok = vm.compressed_pivot.protocol_5_verifier({"g": g, "h": h, "k": k}, P, L, y, proof, gf, transcript="compact")
+        assert ok is True, "the unsharded verifier rejects the sharded proof"
+        out["verified"] = True
     out["rounds"] = n_pow - 1
     return out
+
+
+def run_steps(shard, k, scalar_vectors, pts, depth, batch):
+    """k commitments, in launches of up to `batch` (prepared generators only) with up to `depth` launches in
+    flight; every result is fetched to the host.  A slot is refilled as soon as ITS launch has completed
+    (completion is polled; with a collective every rank must launch and finish in the same order).  The
+    commitments of one launch are over DISTINCT scalar vectors (scalar_vectors[0 .. b-1]); single launches cycle
+    through the vectors.  Returns (results of the last launch, indices into scalar_vectors they belong to)."""
+    per = batch if getattr(pts, "_table", None) is not None else 1
+    nvec = len(scalar_vectors)
+    busy, order, size, which, launched, done, last = {}, {}, {}, {}, 0, 0, None
+    while done < k:
+        while launched < k and len(busy) < depth:
+            slot = next(s_ for s_ in range(depth) if s_ not in busy)
+            b = min(per, k - launched, nvec)
+            idx = list(range(b)) if per > 1 else [launched % nvec]
+            busy[slot] = shard.launch([scalar_vectors[i] for i in idx] if per > 1 else scalar_vectors[idx[0]], pts, slot)
+            order[slot], size[slot], which[slot] = launched, b, idx
+            launched += b
+        if shard.collective:
+            # every rank must enter the all-gathers in the same order: oldest first
+            ready = [min(busy, key=lambda s_: order[s_])]
+        else:
+            ready = [s_ for s_ in busy if shard.ready(s_)]
+            if not ready:
+                if len(busy) == 1:
+                    ready = list(busy)           # nothing else to overlap with: block on it
+                else:
+                    continue
+        for s_ in ready:
+            res = shard.finish(busy.pop(s_))
+            last = (res if isinstance(res, list) else [res], which[s_])
+            done += size[s_]
+    return last
+
+
+def exponent_sum(scalars_arr, exps_arr, order):
+    """sum_i s_i e_i mod l for (n, 32) little-endian byte arrays: the exponent of B a commitment must equal"""
+    return sum(int.from_bytes(bytes(x), "little") * int.from_bytes(bytes(y), "little")
+               for x, y in zip(scalars_arr, exps_arr)) % order
 
 
 def main():
@@ -329,11 +403,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prove", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
-                    help="run the RCCL all-gather + ordered combine even with one rank (self-test)")
+                    help="run the all-gather + ordered combine even with one rank (self-test)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default=os.environ.get("VMPC_DIST_BACKEND", "nccl"),
+                    help="torch.distributed backend of the process group.  gloo: the partial points are staged "
+                         "through host memory (tests: several ranks may share one GPU)")
+    ap.add_argument("--comm", choices=("native", "torch"), default=os.environ.get("VMPC_COMM", "native"),
+                    help="native: the exchange runs inside libvmpc_hip (ncclAllGather on the MSM's stream, "
+                         "include/vmpc.h vmpc_comm_*), bootstrapped over torch.distributed; torch: "
+                         "torch.distributed carries the partial points (fallback when the native communicator "
+                         "cannot be created)")
     ap.add_argument("--sharded-prove", action="store_true",
                     help="time the sharded compact prover also with one rank (--force-collective); with more "
                          "than one rank it is timed by default (--no-sharded-prove to skip)")
     ap.add_argument("--no-sharded-prove", action="store_true")
+    ap.add_argument("--sharded-log2n", type=int, default=20, help="N of the sharded prove section")
     ap.add_argument("--variable-base", action="store_true",
                     help="headline on generators given as plain affine points (prepared per call) instead of "
                          "generators resident in prepared form; the other mode is always reported beside it")
@@ -341,24 +424,47 @@ def main():
                     help="commitments per launch over the prepared generators (vmpc_msm_table_batch_dev): the "
                          "reduction and recombination chains are paid once per batch; 1 = one commitment per launch")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="one commitment in flight (default: 2, on two streams of the same GPU)")
+                    help="one commitment in flight (default: 3 launches, on three streams of the same GPU)")
+    ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("VMPC_BENCH_WATCHDOG_S", "1500")),
+                    help="multi-rank runs: give up (JSON line with an error entry, exit status 3) after this long")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import torch
+    ndev = torch.cuda.device_count()
+    assert ndev >= 1, "no GPU visible: the AC20 hot path has no CPU fallback"
+    # one process per GPU; only the host-staged gloo mode lets ranks share a device (2-rank tests on a 1-GPU box)
+    assert args.dist_backend == "gloo" or local_rank < ndev, f"LOCAL_RANK {local_rank} but {ndev} GPU(s) visible"
+    device_index = local_rank % ndev
+    torch.cuda.set_device(device_index)
     dist = None
+    state = {"line": None, "stage": "init"}
     if world > 1 or args.force_collective:
+        import threading
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+        def give_up():
+            # a stuck collective must not look like success: report what there is and leave with a failure status
+            line = state["line"] or {"metric": "Ed25519 MSM scalar-mults/sec", "value": None, "n_gpus": world}
+            line["error"] = f"rank {rank}: no progress within {args.watchdog_s:.0f} s (stage: {state['stage']})"
+            print(json.dumps(line), flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(args.watchdog_s, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if dist:
+            dist.barrier()
 
     import verifiable_mpc_amd as vm
     from verifiable_mpc_amd import parallel
@@ -366,13 +472,38 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
+    # ---- the exchange: inside the C library when possible -------------------------------------------------
+    comm, comm_kind, comm_note = None, "none", None
+    if dist:
+        state["stage"] = "communicator"
+        want = "host" if args.dist_backend == "gloo" else ("rccl" if args.comm == "native" else None)
+        if want:
+            try:
+                comm = parallel.make_comm(ctx, world, rank, dist, torch, transport=want)
+            except Exception as e:
+                comm, comm_note = None, f"{type(e).__name__}: {e}"
+            # all or nothing: one rank without the native communicator puts every rank on torch.distributed
+            flags = [None] * world
+            dist.all_gather_object(flags, comm is not None)
+            if not all(flags):
+                if comm is not None:
+                    comm.close()
+                comm = None
+                assert args.dist_backend == "nccl", f"host-staged communicator failed: {comm_note}"
+        comm_kind = comm.kind if comm is not None else "torch.distributed"
+
     n = 1 << args.log2n
     rng = np.random.default_rng(20200152 + 1 + rank)
     group = vm.EllipticCurve("Ed25519", "projective")
     # synthetic inputs (SURVEY.md 8d cfg 2/4): g_i = r_i * B on the device, uniform scalars
-    exps = vm.ScalarVector.from_array(rand_scalars(rng, n))
+    exps_arr = rand_scalars(rng, n)
+    exps = vm.ScalarVector.from_array(exps_arr)
     points = vm.PointVector.fixed_base(group.generator, exps, keep_proj=False)
-    scalars = vm.ScalarVector.from_array(rand_scalars(rng, n))
+    batch = 1 if (args.no_pipeline or args.variable_base) else max(1, min(args.batch, 16))
+    # the commitments of one launch are over DISTINCT scalar vectors (A_i / B_i of a round, or queued independent
+    # commitments - never the same vector twice)
+    scalar_arrs = [rand_scalars(rng, n) for _ in range(max(batch, 1))]
+    scalar_vectors = [vm.ScalarVector.from_array(a) for a in scalar_arrs]
     # The generators of a Pedersen commitment are a CRS (circuit_sat_r1cs.py:47-93 creates them once, every
     # commitment reuses them), so by default they are RESIDENT IN PREPARED FORM: the (y-x, y+x, 2dxy) image of
     # each affine point, one 128-byte line, computed once at CRS load (untimed) - a representation of the same
@@ -382,63 +513,35 @@ def main():
     points_plain = points
     if not args.variable_base:
         points = points_prepared
-    shard = parallel.ShardedMsm(ctx, world, rank, dist, torch, force_collective=args.force_collective)
-
+    shard = parallel.ShardedMsm(ctx, world, rank, dist, torch, force_collective=args.force_collective, comm=comm)
     depth = 1 if args.no_pipeline else shard.n_slots
-    batch = 1 if (args.no_pipeline or args.variable_base) else max(1, min(args.batch, 16))
 
-    def run_steps(k, pts=None):
-        """k commitments, in launches of up to `batch` (prepared generators only) with up to `depth` launches in
-        flight; every result is fetched to the host.  A slot is refilled as soon as ITS launch has completed
-        (completion is polled; with a collective every rank must finish in launch order)."""
-        pts = points if pts is None else pts
-        per = batch if getattr(pts, "_table", None) is not None else 1
-        busy, order, size, launched, done, last = {}, {}, {}, 0, 0, None
-        while done < k:
-            while launched < k and len(busy) < depth:
-                slot = next(s_ for s_ in range(depth) if s_ not in busy)
-                b = min(per, k - launched)
-                busy[slot] = shard.launch([scalars] * b if per > 1 else scalars, pts, slot)
-                order[slot], size[slot] = launched, b
-                launched += b
-            if shard.collective:
-                # every rank must enter the all-gathers in the same order: oldest first
-                ready = [min(busy, key=lambda s_: order[s_])]
-            else:
-                ready = [s_ for s_ in busy if shard.ready(s_)]
-                if not ready:
-                    if len(busy) == 1:
-                        ready = list(busy)           # nothing else to overlap with: block on it
-                    else:
-                        continue
-            for s_ in ready:
-                res = shard.finish(busy.pop(s_))
-                last = res[-1] if isinstance(res, list) else res
-                done += size[s_]
-        return last
+    def steps(k, pts):
+        return run_steps(shard, k, scalar_vectors, pts, depth, batch)
 
     def grow_workspaces(pts):
         """one full-size launch on every slot, untimed: each slot's context sizes its scratch arena on first use
         (a hipMalloc), which must not land in the timed region when the W warm-up steps do not reach every slot"""
         per = batch if getattr(pts, "_table", None) is not None else 1
         for slot in range(depth):
-            shard.finish(shard.launch([scalars] * per if per > 1 else scalars, pts, slot))
+            shard.finish(shard.launch(scalar_vectors[:per] if per > 1 else scalar_vectors[0], pts, slot))
 
+    state["stage"] = "warm-up"
     grow_workspaces(points)
-    run_steps(args.warmup)
+    if args.warmup:
+        steps(args.warmup, points)
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    barrier()
     prof_ctxs = list(getattr(shard.backend, "ctxs", [ctx]))[:depth]
     for c_ in prof_ctxs:
         c_.profile(True)
         c_.profile_read(reset=True)
     torch.cuda.synchronize()
+    state["stage"] = "timed region"
     t0 = time.perf_counter()
-    result = run_steps(args.steps)
+    results, result_idx = steps(args.steps, points)
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    barrier()
     elapsed = time.perf_counter() - t0
     prof = {}
     for c_ in prof_ctxs:       # HIP events on each stream the kernels were launched on
@@ -447,7 +550,7 @@ def main():
             prof[name] = (a + ms, b + cnt)
         c_.profile(False)
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ctx.sync()
@@ -455,71 +558,100 @@ def main():
     # outside the timed region: the same commitment alone on the GPU (one in flight), so that
     # the per-stage durations are not stretched by the other in-flight commitments' kernels,
     # and the integer-ALU ceiling the bucket stage is priced against
-    iso, alu_peak = {}, None
+    state["stage"] = "one commitment alone"
+    iso, alu_peak, iso_ms, iso_steps = {}, None, None, 5
+    c0 = prof_ctxs[0]
     if rank == 0:
-        c0 = prof_ctxs[0]
         c0.profile(True)
         c0.profile_read(reset=True)
-        iso_steps = 5
-        t1 = time.perf_counter()
-        for _ in range(iso_steps):
-            shard.finish(shard.launch(scalars, points, 0))
-        iso_ms = (time.perf_counter() - t1) / iso_steps * 1e3
+    t1 = time.perf_counter()
+    for _ in range(iso_steps):             # (every rank: with a collective the launches are collective too)
+        shard.finish(shard.launch(scalar_vectors[0], points, 0))
+    iso_ms = (time.perf_counter() - t1) / iso_steps * 1e3
+    if rank == 0:
         iso = {k: ms / max(c, 1) for k, (ms, c) in c0.profile_read(reset=True).items()}
         c0.profile(False)
         alu_peak = max(c0.madd_rate(400) for _ in range(3))
     # the other generator form, same K steps, same brackets
+    state["stage"] = "other generator form"
     other_pts = points_plain if points is points_prepared else points_prepared
     grow_workspaces(other_pts)
-    run_steps(args.warmup, other_pts)
+    if args.warmup:
+        steps(args.warmup, other_pts)
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    barrier()
     t2 = time.perf_counter()
-    other_result = run_steps(args.steps, other_pts)
+    other_results, other_idx = steps(args.steps, other_pts)
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    barrier()
     other_elapsed = time.perf_counter() - t2
-    assert other_result == result or os.environ.get("BENCH_NO_CHECK"), "prepared and plain generators disagree"
+    no_check = bool(os.environ.get("BENCH_NO_CHECK"))          # (developer A/B builds that break the result)
 
-    # size-independent correctness property at full size: sum_i s_i * (e_i * B) == (sum s_i e_i) * B
-    if world == 1 and not os.environ.get("BENCH_NO_CHECK"):      # (developer A/B builds that break the result)
-        s_int = vm._native.array_to_ints(scalars.ctx.download(scalars.ptr, 32 * n, (n, 32)))
-        e_int = vm._native.array_to_ints(exps.ctx.download(exps.ptr, 32 * n, (n, 32)))
-        tot = sum(a * b for a, b in zip(s_int, e_int)) % vm.groups.ORDER
-        want = vm.PointVector.fixed_base(group.generator, [tot], keep_proj=False)[0]
-        assert want == result, "MSM property check failed"
+    # size-independent correctness property at full size, for every commitment of the last launch:
+    #     sum_i s_i * (e_i * B) == (sum_i s_i e_i mod l) * B,     the sum running over ALL ranks' shards
+    state["stage"] = "result check"
+    checked = False
+    if not no_check:
+        need = sorted(set(result_idx) | set(other_idx))
+        mine = {i: exponent_sum(scalar_arrs[i], exps_arr, vm.groups.ORDER) for i in need}
+        if dist:
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            assert all(sorted(e) == need for e in every), "ranks disagree on which commitments ran last"
+            tot = {i: sum(e[i] for e in every) % vm.groups.ORDER for i in need}
+        else:
+            tot = mine
+        want = vm.PointVector.fixed_base(group.generator, [tot[i] for i in need], keep_proj=False)
+        want = {i: want[j] for j, i in enumerate(need)}
+        for res, idx in ((results, result_idx), (other_results, other_idx)):
+            for pt, i in zip(res, idx):
+                assert pt == want[i], f"MSM property check failed (rank {rank}, scalar vector {i})"
+        checked = True
 
+    line = None
     if rank == 0:
-        traffic, traffic_src = pmc_traffic("k_msm_bucket")
+        traffic = pmc_traffic_calibrated("k_msm_bucket")
         bucket_ms, bucket_n = prof.get("msm_bucket", (0.0, 0))
-        t_bucket_timed = bucket_ms / max(bucket_n, 1) / 1e3          # in the timed region: three commitments in flight
+        t_bucket_timed = bucket_ms / max(bucket_n, 1) / 1e3          # in the timed region: three launches in flight
         c_bits, windows = ctx.msm_plan(n)
         madds = n * windows                     # one mixed addition per non-zero digit (upper bound)
         iso_bucket_s = iso.get("msm_bucket", 0.0) / 1e3
         # The roofline figure uses the kernel ALONE on the GPU (one commitment in flight, same inputs, same
         # process): that is the duration rocprofv3 reports for it (profiles/*_alone_kernel_stats.csv agrees
-        # within a few %).  With three commitments in flight a HIP-event bracket also counts the time the
+        # within a few %).  With three launches in flight a HIP-event bracket also counts the time the
         # kernel's workgroups wait behind other streams' kernels; that figure is reported beside it.
         t_bucket = iso_bucket_s if iso_bucket_s > 0 else t_bucket_timed
         achieved = BYTES_PER_TERM * n / t_bucket / 1e9 if t_bucket > 0 else 0.0
+        value = world * n * args.steps / elapsed
+        other_value = world * n * args.steps / other_elapsed
+        var_value = value if args.variable_base else other_value
         line = {
-            "metric": "Ed25519 MSM scalar-mults/sec", "value": world * n * args.steps / elapsed,
+            "metric": "Ed25519 MSM scalar-mults/sec", "value": value,
             "unit": "scalar-mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 (255-bit modular integers as 10 limbs of 25.5 bits, 32x32->64 multiply-adds)", "data": "synthetic",
+            "checked": checked,
             "config": {"workload": f"Pedersen vector-commitment MSM, n=2^{args.log2n} Ed25519 "
                                    f"generators per GPU, uniform 252-bit scalars",
                        "terms_per_gpu": n, "total_terms": world * n, "launches_in_flight": depth,
                        "commitments_per_launch": batch,
+                       "scalar_vectors": f"{len(scalar_vectors)} distinct (one per commitment of a launch)",
+                       "timing": {"throughput_ms_per_commitment": round(elapsed / args.steps * 1e3, 4),
+                                  "latency_ms_one_commitment_alone": round(iso_ms, 4),
+                                  "what": "value = pipelined throughput (launches_in_flight x commitments_per_launch "
+                                          "commitments in flight); a prover's commitments are sequential and cost "
+                                          "the latency figure"},
                        "generators": ("plain affine points, prepared inside every call" if args.variable_base else
                                       "resident in prepared form (128-byte niels image of each point, made once "
                                       "at CRS load, untimed)"),
-                       "collective": "all_gather(128 B/rank) + ordered add" if shard.collective else "none"},
+                       "variable_base_scalar_mults_per_s": round(var_value, 1),
+                       "collective": (f"all_gather(128 B/rank and commitment) + rank-ordered add, transport: {comm_kind}"
+                                      if shard.collective else "none"),
+                       "dist_backend": args.dist_backend if dist else None},
             "roofline": {"bound": "hbm", "kernel": "k_msm_bucket", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic["bytes"], "traffic_source": traffic["source"],
+                         "traffic_detail": traffic["detail"],
                          "avg_kernel_ms": t_bucket * 1e3, "launches_timed": iso_steps,
                          "timing": "HIP events on the kernel's stream, the commitment alone on the GPU "
                                    "(5 launches after the timed region)",
@@ -541,12 +673,15 @@ def main():
                                  "mixed_additions_per_launch": madds,
                                  "window_bits": c_bits, "windows": windows}},
             ("prepared_generators" if args.variable_base else "variable_base"): {
-                "value": world * n * args.steps / other_elapsed, "ms_per_step": other_elapsed / args.steps * 1e3,
+                "value": other_value, "ms_per_step": other_elapsed / args.steps * 1e3,
                 "note": "same K steps and brackets with the generators in the other form"},
             "stages_us": {k: round(ms / max(c, 1) * 1e3, 1) for k, (ms, c) in prof.items()},
             "alone": {"ms_per_commitment": round(iso_ms, 4),
                       "stages_us": {k: round(v * 1e3, 1) for k, v in iso.items()}},
         }
+        if comm_note:
+            line["config"]["native_comm_error"] = comm_note
+        state["line"] = line
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_log2n, 5)
             try:
@@ -574,29 +709,18 @@ def main():
                 line["bn256_n2^18"] = {"error": f"{type(e).__name__}: {e}"}
     sharded_info = None
     if dist and (args.sharded_prove or (world > 1 and not args.no_sharded_prove)):
-        # every rank takes part; neither a failure nor a stuck collective here may cost the headline line:
-        # rank 0 arms a watchdog that prints the line without this section and leaves
-        watchdog = None
-        if rank == 0:
-            import threading
-
-            def give_up():
-                line["ac20_n2^20_sharded"] = {"error": "no result within 240 s"}
-                print(json.dumps(line), flush=True)
-                os._exit(0)
-            watchdog = threading.Timer(240.0, give_up)
-            watchdog.daemon = True
-            watchdog.start()
+        # every rank takes part; a failure here must not cost the headline line (a stuck collective ends in the
+        # watchdog: line + error entry, exit status 3)
+        state["stage"] = "sharded prove"
         try:
-            sharded_info = {k: round(v, 2) for k, v in
-                            sharded_prove_timing(vm, ctx, 20, world, rank, dist, torch).items()}
+            sharded_info = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in
+                            sharded_prove_timing(vm, ctx, args.sharded_log2n, world, rank, dist, torch, comm).items()}
         except Exception as e:
             sharded_info = {"error": f"{type(e).__name__}: {e}"}
-        if watchdog is not None:
-            watchdog.cancel()
+    state["stage"] = "done"
     if rank == 0:
         if sharded_info is not None:
-            line["ac20_n2^20_sharded"] = sharded_info
+            line[f"ac20_n2^{args.sharded_log2n}_sharded"] = sharded_info
         try:        # RCCL's version banner sits in the C stdio buffer: push it out first, the JSON line is the last line
             import ctypes
             ctypes.CDLL(None).fflush(None)
@@ -605,6 +729,8 @@ def main():
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

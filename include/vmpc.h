@@ -80,6 +80,14 @@ int vmpc_ed25519_msm_plan(vmpc_ctx *ctx, size_t n, int *c_bits, int *windows);
  * a register-resident chain on every lane of the chip - the bucket kernel without memory. */
 int vmpc_ed25519_madd_rate(vmpc_ctx *ctx, int iters, double *madds_per_second);
 
+/* Calibration probe for the HBM-traffic counters (profiles/, bench.py roofline.traffic): n_gathers reads of one
+ * 128-byte line each from a device table of table_lines lines, in the bucket stage's access pattern (one lane per
+ * line, eight 16-byte loads).  mode 0: lines at random (hash of the gather index and seed); 1: consecutive lanes
+ * read consecutive lines; 2: the same bytes as a wide coalesced stream (16 B per lane).  Known bytes read:
+ * 128 * n_gathers.  ms (may be NULL): duration of the launch (synchronises). */
+int vmpc_gather_probe_dev(vmpc_ctx *ctx, const void *table, size_t table_lines, size_t n_gathers, int mode,
+                          uint32_t seed, double *ms);
+
 /* ---- host-buffer one-shots (SURVEY.md 8b proposal) -------------------------------- */
 /* h^gamma-less MSM: out = sum scalars[i] * points[i].
  * Replaces the list comprehension + reduce of pivot.vector_commitment,
@@ -144,6 +152,36 @@ int vmpc_points_sum_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, void *o
  * k partial points per rank produces (A_i and B_i of a round: k = 2); outputs consecutive */
 int vmpc_points_sum_many_dev(vmpc_ctx *ctx, const void *ext_points, size_t m, size_t k, void *out_ext,
                              void *out_affine);
+
+/* ---- the multi-GPU exchange step (kernel row "allgather_add_points") ------------------------------
+ * One process per GPU.  A commitment over generators that are sharded over G ranks (pivot.py:143-144 is a sum of
+ * independent terms) is G partial sums plus ONE exchange: an all-gather of the 128-byte partial points and, on
+ * every rank, their sum in rank order - the same bits on all ranks, so Fiat-Shamir challenges need no broadcast.
+ * Transports: RCCL (ncclAllGather on the context's stream, xGMI inside a node; librccl is dlopen'ed on first use,
+ * there is no link-time dependency), or a caller-supplied callback (host-staged gloo in the tests, any other
+ * fabric), or none for world = 1. */
+typedef struct vmpc_comm vmpc_comm;
+#define VMPC_COMM_ID_BYTES 128
+/* rank 0 draws the id (ncclGetUniqueId) and hands it to every rank over any side channel */
+int vmpc_comm_unique_id(uint8_t out[VMPC_COMM_ID_BYTES]);
+/* collective: every rank calls it with the same id (ncclCommInitRank on ctx's device) */
+int vmpc_comm_create_rccl(vmpc_ctx *ctx, const uint8_t unique_id[VMPC_COMM_ID_BYTES], int world, int rank,
+                          vmpc_comm **out);
+/* the caller moves the bytes: fn(user, mine, gathered, bytes_per_rank) is called with DEVICE pointers after the
+ * context's stream has been synchronised, must fill gathered[r * bytes_per_rank ..] with rank r's `mine` for every r
+ * and return 0.  fn = NULL is allowed for world = 1 (the gather is a device copy). */
+typedef int (*vmpc_exchange_fn)(void *user, const void *mine, void *gathered, size_t bytes_per_rank);
+int vmpc_comm_create_callback(int world, int rank, vmpc_exchange_fn fn, void *user, vmpc_comm **out);
+int vmpc_comm_destroy(vmpc_comm *comm);
+/* kind: 0 = self (world 1), 1 = RCCL, 2 = callback */
+int vmpc_comm_info(const vmpc_comm *comm, int *world, int *rank, int *kind);
+/* gathered (world x bytes_per_rank, device) = every rank's `mine`, in rank order; enqueued on ctx's stream */
+int vmpc_comm_allgather_dev(vmpc_comm *comm, vmpc_ctx *ctx, const void *mine, void *gathered, size_t bytes_per_rank);
+/* k commitments at once: mine_ext = this rank's k partial points (128 B each, device); gathered_scratch = world x k x
+ * 128 bytes of device scratch; out_ext / out_affine (either may be NULL) = the k rank-ordered sums, as
+ * vmpc_points_sum_many_dev writes them.  No host synchronisation with the RCCL transport. */
+int vmpc_comm_points_allsum_dev(vmpc_comm *comm, vmpc_ctx *ctx, const void *mine_ext, size_t k,
+                                void *gathered_scratch, void *out_ext, void *out_affine);
 
 /* element-wise `base_i ** n_i` replaying the reference's operation sequence (ge25519.h):
  * bases are projective (96 B) or, with bases_affine != 0, affine (64 B, Z = 1); a single
@@ -247,6 +285,10 @@ int vmpc_bn256_fixed_base_dev(vmpc_ctx *ctx, int group, const void *base_affine,
                               void *out_affine);
 
 int vmpc_bn256_validate_dev(vmpc_ctx *ctx, int group, const void *points, size_t n, uint64_t *n_bad);
+/* Integer-ALU ceiling of the BN-256 bucket stage (bench.py, `alu` block of the bn256 line): Jacobian mixed
+ * additions (madd-2007-bl on the Montgomery-form field; group 2: over F_p^2) per second of a register-resident
+ * chain on every lane of the chip - the bucket kernel without memory. */
+int vmpc_bn256_madd_rate(vmpc_ctx *ctx, int group, int iters, double *madds_per_second);
 /* Fixed-base tables over an evaluation-key vector (fixed per circuit; pynocchio.py:228-246 reads the
  * same evalkey entries for every proof): 17 rows 2^(16 w) * P_i.  vmpc_bn256_table_msm_dev computes
  * sum_{i<m} scalars[i] * P_i, equal to vmpc_bn256_g{1,2}_msm_dev on the first m points. */
@@ -291,8 +333,20 @@ int vmpc_msm_table_fold_table_dev(vmpc_ctx *ctx, const void *table, size_t table
 typedef struct vmpc_p4 vmpc_p4;
 int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows, int h_slots,
                    int k_slot, const uint8_t k_affine[64], const void *z_hat, const void *L_tilde, vmpc_p4 **out);
+/* The same rounds with g_hat cut into `world` CONTIGUOUS blocks, one per rank of `comm` (one process
+ * per GPU): block_table = vmpc_msm_table_build_dev over THIS rank's block_n = N / world generators (h is the last
+ * generator of the last block) with k among its extras (k_slot); z_hat / L_tilde: all N scalars, the same on every
+ * rank.  A round computes the partial A_i, B_i over the block and exchanges them once (vmpc_comm_points_allsum_dev);
+ * every rank returns the same A_i, B_i.  The k term is added by rank 0.  The fold of the generators after 5 rounds
+ * stays local: a rank folds the strides its block holds (needs 2^5 >= 2 world and a block of >= 2^18 generators)
+ * and later rounds commit to the rank's partial vector.  world must be a power of two.  All ranks must make the
+ * same calls in the same order. */
+int vmpc_p4_create_sharded(vmpc_ctx *ctx, vmpc_comm *comm, const void *block_table, size_t block_n, size_t table_extra,
+                           int rows, int k_slot, const uint8_t k_affine[64], const void *z_hat, const void *L_tilde,
+                           vmpc_p4 **out);
 /* prev_challenge: derived from the previous call's A, B; NULL on the first call.  out_A / out_B: affine x||y.
- * Valid log2(N) - 1 times. */
+ * Valid log2(N) - 1 times.  If a call fails after the witness fold was enqueued the context is unusable: every
+ * further call returns VMPC_E_INVAL, destroy it (vmpc_ctx_destroy refuses while a round context is alive). */
 int vmpc_p4_round(vmpc_p4 *p4, const uint8_t prev_challenge[32], uint8_t out_A[64], uint8_t out_B[64]);
 /* after the last round: fold with its challenge and return z' (two 32-byte residues, compressed_pivot.py:77-79) */
 int vmpc_p4_finish(vmpc_p4 *p4, const uint8_t last_challenge[32], uint8_t out_z_prime[64]);

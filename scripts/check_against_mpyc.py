@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Pin the one residual of parity - MPyC's byte-level formats - on a machine that HAS MPyC.
+
+The arithmetic of the AC20 path lives in MPyC (`mpyc >= 0.8`, verifiable_mpc/setup.py:28), which is installed on
+neither the build container nor the GPU box.  The oracle and the kernels therefore follow MPyC's formats as
+recalled ([mpyc-recall] in SURVEY.md): repr of a curve point and of a field element inside str(input_list)
+(verifiable_mpc/ac20/pivot.py:134), the signed int() of a field element (pivot.py:119-128), the projective
+representative `repeat` leaves (pivot.py:143, compressed_pivot.py:64), the shape of mpctools.reduce
+(pivot.py:26-28).  Everything above that layer is pinned by fixtures generated from the reference's own modules
+over a build-written stand-in for MPyC (tests/golden/mpyc_shim).  This script closes the gap where real MPyC
+exists:
+
+    pip install mpyc            # and a checkout of toonsegers/verifiable_mpc
+    python scripts/check_against_mpyc.py --reference /path/to/verifiable_mpc
+
+It needs no GPU.  It compares, and prints the first difference of:
+  1. repr / str / int of GF(l) elements and repr of Ed25519 'projective' elements (plain, product, normalised);
+  2. the (X : Y : Z) representative of g ** e for several exponents (incl. negative) and of a * b;
+  3. the grouping of mpctools.reduce for 1..9 operands with and without `initial`;
+  4. the WHOLE N = 4 Protocol-5 case of tests/golden/ac20_ed25519_small.json re-run with the reference's modules
+     over real MPyC: every proof element, every challenge and the text of every Fiat-Shamir pre-image.
+Exit status 0 = everything equal (parity with real MPyC pinned), 1 = a difference (shown), 2 = MPyC missing.
+"""
+import argparse
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+
+
+def first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return i
+    return n if len(a) != len(b) else -1
+
+
+class Report:
+    def __init__(self):
+        self.failed = 0
+
+    def check(self, what, got, want):
+        if got == want:
+            print(f"  ok    {what}")
+            return True
+        self.failed += 1
+        print(f"  DIFF  {what}")
+        if isinstance(got, str) and isinstance(want, str):
+            i = first_diff(got, want)
+            lo = max(0, i - 40)
+            print(f"        first differing byte: offset {i} (lengths {len(got)} real / {len(want)} ours)")
+            print(f"        real MPyC : ...{got[lo:i + 40]!r}")
+            print(f"        this build: ...{want[lo:i + 40]!r}")
+        else:
+            print(f"        real MPyC : {got!r}\n        this build: {want!r}")
+        return False
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--reference", default=os.environ.get("VMPC_REFERENCE", "/root/reference"),
+                    help="checkout of toonsegers/verifiable_mpc (the directory that holds verifiable_mpc/)")
+    args = ap.parse_args()
+    self_test = os.environ.get("VMPC_CHECK_AGAINST_SHIM") == "1"     # tests/: run the comparisons over the stand-in
+    if self_test:
+        sys.path.insert(0, os.path.join(REPO, "tests", "golden", "mpyc_shim"))
+    else:
+        # make sure the stand-in cannot be picked up instead of the real package
+        sys.path[:] = [p for p in sys.path if not p.rstrip("/").endswith("mpyc_shim")]
+    try:
+        import mpyc
+        from mpyc import mpctools
+        from mpyc.finfields import GF
+        from mpyc.fingroups import EllipticCurve
+    except ImportError as e:
+        print(f"real MPyC is not importable here ({e}); nothing checked.  pip install mpyc and re-run.")
+        return 2
+    where = os.path.dirname(os.path.abspath(mpyc.__file__))
+    if "mpyc_shim" in where and not self_test:
+        print(f"`import mpyc` resolved to the build's stand-in ({where}); nothing checked.")
+        return 2
+    print(f"MPyC {getattr(mpyc, '__version__', '?')} at {where}")
+
+    from oracle import ac20_ref as ac
+    from oracle import ed25519_ref as ed
+    from verifiable_mpc_amd import fields as our_fields
+    from verifiable_mpc_amd import groups as our_groups
+    rep = Report()
+
+    group = EllipticCurve("Ed25519", "projective")          # demos/demo_zkp_ac20.py:46-49
+    group.is_additive, group.is_multiplicative = False, True
+    gf = GF(modulus=group.order)
+    ogf = our_fields.GF(ed.ELL)
+    ogroup = our_groups.EllipticCurve("Ed25519", "projective")
+
+    print("1. element formats (pivot.py:134 hashes str(input_list))")
+    rep.check("group.order", int(group.order), ed.ELL)
+    for v in (0, 1, 5, -1, ed.ELL - 1, ed.ELL // 2, ed.ELL // 2 + 1, 2**200 + 12345):
+        rep.check(f"repr(gf({v if abs(v) < 10**6 else hex(v)}))", repr(gf(v)), repr(ogf(v)))
+        rep.check(f"str / int of the same", (str(gf(v)), int(gf(v))), (str(ogf(v)), int(ogf(v))))
+    rep.check("str([gf(3), gf(-3)])", str([gf(3), gf(-3)]), str([ogf(3), ogf(-3)]))
+    g, og = group.generator, ogroup.generator
+    rep.check("repr(generator)", repr(g), repr(og))
+    rep.check("repr(generator ** 3)", repr(g ** 3), repr(our_groups.Ed25519Point.repeat(og, 3)))
+    rep.check("repr((generator ** 3).normalize())", repr((g ** 3).normalize()),
+              repr(our_groups.Ed25519Point.repeat(og, 3).normalize()))
+    rep.check("repr(identity)", repr(group.identity), repr(ogroup.identity))
+    rep.check("str([g, g ** 2]) (list of points)", str([g, g ** 2]), str([og, our_groups.Ed25519Point.repeat(og, 2)]))
+
+    def coords(pt):
+        return tuple(int(c) % ed.P for c in pt.value) if hasattr(pt, "value") else tuple(int(c) % ed.P for c in pt)
+
+    print("2. projective representatives (repeat: pivot.py:143; product: compressed_pivot.py:64)")
+    rep.check("generator coordinates", coords(g), ed.BASE)
+    for e in (1, 2, 3, 0xdeadbeef, ed.ELL - 2, -5, 2**252, 0):
+        rep.check(f"(X:Y:Z) of g ** {e if abs(e) < 10**6 else hex(e)}", coords(g ** e), ed.pt_repeat(ed.BASE, e))
+    a, b = g ** 7, g ** 11
+    rep.check("(X:Y:Z) of (g**7) * (g**11)", coords(a * b), ed.pt_add(ed.pt_repeat(ed.BASE, 7), ed.pt_repeat(ed.BASE, 11)))
+    rep.check("(X:Y:Z) of ((g**7) ** c) * (g**11), the fold of one element",
+              coords((a ** 0x1234567) * b),
+              ed.pt_add(ed.pt_repeat(ed.pt_repeat(ed.BASE, 7), 0x1234567), ed.pt_repeat(ed.BASE, 11)))
+
+    print("3. shape of mpctools.reduce (pivot.list_mul, pivot.py:26-28)")
+    glue = lambda x, y: f"({x}{y})"
+    for m in range(1, 10):
+        xs = [chr(ord("a") + i) for i in range(m)]
+        rep.check(f"reduce over {m} operands", mpctools.reduce(glue, xs), ed.tree_reduce(glue, xs))
+        rep.check(f"reduce over {m} operands, initial", mpctools.reduce(glue, xs, "I"), ed.tree_reduce(glue, xs, "I"))
+
+    print("4. the N = 4 Protocol-5 fixture, re-run over real MPyC")
+    os.environ["VMPC_FIXTURES_REAL_MPYC"] = "0" if self_test else "1"
+    os.environ["VMPC_REFERENCE"] = args.reference
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    try:
+        import make_fixtures as mf
+    except Exception as e:
+        rep.failed += 1
+        print(f"  DIFF  could not import the reference's ac20 modules from {args.reference}: {type(e).__name__}: {e}")
+        mf = None
+    if mf is not None:
+        with open(os.path.join(REPO, "tests", "golden", "ac20_ed25519_small.json")) as f:
+            want = json.load(f)["p5"][0]
+        got = json.loads(json.dumps(mf.p5_case(3, mf.SEED, keep_text=True, keep_proj=True), sort_keys=True))
+        for key in sorted(want):
+            if key == "hashes":
+                continue
+            rep.check(f"fixture[{key!r}]", got.get(key), want[key])
+        rep.check("number of Fiat-Shamir hashes", len(got["hashes"]), len(want["hashes"]))
+        for i, (hg, hw) in enumerate(zip(got["hashes"], want["hashes"])):
+            if rep.check(f"pre-image {i}: text ({hw['len']} bytes)", hg.get("text"), hw.get("text")):
+                rep.check(f"pre-image {i}: challenge", hg["c"], hw["c"])
+            else:
+                print("        (later challenges differ as a consequence)")
+                break
+    print()
+    if rep.failed:
+        print(f"{rep.failed} difference(s): the [mpyc-recall] format layer (oracle/ed25519_ref.py switches, "
+              "verifiable_mpc_amd/groups.py, fields.py, csrc/fmt.h) needs the adjustments shown above.")
+        return 1
+    print("all equal over the build's own stand-in (self-test of this script; nothing pinned)." if self_test else
+          "all equal: parity with real MPyC's byte formats is pinned on this machine.")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 python3 bench.py > "$OUT/bench_$TAG.json" 2> "$OUT/bench_$TAG.err"
 tail -c 300 "$OUT/bench_$TAG.json"
 cd /tmp
-rm -rf "$OUT"/prof_${TAG}* "$OUT"/pmc_fetch_$TAG "$OUT"/pmc_write_$TAG
+rm -rf "$OUT"/prof_${TAG}* "$OUT"/pmc_fetch_$TAG "$OUT"/pmc_write_$TAG "$OUT"/pmc_calib_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -- \
     python3 "$REPO/bench.py" --no-cpu-baseline --no-prove > "$OUT/prof_$TAG.bench.json" 2> "$OUT/prof_$TAG.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_alone" -- \
@@ -27,6 +27,11 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$TAG" -- \
     python3 "$REPO/bench.py" --steps 4 --warmup 2 --batch 1 --no-cpu-baseline --no-prove > /dev/null 2> "$OUT/pmc_fetch_$TAG.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$TAG" -- \
     python3 "$REPO/bench.py" --steps 4 --warmup 2 --batch 1 --no-cpu-baseline --no-prove > /dev/null 2> "$OUT/pmc_write_$TAG.err"
+# the same counter on reads of KNOWN size in the bucket stage's access pattern (csrc/probe.hip): the factor that turns
+# FETCH_SIZE into bytes for a one-lane-per-128-byte-line gather (MI355X_MICROARCH.md: calibrate other patterns yourself)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_calib_$TAG" -- \
+    python3 "$REPO/scripts/traffic_calibration.py" "$OUT/pmc_calib_$TAG/manifest.json" > "$OUT/pmc_calib_$TAG.log" 2> "$OUT/pmc_calib_$TAG.err"
+(cd "$REPO" && git rev-parse --short HEAD 2>/dev/null || cat "$REPO/.revision" 2>/dev/null) > "$OUT/revision_$TAG.txt"
 # (--batch 1 in the PMC passes: every k_msm_bucket launch is then ONE commitment, the unit the roofline figure uses)
 # keep what travels back small: stats + counter csv only
 find "$OUT" -name '*kernel_trace.csv' -delete

@@ -29,6 +29,41 @@ def counter_avgs(dirname, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in rows.items()}
 
 
+def calibration(out, tag):
+    """bytes per FETCH_SIZE KiB for the probe's three patterns and two table sizes (scripts/traffic_calibration.py)"""
+    d = os.path.join(out, f"pmc_calib_{tag}")
+    man = os.path.join(d, "manifest.json")
+    paths = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    if not os.path.exists(man) or not paths:
+        return None
+    with open(man) as f:
+        launches = json.load(f)["launches"]
+    rows = []
+    with open(paths[-1]) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") == "FETCH_SIZE" and r["Kernel_Name"].startswith("k_gather_probe"):
+                rows.append((int(r.get("Dispatch_Id", len(rows))), float(r["Counter_Value"]), r.get("Grid_Size")))
+    rows.sort()
+    if len(rows) != len(launches):
+        return {"error": f"{len(rows)} counter rows for {len(launches)} launches"}
+    names = {0: "gather_random_lines", 1: "lines_in_order", 2: "coalesced_stream"}
+    res = {}
+    for l, (_, kib, grid) in zip(launches, rows):
+        if l["rep"] == 0:
+            continue                            # warm-up launch of the configuration
+        key = f"{names[l['mode']]}_{l['table_MiB']}MiB"
+        e = res.setdefault(key, {"known_bytes": l["known_bytes"], "FETCH_SIZE_KiB": [], "ms": [], "GBps": []})
+        e["FETCH_SIZE_KiB"].append(kib)
+        e["ms"].append(l["ms"])
+        e["GBps"].append(l["GBps"])
+    for e in res.values():
+        kib = sum(e["FETCH_SIZE_KiB"]) / len(e["FETCH_SIZE_KiB"])
+        e["FETCH_SIZE_KiB_avg"] = kib
+        e["bytes_per_FETCH_SIZE_byte"] = e["known_bytes"] / (kib * 1024.0) if kib else None
+        e["GBps_avg"] = sum(e["GBps"]) / len(e["GBps"])
+    return res
+
+
 def main():
     tag = sys.argv[1]
     out = os.path.join(ROOT, "gpurun_out")
@@ -57,7 +92,26 @@ def main():
         kernels[k] = {"FETCH_SIZE_KiB_avg": f_kib, "WRITE_SIZE_KiB_avg": w_kib,
                       "hbm_bytes_per_launch_corrected": (2.0 * f_kib + w_kib) * 1024.0,
                       "launches_FETCH_SIZE": f_n, "launches_WRITE_SIZE": w_n}
-    summary = {"command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 4 --warmup 2 "
+    calib = calibration(out, tag)
+    calibrated = {}
+    rev = None
+    if os.path.exists(os.path.join(out, f"revision_{tag}.txt")):
+        with open(os.path.join(out, f"revision_{tag}.txt")) as f:
+            rev = f.read().strip() or None
+    if calib and "error" not in calib and "k_msm_bucket" in kernels:
+        # k_msm_bucket's reads are one-lane-per-line gathers from the 128-MiB prepared-generator table plus the
+        # sorted index stream (4 B per entry, in order): apply the factor measured for the gather in this pass
+        key = "gather_random_lines_128MiB"
+        fac = calib[key]["bytes_per_FETCH_SIZE_byte"]
+        kb = kernels["k_msm_bucket"]
+        n, windows = 1 << 20, 16
+        calibrated["k_msm_bucket"] = {
+            "fetch_factor": fac, "factor_from": key,
+            "hbm_bytes_per_launch": (fac * kb["FETCH_SIZE_KiB_avg"] + kb["WRITE_SIZE_KiB_avg"]) * 1024.0,
+            "structural_bytes": windows * n * (128 + 4) + windows * (1 << 15) * 160,
+            "structural_note": "16 windows x 2^20 terms x (128-B table line + 4-B sorted index) read, "
+                               "16 x 2^15 buckets x 160 B written"}
+    summary = {"revision": rev, "calibration": calib, "calibrated": calibrated, "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 4 --warmup 2 "
                           "--batch 1 --no-cpu-baseline --no-prove (one pass per counter, one commitment per launch; "
                           "scripts/profile_round.sh)",
                "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE tallies 128-B "

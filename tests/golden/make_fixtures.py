@@ -24,8 +24,11 @@ import types
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
-sys.path.insert(0, os.path.join(HERE, "mpyc_shim"))
-sys.path.insert(0, "/root/reference")
+# scripts/check_against_mpyc.py re-runs the cases below over REAL MPyC on a machine that has it
+# (VMPC_FIXTURES_REAL_MPYC=1: no shim on the path; VMPC_REFERENCE: the reference checkout)
+if os.environ.get("VMPC_FIXTURES_REAL_MPYC") != "1":
+    sys.path.insert(0, os.path.join(HERE, "mpyc_shim"))
+sys.path.insert(0, os.environ.get("VMPC_REFERENCE", "/root/reference"))
 sys.path.insert(0, REPO)
 
 # the KoE pivot's BN256 pairing module is out of scope and needs extension fields the

@@ -1,0 +1,84 @@
+"""bench.py with MORE THAN ONE RANK, before the driver runs it on eight GPUs.
+
+A one-GPU box cannot host two RCCL ranks (RCCL refuses a device twice), so:
+ * two ranks of bench.py itself, launched exactly as the driver launches them (torch.distributed.run), with
+   --dist-backend gloo: both ranks share the GPU, the partial points travel through host memory - every line of
+   the world > 1 path runs (cyclic shard inputs, the collective branch of run_steps with batch 3 and three
+   launches in flight, the exchange inside the C library's callback transport, the cross-rank exponent-identity
+   check, the sharded prover on two blocks with the block-local generator fold, max-over-ranks timing);
+ * one rank with the real RCCL communicator (--force-collective): ncclAllGather on the MSM's stream and the
+   sharded round context over RCCL.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def last_json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.strip().startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_two_ranks_of_bench_py_over_gloo():
+    env = dict(os.environ, VMPC_P4_JUMP_MIN_LOG2="9", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "2", "--log2n", "12",
+           "--dist-backend", "gloo", "--sharded-log2n", "12", "--watchdog-s", "600"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    d = last_json_line(out.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 7 and d["checked"] is True and "error" not in d
+    assert d["config"]["total_terms"] == 2 << 12 and d["config"]["commitments_per_launch"] == 3
+    assert d["config"]["launches_in_flight"] == 3 and "callback" in d["config"]["collective"]
+    assert abs(d["value"] - 2 * (1 << 12) * 7 / (d["ms_per_step"] * 7e-3)) / d["value"] < 1e-6
+    sp = d["ac20_n2^12_sharded"]
+    assert "error" not in sp, sp
+    assert sp["blocks"] == 2 and sp["ranks_agree"] is True and sp["verified"] is True
+    assert sp["rounds_in"].startswith("libvmpc_hip")
+
+
+def test_one_rank_over_rccl_force_collective():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "1", "--log2n", "14",
+           "--force-collective", "--sharded-prove", "--sharded-log2n", "14", "--no-cpu-baseline", "--no-prove",
+           "--watchdog-s", "600"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    d = last_json_line(out.stdout)
+    assert d["n_gpus"] == 1 and d["checked"] is True and "error" not in d
+    assert "rccl" in d["config"]["collective"], d["config"]
+    sp = d["ac20_n2^14_sharded"]
+    assert "error" not in sp, sp
+    assert sp["transport"] == "rccl" and sp["verified"] is True and sp["rounds_in"].startswith("libvmpc_hip")
+
+
+def test_torch_distributed_fallback_path_one_rank():
+    """--comm torch: the exchange through torch.distributed (the path taken when the native communicator cannot
+    be created on some rank)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--log2n", "13",
+           "--force-collective", "--comm", "torch", "--sharded-prove", "--sharded-log2n", "12",
+           "--no-cpu-baseline", "--no-prove", "--watchdog-s", "600"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    d = last_json_line(out.stdout)
+    assert d["checked"] is True and "torch.distributed" in d["config"]["collective"]
+    sp = d["ac20_n2^12_sharded"]
+    assert "error" not in sp and sp["verified"] is True and sp["rounds_in"].startswith("python")

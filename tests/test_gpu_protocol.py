@@ -399,6 +399,41 @@ def test_native_round_context_with_fold_jumps(vm, monkeypatch, log_n, jump_k, mi
     assert proofs[0] == proofs[1]
 
 
+@pytest.mark.parametrize("n_table,with_h", [(128, False), (127, True)])
+def test_protocol4_over_a_prefix_of_a_tabulated_crs(vm, n_table, with_h):
+    """protocol_4_prover(g[:m], ...) with g[:m] a STRICT prefix of a tabulated vector (PointVector slices keep
+    the table): the round context derives N from the table, so a prefix must take the round-by-round path.
+    Same proof as over an untabulated copy of the same 64 points."""
+    rng = random.Random(4711 + n_table)
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    h, k = group.generator, vm.Ed25519Point.repeat(group.generator, rng.randrange(1, ELL))
+    g = vm.PointVector.fixed_base(h, [rng.randrange(1, ELL) for _ in range(n_table)], keep_proj=False)
+    g.precompute([h, k] if with_h else [k])
+    m = 64
+    prefix = g[:m]
+    assert prefix._table is g._table and len(prefix) == m
+    plain = vm.PointVector.from_affine_array(prefix.affine_array())
+    assert plain._table is None
+    z = [rng.randrange(ELL) for _ in range(m)]
+    lc = [rng.randrange(ELL) for _ in range(m)]
+    proofs = []
+    for gv in (prefix, plain):
+        z_hat = vm.ScalarVector.from_ints(z)
+        L_tilde = vm.pivot.LinearForm(vm.ScalarVector.from_ints(lc))
+        Q = vm.pivot.vector_commitment(z_hat, int(L_tilde(z_hat)), gv, k)
+        tr = vm.compressed_pivot._Transcript("compact", group.order, hashlib.sha256(b"prefix test").digest())
+        proof = vm.compressed_pivot.protocol_4_prover(gv, k, Q, L_tilde, z_hat, gf, {}, transcript=tr)
+        tr = vm.compressed_pivot._Transcript("compact", group.order, hashlib.sha256(b"prefix test").digest())
+        assert vm.compressed_pivot.protocol_4_verifier(plain, k, Q, L_tilde, gf, proof, transcript=tr) is True
+        proofs.append({key: (tuple(v.normalize().coords) if hasattr(v, "normalize") else [int(e) for e in v])
+                       for key, v in proof.items()})
+    assert proofs[0] == proofs[1]
+    # the binding itself refuses a table that is longer than the vectors it is handed
+    with pytest.raises(AssertionError):
+        vm._native.P4Rounds(g.ctx, g._table, 0, g._table.extra_index(k), z_hat.ptr, z_hat.ptr, n_total=m)
+
+
 def test_two_round_contexts_on_one_vmpc_ctx(vm):
     """The first context takes the arena pooled in the vmpc_ctx, a second one alive at the same time gets a
     private one (csrc/prover.hip); interleaved rounds give what each gives alone, and the pool is free again

@@ -104,3 +104,87 @@ def test_cyclic_sharding_helpers():
     assert sum(len(p) for p in parts) == 10
     assert [list(parallel.cyclic_indices(10, 4, r)) for r in range(4)] == [[0, 4, 8], [1, 5, 9], [2, 6], [3, 7]]
     assert (parts[1] == a[[1, 5, 9]]).all()
+
+
+# ---- bench.py's own driver loop (run_steps) through the collective branch, two ranks ------------------------
+class BatchOracleBackend(OracleBackend):
+    """three slots, launches of several commitments (the layout HipBackend produces: b points per rank)"""
+    n_slots = 3
+    max_batch = 4
+
+    def __init__(self):
+        super().__init__()
+        self.batch_of = {}
+
+    def launch_partial(self, scalars, points, slot, want_affine):
+        assert not want_affine
+        many = scalars if isinstance(scalars[0], (list, tuple)) else [scalars]
+        raw = b""
+        for sc in many:
+            acc = ed.IDENTITY
+            for s, p in zip(sc, points.pts):
+                acc = ed.pt_add(acc, ed.pt_repeat(p, s))
+            raw += ext_bytes(acc)
+        self.batch_of[slot] = len(many)
+        self.partials[slot] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+
+    def new_gather_buffer(self, world):
+        return torch.zeros((world, 128 * self.max_batch), dtype=torch.uint8)
+
+    def combine(self, gathered, world, slot=0):
+        b = self.batch_of[slot]
+        raw = gathered.view(-1)[:world * 128 * b].numpy().tobytes()
+        out = []
+        for j in range(b):
+            acc = ed.IDENTITY
+            for r in range(world):          # rank order
+                o = 128 * (r * b + j)
+                X, Y, Z = (int.from_bytes(raw[o + 32 * i:o + 32 * i + 32], "little") for i in range(3))
+                acc = ed.pt_add(acc, (X, Y, Z))
+            out.append(ed.pt_affine(acc))
+        return out if b > 1 else out[0]
+
+
+class _Pts:
+    def __init__(self, pts, tabulated):
+        self.pts, self._table = pts, (object() if tabulated else None)
+
+
+def bench_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from verifiable_mpc_amd import parallel
+    n = 9
+    rng = random.Random(77)
+    exps = [rng.randrange(1, ed.ELL) for _ in range(n)]
+    pts = [ed.pt_repeat(ed.BASE, e) for e in exps]
+    vecs = [[rng.randrange(ed.ELL) for _ in range(n)] for _ in range(3)]
+    idx = parallel.cyclic_indices(n, world, rank)
+    shard = parallel.ShardedMsm(None, world, rank, dist, torch, backend=BatchOracleBackend())
+    assert shard.collective and shard.n_slots == 3
+    local = [[v[i] for i in idx] for v in vecs]
+    want = [ed.pt_affine(ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(v, exps)) % ed.ELL)) for v in vecs]
+    ok = True
+    # batch 3 over "tabulated" generators, three launches in flight; 7 steps = launches of 3, 3, 1
+    res, which = bench.run_steps(shard, 7, local, _Pts([pts[i] for i in idx], True), depth=3, batch=3)
+    ok &= which == [0] and res == [want[0]]
+    res, which = bench.run_steps(shard, 6, local, _Pts([pts[i] for i in idx], True), depth=3, batch=3)
+    ok &= which == [0, 1, 2] and res == want
+    # one commitment per launch (plain generators): cycles through the vectors
+    res, which = bench.run_steps(shard, 5, local, _Pts([pts[i] for i in idx], False), depth=3, batch=3)
+    ok &= which == [4 % 3] and res == [want[1]]
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_run_steps_collective_world2():
+    """bench.py's launch/refill loop with a collective: batch 3, three slots, two ranks - every rank must enter the
+    all-gathers in the same order and end with the commitment over BOTH shards"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(bench_worker, args=(world, free_port(), ret), nprocs=world, join=True)
+    assert ret[0] and ret[1]

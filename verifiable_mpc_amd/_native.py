@@ -37,6 +37,8 @@ SYMBOLS = [
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
     "vmpc_bn256_validate_dev", "vmpc_bn256_fixed_base_dev",
     "vmpc_msm_table_fold_dev", "vmpc_msm_table_fold_table_dev", "vmpc_p4_create", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_run_compact", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
+    "vmpc_comm_unique_id", "vmpc_comm_create_rccl", "vmpc_comm_create_callback", "vmpc_comm_destroy", "vmpc_comm_info",
+    "vmpc_comm_allgather_dev", "vmpc_comm_points_allsum_dev", "vmpc_p4_create_sharded", "vmpc_gather_probe_dev", "vmpc_bn256_madd_rate",
 ]
 
 
@@ -47,6 +49,8 @@ class VmpcError(RuntimeError):
 
 
 _lib = None
+# vmpc_exchange_fn (include/vmpc.h): int fn(void *user, const void *mine, void *gathered, size_t bytes_per_rank)
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 
 
 def load_library():
@@ -130,6 +134,16 @@ def load_library():
         "vmpc_bn256_table_bytes": (i32, [i32, sz, vp]),
         "vmpc_bn256_table_build_dev": (i32, [vp, i32, vp, sz, vp]),
         "vmpc_bn256_table_msm_dev": (i32, [vp, i32, vp, sz, vp, sz, vp, vp]),
+        "vmpc_comm_unique_id": (i32, [vp]),
+        "vmpc_comm_create_rccl": (i32, [vp, vp, i32, i32, ctypes.POINTER(vp)]),
+        "vmpc_comm_create_callback": (i32, [i32, i32, EXCHANGE_FN, vp, ctypes.POINTER(vp)]),
+        "vmpc_comm_destroy": (i32, [vp]),
+        "vmpc_comm_info": (i32, [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]),
+        "vmpc_comm_allgather_dev": (i32, [vp, vp, vp, vp, sz]),
+        "vmpc_comm_points_allsum_dev": (i32, [vp, vp, vp, sz, vp, vp, vp]),
+        "vmpc_p4_create_sharded": (i32, [vp, vp, vp, sz, sz, i32, i32, vp, vp, vp, ctypes.POINTER(vp)]),
+        "vmpc_bn256_madd_rate": (i32, [vp, i32, i32, vp]),
+        "vmpc_gather_probe_dev": (i32, [vp, vp, sz, sz, i32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the export is missing
@@ -416,6 +430,13 @@ class Context:
                "vmpc_ed25519_madd_rate")
         return r.value
 
+    def bn256_madd_rate(self, group, iters=200):
+        """Jacobian mixed additions per second (group 1: F_p, 2: F_p^2) of the register-resident probe"""
+        r = ctypes.c_double(0.0)
+        _check(self.lib.vmpc_bn256_madd_rate(self.handle, int(group), int(iters), ctypes.byref(r)),
+               "vmpc_bn256_madd_rate")
+        return r.value
+
     def profile(self, enable=True):
         _check(self.lib.vmpc_ctx_profile(self.handle, 1 if enable else 0), "vmpc_ctx_profile")
 
@@ -501,6 +522,13 @@ class Context:
         _check(self.lib.vmpc_points_sum_dev(self.handle, ctypes.c_void_p(ext_ptr), m,
                                             ctypes.c_void_p(out_ext_ptr),
                                             ctypes.c_void_p(out_affine_ptr)), "vmpc_points_sum_dev")
+
+    def gather_probe(self, table_ptr, table_lines, n_gathers, mode=0, seed=1, timed=True):
+        """vmpc_gather_probe_dev: n_gathers 128-byte line reads in the bucket stage's pattern; returns ms"""
+        ms = ctypes.c_double()
+        _check(self.lib.vmpc_gather_probe_dev(self.handle, ctypes.c_void_p(table_ptr), table_lines, n_gathers, mode,
+                                              seed, ctypes.byref(ms) if timed else None), "vmpc_gather_probe_dev")
+        return ms.value
 
     def points_sum_many(self, ext_ptr, m, k, out_ext_ptr=None, out_affine_ptr=None):
         _check(self.lib.vmpc_points_sum_many_dev(self.handle, ctypes.c_void_p(ext_ptr), m, k,
@@ -676,16 +704,107 @@ class PendingDigests:
         return res
 
 
+class Comm:
+    """vmpc_comm: the exchange step of the multi-GPU path (all-gather of partial points + rank-ordered add).
+
+    Comm.rccl(ctx, unique_id, world, rank)      ncclAllGather on the context's stream (one process per GPU)
+    Comm.callback(world, rank, fn)               fn(mine_ptr, gathered_ptr, bytes_per_rank) moves the bytes
+    Comm.solo()                                  world = 1"""
+
+    KINDS = {0: "self", 1: "rccl", 2: "callback"}
+
+    def __init__(self, handle, world, rank, keep=None):
+        self.lib = load_library()
+        self.handle, self.world, self.rank, self._keep = handle, world, rank, keep
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _check(load_library().vmpc_comm_unique_id(buf), "vmpc_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, ctx, unique_id, world, rank):
+        h = ctypes.c_void_p()
+        _check(ctx.lib.vmpc_comm_create_rccl(ctx.handle, ctypes.create_string_buffer(bytes(unique_id), 128), world, rank,
+                                             ctypes.byref(h)), "vmpc_comm_create_rccl")
+        return cls(h, world, rank)
+
+    @classmethod
+    def callback(cls, world, rank, fn):
+        def trampoline(_user, mine, gathered, nbytes):
+            try:
+                fn(mine, gathered, nbytes)
+                return 0
+            except BaseException:       # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        cfn = EXCHANGE_FN(trampoline)
+        h = ctypes.c_void_p()
+        _check(load_library().vmpc_comm_create_callback(world, rank, cfn, None, ctypes.byref(h)),
+               "vmpc_comm_create_callback")
+        return cls(h, world, rank, keep=cfn)
+
+    @classmethod
+    def solo(cls):
+        h = ctypes.c_void_p()
+        _check(load_library().vmpc_comm_create_callback(1, 0, EXCHANGE_FN(0), None, ctypes.byref(h)),
+               "vmpc_comm_create_callback")
+        return cls(h, 1, 0)
+
+    @property
+    def kind(self):
+        k = ctypes.c_int()
+        _check(self.lib.vmpc_comm_info(self.handle, None, None, ctypes.byref(k)), "vmpc_comm_info")
+        return self.KINDS[k.value]
+
+    def allgather(self, ctx, mine_ptr, gathered_ptr, bytes_per_rank):
+        _check(self.lib.vmpc_comm_allgather_dev(self.handle, ctx.handle, ctypes.c_void_p(mine_ptr),
+                                                ctypes.c_void_p(gathered_ptr), bytes_per_rank),
+               "vmpc_comm_allgather_dev")
+
+    def points_allsum(self, ctx, mine_ptr, k, scratch_ptr, out_ext_ptr, out_affine_ptr=None):
+        """k rank-ordered sums of the ranks' partial points (enqueued on ctx's stream)"""
+        _check(self.lib.vmpc_comm_points_allsum_dev(self.handle, ctx.handle, ctypes.c_void_p(mine_ptr), k,
+                                                    ctypes.c_void_p(scratch_ptr), ctypes.c_void_p(out_ext_ptr),
+                                                    ctypes.c_void_p(out_affine_ptr) if out_affine_ptr else None),
+               "vmpc_comm_points_allsum_dev")
+
+    def close(self):
+        if self.handle:
+            self.lib.vmpc_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class P4Rounds:
     """vmpc_p4_*: the Protocol-4 prover's rounds with z_hat, L~ and the challenge products resident in HBM."""
 
-    def __init__(self, ctx, table, h_slots, k_slot, z_ptr, l_ptr):
-        self.ctx, self.table = ctx, table
+    def __init__(self, ctx, table, h_slots, k_slot, z_ptr, l_ptr, n_total=None, comm=None):
+        """comm (a Comm): `table` holds this rank's block of g_hat (vmpc_p4_create_sharded), z / L~ all N scalars"""
+        self.ctx, self.table, self.comm = ctx, table, comm
+        # the C side takes N = world * (table.n + h_slots) and reads that many scalars from z_hat and L~
+        world = comm.world if comm is not None else 1
+        assert n_total is None or n_total == world * (table.n + h_slots), \
+            "round context needs the whole tabulated vector"
         h = ctypes.c_void_p()
-        _check(ctx.lib.vmpc_p4_create(ctx.handle, ctypes.c_void_p(table.ptr), table.n, len(table.extra_bytes), table.rows,
-                                      h_slots, k_slot, ctypes.create_string_buffer(table.extra_bytes[k_slot], 64),
-                                      ctypes.c_void_p(z_ptr), ctypes.c_void_p(l_ptr), ctypes.byref(h)),
-               "vmpc_p4_create")
+        k_aff = ctypes.create_string_buffer(table.extra_bytes[k_slot], 64)
+        if comm is not None:
+            assert h_slots == 0, "a sharded CRS keeps h as the last generator of the last block"
+            _check(ctx.lib.vmpc_p4_create_sharded(ctx.handle, comm.handle, ctypes.c_void_p(table.ptr), table.n,
+                                                  len(table.extra_bytes), table.rows, k_slot, k_aff,
+                                                  ctypes.c_void_p(z_ptr), ctypes.c_void_p(l_ptr), ctypes.byref(h)),
+                   "vmpc_p4_create_sharded")
+        else:
+            _check(ctx.lib.vmpc_p4_create(ctx.handle, ctypes.c_void_p(table.ptr), table.n, len(table.extra_bytes),
+                                          table.rows, h_slots, k_slot, k_aff, ctypes.c_void_p(z_ptr),
+                                          ctypes.c_void_p(l_ptr), ctypes.byref(h)), "vmpc_p4_create")
         self.handle = h
 
     def round(self, prev_challenge=None):

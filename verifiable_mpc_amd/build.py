@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvmpc_hip.so")
-UNITS = ["api", "msm", "msm_sort", "exact", "frvec", "format", "sha256", "bn256", "fold_jump", "prover"]
+UNITS = ["api", "msm", "msm_sort", "exact", "frvec", "format", "sha256", "bn256", "fold_jump", "prover", "comm", "probe"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("VMPC_EXTRA_FLAGS", "").split()
 
@@ -43,7 +43,7 @@ def build(force=False, verbose=True):
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_unit, UNITS))
     if force or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

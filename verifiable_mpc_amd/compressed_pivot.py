@@ -238,11 +238,15 @@ class _Transcript:
 
 # ---- Protocol 4 --------------------------------------------------------------------------------------
 
-def _tabulated(g_hat, k):
+def _tabulated(g_hat, k, whole=False):
     """g_hat and k live in one fixed-base table: commitments over the UNFOLDED g_hat are then cheaper
-    than folding it (a 2^19-element fold costs as much as eight 2^20-term table commitments)"""
+    than folding it (a 2^19-element fold costs as much as eight 2^20-term table commitments).
+    whole: g_hat must be ALL of the table's generators (+ its leading extras), not a strict prefix - the
+    round context (vmpc_p4_create) derives N from the table, a prefix has to take the round-by-round path."""
     t = getattr(g_hat, "_table", None)
     if t is None:
+        return False
+    if whole and len(g_hat) - g_hat._table_tail != t.n:
         return False
     slot = t.extra_index(k)
     return slot is not None and slot >= g_hat._table_tail
@@ -349,7 +353,8 @@ def _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, tran
     table = g_hat._table
     assert L_tilde.constant == 0, "Next line assumes L_tilde is a linear form, not affine form."
     Lc = _coeffs_dev(L_tilde)
-    rounds = P4Rounds(g_hat.ctx, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, Lc.ptr)
+    rounds = P4Rounds(g_hat.ctx, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, Lc.ptr,
+                      n_total=len(z_hat))
     try:
         n_rounds = len(z_hat).bit_length() - 2
         if NATIVE_CHAIN:
@@ -390,7 +395,7 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
         half = m // 2
         if tail_cs is None and NATIVE_ROUNDS and transcript.mode == "compact" and isinstance(z_hat, ScalarVector) \
                 and isinstance(L_tilde.coeffs, ScalarVector) and len(g_hat) == m and m >= 4 and m & (m - 1) == 0 \
-                and _tabulated(g_hat, k):
+                and _tabulated(g_hat, k, whole=True):
             return _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, transcript)
         z_l, z_r, gamma_a, gamma_b = _round_prover_scalars(L_tilde, z_hat, half, gf)
         logger_cp.debug("Calculate A_i, B_i.")

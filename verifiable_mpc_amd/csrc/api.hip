@@ -74,6 +74,10 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
 
 extern "C" int vmpc_ctx_destroy(vmpc_ctx *ctx) {
     if (!ctx) return VMPC_E_INVAL;
+    if (ctx->p4_pool_busy) {        // a live round context holds this context's arena and a pointer to it
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "vmpc_ctx_destroy: a vmpc_p4 of this context is still alive");
+        return VMPC_E_INVAL;
+    }
     VMPC_IGNORE(hipSetDevice(ctx->device));
     VMPC_IGNORE(hipStreamSynchronize(ctx->stream));
     for (auto &s : ctx->stages)

@@ -18,6 +18,17 @@
 // table, and the remaining rounds run on that - a round over 2^15 generators is bound by launch latency
 // (0.4 ms), one over the unfolded 2^20 by its 16 M bucket additions (1.7 ms).
 //
+// Sharded form (vmpc_p4_create_sharded): g_hat is cut into `world` CONTIGUOUS blocks, one per rank; this rank's table
+// holds block `rank`.  z_hat and L~ are replicated (their folds are 2N scalar operations over the whole proof), the
+// per-generator scalars (challenge products, v_a, v_b) exist for the rank's block only, A_i and B_i are partial sums
+// followed by ONE exchange per round (vmpc_comm_points_allsum_dev: all-gather of 2 x 128 bytes per rank on the
+// context's stream + rank-ordered add), after which every rank holds the same bits and derives the same challenge.
+// The jump stays local: index j + b N/2^k of the k-round fold lies in block (j + b N/2^k) / (N/world), so with
+// 2^k >= world a block holds 2^k / world whole strides and the rank folds ITS strides into a partial vector
+//       part_r[j] = sum_{b in the rank's strides} s_b g[j + b N/2^k],       g^(k)[j] = sum_r part_r[j];
+// the parts are never added up: later rounds commit to part_r with the full (short, replicated) scalar vector and
+// the exchange sums the partial commitments as before.  No generator ever crosses a link.
+//
 // Built entirely on the public C-ABI of this library (include/vmpc.h) plus the host-callable field code.
 #include <stdlib.h>
 
@@ -123,7 +134,7 @@ k_p4_extras(const uint32_t *__restrict__ partials, int n_partials, const uint32_
         __syncthreads();
     }
     for (int s = threadIdx.x; s < n_extra; s += P4_BLOCK) {
-        fr e = fr_zero();
+        fr e = fr_zero();       // k_slot < 0: this rank does not add the k term (sharded prover: rank 0 does)
         if (s < h_slots) e = p4_ld(v + 8 * (table_n + s));
         else if (s == k_slot) e = p4_ld(lds);
         p4_st(ex + 8 * s, e);
@@ -156,6 +167,13 @@ struct vmpc_p4 {
     bool arena_pooled;
     std::vector<char *> extra;        // buffers of second and later jumps
     uint8_t k_host[64];
+    // sharded form: this rank's block of g_hat is [block_lo, block_lo + block_n) until the generators are folded,
+    // afterwards every rank holds a full-length partial vector (block_lo = 0)
+    vmpc_comm *comm;
+    int world, rank;
+    size_t block_lo, block_n;
+    char *mine, *gathered;            // 2 partial points of this rank; world x 2 gathered ones
+    bool poisoned;                    // a call failed after the fold state advanced: only destroy is valid
 };
 
 // All device buffers of a context are carved from one arena that stays with the vmpc_ctx between proofs
@@ -180,23 +198,36 @@ static int p4_jump_rows(size_t m_out) {
 
 static size_t p4_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
-// table: fixed-base table over table_n generators g followed by table_extra extras, of which extras
-// 0 .. h_slots-1 are the tail of g_hat (g_hat = g || h: h_slots = 1) and extra `k_slot` is k.
-// z_hat, L_tilde: N = table_n + h_slots scalars each (device, 32-byte canonical residues), N a power of two >= 4.
-extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
-                              int h_slots, int k_slot, const uint8_t k_affine[64], const void *z_hat,
-                              const void *L_tilde, vmpc_p4 **out) {
+static int p4_log2(size_t v) {
+    int l = 0;
+    while (((size_t)1 << l) < v) l++;
+    return l;
+}
+
+// table: fixed-base table over table_n generators followed by table_extra extras, of which extras
+// 0 .. h_slots-1 are the tail of g_hat (g_hat = g || h: h_slots = 1) and extra `k_slot` is k.  The table's
+// generators (and tail) are block `rank` of g_hat's `world` equal blocks (comm = NULL: the whole of g_hat).
+// z_hat, L_tilde: N = world * (table_n + h_slots) scalars each (device, canonical residues), N a power of two >= 4.
+static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t table_n, size_t table_extra, int rows,
+                     int h_slots, int k_slot, const uint8_t k_affine[64], const void *z_hat, const void *L_tilde,
+                     vmpc_p4 **out) {
     if (!ctx || !table || !z_hat || !L_tilde || !out || !k_affine || h_slots < 0 || k_slot < h_slots ||
         (size_t)k_slot >= table_extra)
         return VMPC_E_INVAL;
-    const size_t N = table_n + (size_t)h_slots;
-    if (N < 4 || (N & (N - 1))) return VMPC_E_INVAL;
+    int world = 1, rank = 0;
+    if (comm) VMPC_CHECK(vmpc_comm_info(comm, &world, &rank, nullptr));
+    // the tail slots (h) belong to the last block only; a sharded CRS keeps h as that block's last generator
+    if (world < 1 || (world & (world - 1)) || (world > 1 && h_slots != 0)) return VMPC_E_INVAL;
+    const size_t block_n = table_n + (size_t)h_slots;
+    const size_t N = block_n * (size_t)world;
+    if (N < 4 || (N & (N - 1)) || block_n < 1) return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     vmpc_p4 *p = new vmpc_p4();
     p->z[0] = p->z[1] = p->L[0] = p->L[1] = p->products = p->va = p->vb = p->ex_a = p->ex_b = p->out = nullptr;
-    p->k_aff = p->jump_g = p->jump_table = p->partials = nullptr;
+    p->k_aff = p->jump_g = p->jump_table = p->partials = p->mine = p->gathered = nullptr;
     p->arena = nullptr;
     p->arena_pooled = false;
+    p->poisoned = false;
     p->dots_grid = 0;
     p->round = p->committed = p->cur = p->log2_n = 0;
     p->jump_k = 5;                               // VMPC_P4_JUMP=0 keeps every round on the unfolded CRS
@@ -205,6 +236,11 @@ extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, 
     p->jump_min = (size_t)1 << 18;
     if (const char *e = getenv("VMPC_P4_JUMP_MIN_LOG2")) p->jump_min = (size_t)1 << atoi(e);
     p->ctx = ctx;
+    p->comm = comm;
+    p->world = world;
+    p->rank = rank;
+    p->block_lo = (size_t)rank * block_n;
+    p->block_n = block_n;
     p->table = table;
     p->table_n = table_n;
     p->table_extra = table_extra;
@@ -212,11 +248,12 @@ extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, 
     p->h_slots = h_slots;
     p->k_slot = k_slot;
     p->m = N;
-    while (((size_t)1 << p->log2_n) < N) p->log2_n++;
+    p->log2_n = p4_log2(N);
     p->total_rounds = p->log2_n - 1;
-    // jump buffers, if this CRS is large enough to be folded (sizes of the FIRST jump; a later one is smaller)
+    // jump buffers, if this rank's block is large enough to be folded (sizes of the FIRST jump; a later one is
+    // smaller): the block must hold at least two strides of the k-round fold (2^k >= 2 world)
     p->jump_g_bytes = p->jump_table_bytes = 0;
-    if (p->jump_k && N >= p->jump_min && p->log2_n - p->jump_k >= 2) {
+    if (p->jump_k && block_n >= p->jump_min && p->log2_n - p->jump_k >= 2 && ((size_t)1 << p->jump_k) >= 2 * (size_t)world) {
         const size_t m_out = N >> p->jump_k;
         p->jump_g_bytes = 64 * m_out;
         if (vmpc_msm_table_bytes(m_out, 1, p4_jump_rows(m_out), &p->jump_table_bytes) != VMPC_OK) {
@@ -224,11 +261,12 @@ extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, 
             return VMPC_E_INVAL;
         }
     }
-    const size_t sizes[] = {32 * N, 32 * N, 32 * N, 32 * N, 32 * N, 32 * N, 32 * N, 32 * table_extra + 32,
+    const size_t per_gen = 32 * block_n;          // products, v_a, v_b: one entry per local column (fewer after a jump)
+    const size_t sizes[] = {32 * N, 32 * N, 32 * N, 32 * N, per_gen, per_gen, per_gen, 32 * table_extra + 32,
                             32 * table_extra + 32, 256, (size_t)2 * P4_MAX_GRID * 32, 64, p->jump_g_bytes,
-                            p->jump_table_bytes};
+                            p->jump_table_bytes, 256, (size_t)256 * world};
     char **slots[] = {&p->z[0], &p->z[1], &p->L[0], &p->L[1], &p->products, &p->va, &p->vb, &p->ex_a,
-                      &p->ex_b, &p->out, &p->partials, &p->k_aff, &p->jump_g, &p->jump_table};
+                      &p->ex_b, &p->out, &p->partials, &p->k_aff, &p->jump_g, &p->jump_table, &p->mine, &p->gathered};
     size_t total = 0;
     for (size_t b : sizes) total += p4_align(b);
     if (!ctx->p4_pool_busy) {
@@ -273,6 +311,19 @@ extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, 
     return VMPC_OK;
 }
 
+extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                              int h_slots, int k_slot, const uint8_t k_affine[64], const void *z_hat,
+                              const void *L_tilde, vmpc_p4 **out) {
+    return p4_create(ctx, nullptr, table, table_n, table_extra, rows, h_slots, k_slot, k_affine, z_hat, L_tilde, out);
+}
+
+extern "C" int vmpc_p4_create_sharded(vmpc_ctx *ctx, vmpc_comm *comm, const void *block_table, size_t block_n,
+                                      size_t table_extra, int rows, int k_slot, const uint8_t k_affine[64],
+                                      const void *z_hat, const void *L_tilde, vmpc_p4 **out) {
+    if (!comm) return VMPC_E_INVAL;
+    return p4_create(ctx, comm, block_table, block_n, table_extra, rows, 0, k_slot, k_affine, z_hat, L_tilde, out);
+}
+
 extern "C" int vmpc_p4_destroy(vmpc_p4 *p) {
     if (!p) return VMPC_E_INVAL;
     (void)hipSetDevice(p->ctx->device);
@@ -312,11 +363,22 @@ static int p4_fold_dots(vmpc_p4 *p, const uint8_t *c) {
     return VMPC_OK;
 }
 
+// the jump is due: enough pending challenges, a block worth folding, and at least two of the fold's strides in it
+static bool p4_jump_due(const vmpc_p4 *p) {
+    const size_t spread = p->block_n < ((size_t)1 << p->log2_n) ? (size_t)p->world : 1;   // ranks g_hat is cut over
+    return p->jump_k && (int)p->pending.size() == p->jump_k && p->block_n >= p->jump_min &&
+           p->log2_n - p->jump_k >= 2 && ((size_t)1 << p->jump_k) >= 2 * spread;
+}
+
 // Apply the pending challenges to the generators: g' = k folds of the table's vector, then a table for g' || k.
+// Sharded: the rank folds the strides its block holds into a partial vector of the same length (see the top).
 static int p4_jump(vmpc_p4 *p) {
     vmpc_ctx *ctx = p->ctx;
     const int k = (int)p->pending.size();
     const size_t N = (size_t)1 << p->log2_n, m_out = N >> k;
+    const bool spread = p->block_n < N;                       // g_hat still in blocks over the ranks
+    const int k_loc = k - (spread ? p4_log2((size_t)p->world) : 0);
+    const size_t b0 = spread ? (size_t)p->rank << k_loc : 0;  // first stride of this rank's block
     // s_b = prod_i (c_i if bit (k - i) of b is 0), i = 1..k: the products k_fr_tail_scalars_inc keeps per generator
     std::vector<uint8_t> s((size_t)32 << k);
     for (int b = 0; b < (1 << k); b++) {
@@ -326,6 +388,7 @@ static int p4_jump(vmpc_p4 *p) {
             if (!((b >> (k - 1 - i)) & 1)) v = fr_mul(v, fr_load((const uint32_t *)p->pending[i].data()));
         fr_store((uint32_t *)(s.data() + 32 * b), v);
     }
+    const uint8_t *s_loc = s.data() + 32 * b0;
     const int rows = p4_jump_rows(m_out);
     size_t bytes = 0;
     VMPC_CHECK(vmpc_msm_table_bytes(m_out, 1, rows, &bytes));
@@ -348,11 +411,11 @@ static int p4_jump(vmpc_p4 *p) {
             ctx->p4_kblock_rows = rows;
             memcpy(ctx->p4_kblock_key, p->k_host, 64);
         }
-        VMPC_CHECK(vmpc_table_fold_table_with_block(ctx, p->table, p->table_n, p->table_extra, p->rows, N, k, s.data(), 1,
-                                                    rows, ctx->p4_kblock, t));
+        VMPC_CHECK(vmpc_table_fold_table_with_block(ctx, p->table, p->table_n, p->table_extra, p->rows, p->block_n, k_loc,
+                                                    s_loc, 1, rows, ctx->p4_kblock, t));
     } else {
-        VMPC_CHECK(vmpc_msm_table_fold_table_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, N, k, s.data(),
-                                                 p->k_aff, 1, rows, t));
+        VMPC_CHECK(vmpc_msm_table_fold_table_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, p->block_n, k_loc,
+                                                 s_loc, p->k_aff, 1, rows, t));
     }
     p->table = t;
     p->table_n = m_out;
@@ -361,6 +424,8 @@ static int p4_jump(vmpc_p4 *p) {
     p->h_slots = 0;
     p->k_slot = 0;
     p->log2_n -= k;
+    p->block_lo = 0;                  // every rank now holds a full-length (partial) vector
+    p->block_n = m_out;
     p->pending.clear();
     return VMPC_OK;
 }
@@ -386,43 +451,41 @@ static void p4_affine_pair(const uint8_t ext[256], uint8_t out_a[64], uint8_t ou
     }
 }
 
-// One round: prev_challenge = the challenge derived from the PREVIOUS call's A, B (NULL on the first call).
-// Returns A_i, B_i as 64-byte affine points.  Synchronises the context's stream (the results are needed
-// for the next hash).
-extern "C" int vmpc_p4_round(vmpc_p4 *p, const uint8_t prev_challenge[32], uint8_t out_A[64], uint8_t out_B[64]) {
-    // the first call has no challenge yet, every later one needs the previous round's; log2(N) - 1 rounds in all
-    if (!p || !out_A || !out_B || (p->committed == 0) != (prev_challenge == nullptr) ||
-        (prev_challenge && p->m / 2 < 4))
-        return VMPC_E_INVAL;
+static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
     vmpc_ctx *ctx = p->ctx;
-    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
-    // fold with the previous challenge; exponents of k: L~(0 || z_l) and L~(z_r || 0) (compressed_pivot.py:41-42)
-    VMPC_CHECK(p4_fold_dots(p, prev_challenge));
-    if (p->jump_k && (int)p->pending.size() == p->jump_k && ((size_t)1 << p->log2_n) >= p->jump_min &&
-        p->log2_n - p->jump_k >= 2)
-        VMPC_CHECK(p4_jump(p));
+    if (p4_jump_due(p)) VMPC_CHECK(p4_jump(p));
     const int t = (int)p->pending.size();                   // challenges the table's generators have not seen
-    const size_t N = (size_t)1 << p->log2_n;
     const char *z = p->z[p->cur];
     hipStream_t st = ctx->stream;
-    // commitment scalars over the unfolded g_hat: challenge products x the (shifted) witness halves
+    // commitment scalars over the unfolded g_hat (this rank's block of it): challenge products x the (shifted)
+    // witness halves
     static const uint8_t zero[32] = {0};
-    VMPC_CHECK(vmpc_fr_tail_scalars_block_dev(ctx, t ? p->pending.back().data() : zero, t, p->log2_n, z, 0, N,
-                                              p->products, p->va, p->vb));
-    // extras: the tail of g_hat (h) lives among them, and k with the inner products as exponents
+    VMPC_CHECK(vmpc_fr_tail_scalars_block_dev(ctx, t ? p->pending.back().data() : zero, t, p->log2_n, z, p->block_lo,
+                                              p->block_n, p->products, p->va, p->vb));
+    // extras: the tail of g_hat (h) lives among them, and k with the inner products as exponents (rank 0 only:
+    // the k term must enter the sum over the ranks once)
     {
         vmpc_stage_scope s(ctx, "p4_extras");
         k_p4_extras<<<2, P4_BLOCK, 0, st>>>((const uint32_t *)p->partials, (int)p->dots_grid, (const uint32_t *)p->va,
-                                           (const uint32_t *)p->vb, p->table_n, p->h_slots, p->k_slot,
-                                           (int)p->table_extra, (uint32_t *)p->ex_a, (uint32_t *)p->ex_b);
+                                           (const uint32_t *)p->vb, p->table_n, p->h_slots,
+                                           p->rank == 0 ? p->k_slot : -1, (int)p->table_extra, (uint32_t *)p->ex_a,
+                                           (uint32_t *)p->ex_b);
         VMPC_KERNEL_CHECK();
     }
     const void *sc[2] = {p->va, p->vb}, *ex[2] = {p->ex_a, p->ex_b};
     // the recombination kernel writes the 2 x 128 bytes straight into pinned host memory: no copy command at all
     // (a pageable destination costs a staged copy, 20 us a round)
     VMPC_CHECK(vmpc_pinned_reserve(ctx, 0));
-    VMPC_CHECK(vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
-                                        ctx->pin_out_dev, nullptr));
+    if (p->comm) {
+        // partial sums over this rank's block, then the round's one exchange: all-gather + rank-ordered add on
+        // the same stream, the result lands in the pinned block
+        VMPC_CHECK(vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
+                                            p->mine, nullptr));
+        VMPC_CHECK(vmpc_comm_points_allsum_dev(p->comm, ctx, p->mine, 2, p->gathered, ctx->pin_out_dev, nullptr));
+    } else {
+        VMPC_CHECK(vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
+                                            ctx->pin_out_dev, nullptr));
+    }
     const uint8_t *ext = (const uint8_t *)ctx->pin_out;
     VMPC_CHECK(vmpc_ctx_sync(ctx));
     p->committed++;
@@ -430,9 +493,27 @@ extern "C" int vmpc_p4_round(vmpc_p4 *p, const uint8_t prev_challenge[32], uint8
     return VMPC_OK;
 }
 
+// One round: prev_challenge = the challenge derived from the PREVIOUS call's A, B (NULL on the first call).
+// Returns A_i, B_i as 64-byte affine points.  Synchronises the context's stream (the results are needed
+// for the next hash).  A failure after the fold has advanced the state leaves the context unusable (every
+// further call returns VMPC_E_INVAL; destroy it).
+extern "C" int vmpc_p4_round(vmpc_p4 *p, const uint8_t prev_challenge[32], uint8_t out_A[64], uint8_t out_B[64]) {
+    // the first call has no challenge yet, every later one needs the previous round's; log2(N) - 1 rounds in all
+    if (!p || p->poisoned || !out_A || !out_B || (p->committed == 0) != (prev_challenge == nullptr) ||
+        (prev_challenge && p->m / 2 < 4))
+        return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
+    // fold with the previous challenge; exponents of k: L~(0 || z_l) and L~(z_r || 0) (compressed_pivot.py:41-42)
+    VMPC_CHECK(p4_fold_dots(p, prev_challenge));      // rejects a non-canonical challenge before touching the state
+    const int rc = p4_round_body(p, out_A, out_B);
+    if (rc != VMPC_OK) p->poisoned = true;
+    return rc;
+}
+
 // After the last round's challenge: fold once more and hand back z' (2 x 32 bytes, compressed_pivot.py:77-79).
 extern "C" int vmpc_p4_finish(vmpc_p4 *p, const uint8_t last_challenge[32], uint8_t out_z_prime[64]) {
-    if (!p || !last_challenge || !out_z_prime || p->m != 4 || p->committed != p->total_rounds) return VMPC_E_INVAL;
+    if (!p || p->poisoned || !last_challenge || !out_z_prime || p->m != 4 || p->committed != p->total_rounds)
+        return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
     VMPC_CHECK(p4_fold_dots(p, last_challenge));
     VMPC_HIP_CHECK(hipMemcpyAsync(out_z_prime, p->z[p->cur], 64, hipMemcpyDeviceToHost, p->ctx->stream));

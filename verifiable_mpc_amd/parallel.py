@@ -1,5 +1,9 @@
 """Multi-GPU Pedersen commitment: one process per GPU, cyclic sharding, ONE exchange step.
 
+The exchange itself lives in the C library (include/vmpc.h, vmpc_comm_*: ncclAllGather on the MSM's own
+stream + rank-ordered add); torch.distributed only bootstraps it (make_comm) - or carries the bytes when no
+`comm` is given.
+
 An MSM is a sum of independent terms, so the generator / scalar vectors are sharded
 cyclically by index (rank r owns i = r mod G) and each rank runs the local
 Pippenger MSM on its shard.  The only data-path collective is an all-gather of the G partial
@@ -30,24 +34,40 @@ def shard_rows(arr, world, rank):
 class HipBackend:
     """Local MSM + ordered combine on the GPU of this process (csrc/msm.hip).
 
-    Two slots (two vmpc contexts = two streams + workspaces on the same GPU) let consecutive
+    Several slots (vmpc contexts = streams + workspaces on the same GPU) let consecutive
     commitments overlap: the latency-bound tail of one MSM (bucket reduction, Horner chain)
-    runs next to the throughput-bound head of the next."""
+    runs next to the throughput-bound head of the next.
 
-    def __init__(self, ctx, torch, n_slots=None):
+    comm (verifiable_mpc_amd._native.Comm): the exchange and the rank-ordered add are enqueued by the C library
+    on the slot's own stream right behind the partial sum (vmpc_comm_points_allsum_dev) - no host
+    synchronisation between the MSM and the all-gather, and the slots' exchanges overlap like their MSMs.
+    Without it the exchange goes through torch.distributed (ShardedMsm.finish)."""
+
+    def __init__(self, ctx, torch=None, n_slots=None, comm=None):
         import os
         from .device import get_aux_context
         if n_slots is None:
             n_slots = int(os.environ.get("VMPC_MSM_SLOTS", "3"))
-        self.torch = torch
+        self.torch, self.comm = torch, comm
         self.ctxs = [ctx] + [get_aux_context(10 + i) for i in range(max(0, n_slots - 1))]
-        # torch's fills run on torch's current stream, which the vmpc streams (hipStreamNonBlocking) are
-        # not ordered with: finish them before the first MSM writes into these buffers
         self.max_batch = 16
-        self.partial_bufs = [torch.zeros(128 * self.max_batch, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
-        self.combine_bufs = [torch.zeros(128 * self.max_batch, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
+        world = comm.world if comm is not None else 1
+        if comm is not None or torch is None:
+            self._owners = [[c.alloc(128 * self.max_batch), c.alloc(128 * self.max_batch),
+                             c.alloc(128 * self.max_batch * world)] for c in self.ctxs]
+            self.partial_ptrs = [o[0].ptr for o in self._owners]
+            self.combine_ptrs = [o[1].ptr for o in self._owners]
+            self.scratch_ptrs = [o[2].ptr for o in self._owners]
+            self.partial_bufs = None
+        else:
+            # torch's fills run on torch's current stream, which the vmpc streams (hipStreamNonBlocking) are
+            # not ordered with: finish them before the first MSM writes into these buffers
+            self.partial_bufs = [torch.zeros(128 * self.max_batch, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
+            self._owners = [torch.zeros(128 * self.max_batch, dtype=torch.uint8, device="cuda") for _ in self.ctxs]
+            self.partial_ptrs = [t.data_ptr() for t in self.partial_bufs]
+            self.combine_ptrs = [t.data_ptr() for t in self._owners]
+            torch.cuda.current_stream().synchronize()
         self.batch_of = [1] * len(self.ctxs)
-        torch.cuda.current_stream().synchronize()
 
     @property
     def n_slots(self):
@@ -66,16 +86,24 @@ class HipBackend:
             assert table is not None and points._table_tail == 0 and 1 <= len(scalars) <= self.max_batch
             self.batch_of[slot] = len(scalars)
             ctx.msm_table_batch(table.ptr, table.n, len(table.extra_bytes), [s.ptr for s in scalars], len(scalars[0]),
-                                None, self.partial_bufs[slot].data_ptr(), None, rows=table.rows)
+                                None, self.partial_ptrs[slot], None, rows=table.rows)
             return
         self.batch_of[slot] = 1
         if table is not None and points._table_tail == 0 and len(scalars) <= table.n:
             # generators held in prepared form (PointVector.precompute): no per-call point preparation
             ctx.msm_table(table.ptr, table.n, len(table.extra_bytes), scalars.ptr, len(scalars), None,
-                          self.partial_bufs[slot].data_ptr(), None, rows=table.rows)
+                          self.partial_ptrs[slot], None, rows=table.rows)
             return
-        ctx.msm(scalars.ptr, points.affine_ptr, len(scalars), None, None, 0,
-                self.partial_bufs[slot].data_ptr(), None)
+        ctx.msm(scalars.ptr, points.affine_ptr, len(scalars), None, None, 0, self.partial_ptrs[slot], None)
+
+    def enqueue_allsum(self, slot):
+        """the single curve-point exchange + ordered add of this slot's batch, behind its MSM on its stream"""
+        self.comm.points_allsum(self.ctxs[slot], self.partial_ptrs[slot], self.batch_of[slot], self.scratch_ptrs[slot],
+                                self.combine_ptrs[slot])
+
+    def allsum_result(self, slot):
+        self.ctxs[slot].sync()
+        return self._points(self.ctxs[slot], self.combine_ptrs[slot], self.batch_of[slot])
 
     def wait(self, slot):
         self.ctxs[slot].sync()
@@ -90,12 +118,14 @@ class HipBackend:
 
     def affine_result(self, slot):
         self.ctxs[slot].sync()
-        return self._points(self.ctxs[slot], self.partial_bufs[slot].data_ptr(), self.batch_of[slot])
+        return self._points(self.ctxs[slot], self.partial_ptrs[slot], self.batch_of[slot])
 
     def partial_tensor(self, slot):
         return self.partial_bufs[slot][:128 * self.batch_of[slot]]
 
     def new_gather_buffer(self, world):
+        if self.torch is None or self.comm is not None:
+            return None
         buf = self.torch.zeros((world, 128 * self.max_batch), dtype=self.torch.uint8, device="cuda")
         self.torch.cuda.current_stream().synchronize()
         return buf
@@ -105,29 +135,34 @@ class HipBackend:
         # overwriting another commitment in flight.  `gathered` holds world x batch points (rank-major): one
         # rank-ordered sum per commitment of the batch
         ctx, b = self.ctxs[slot], self.batch_of[slot]
-        ctx.points_sum_many(gathered.data_ptr(), world, b, self.combine_bufs[slot].data_ptr(), None)
+        ctx.points_sum_many(gathered.data_ptr(), world, b, self.combine_ptrs[slot], None)
         ctx.sync()
-        return self._points(ctx, self.combine_bufs[slot].data_ptr(), b)
+        return self._points(ctx, self.combine_ptrs[slot], b)
 
 
 class ShardedMsm:
     """commit(scalars_shard, points_shard) -> the commitment over ALL ranks' shards.
-    launch()/finish() split the call so that up to `n_slots` commitments are in flight."""
+    launch()/finish() split the call so that up to `n_slots` commitments are in flight.
 
-    def __init__(self, ctx, world, rank, dist=None, torch=None, backend=None, force_collective=False):
-        self.world, self.rank, self.dist = world, rank, dist
-        self.backend = backend if backend is not None else HipBackend(ctx, torch)
+    Exchange, in order of preference: `comm` (the C library's own: RCCL on the MSM's stream, or a callback
+    transport) - enqueued at launch(); else torch.distributed (`dist`) at finish().  Every rank must launch and
+    finish in the same order."""
+
+    def __init__(self, ctx, world, rank, dist=None, torch=None, backend=None, force_collective=False, comm=None):
+        self.world, self.rank, self.dist, self.comm = world, rank, dist, comm
+        assert comm is None or (comm.world == world and comm.rank == rank)
+        self.backend = backend if backend is not None else HipBackend(ctx, torch, comm=comm)
         self.collective = world > 1 or force_collective
         # wait for the collective only: RCCL runs on torch's current stream; a device-wide
         # synchronize here would also drain the other commitments in flight on their own streams
         self.sync_device = None
-        if torch is not None and backend is None:
+        if torch is not None and backend is None and comm is None:
             def _wait_collective():
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
                 ev.synchronize()
             self.sync_device = _wait_collective
-        self.gathered = self.backend.new_gather_buffer(world) if self.collective else None
+        self.gathered = self.backend.new_gather_buffer(world) if self.collective and comm is None else None
 
     @property
     def n_slots(self):
@@ -135,11 +170,15 @@ class ShardedMsm:
 
     def launch(self, scalars, points, slot=0):
         self.backend.launch_partial(scalars, points, slot, want_affine=not self.collective)
+        if self.collective and self.comm is not None:
+            self.backend.enqueue_allsum(slot)
         return slot
 
     def finish(self, slot):
         if not self.collective:
             return self.backend.affine_result(slot)
+        if self.comm is not None:
+            return self.backend.allsum_result(slot)
         self.backend.wait(slot)                     # partial point is complete
         # the single curve-point exchange: G x 128 B (x the number of commitments of a batch)
         mine = self.backend.partial_tensor(slot)
@@ -155,3 +194,25 @@ class ShardedMsm:
 
     def commit(self, scalars, points):
         return self.finish(self.launch(scalars, points, 0))
+
+
+def make_comm(ctx, world, rank, dist, torch=None, transport="rccl"):
+    """The C library's communicator for this process group, bootstrapped over torch.distributed (any backend):
+    rank 0 draws the RCCL unique id and broadcasts it (transport "rccl"), or the bytes travel through
+    torch.distributed's CPU collectives, staged through host memory (transport "host": gloo - tests, or machines
+    without a direct GPU fabric)."""
+    from ._native import Comm
+    if transport == "rccl":
+        box = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return Comm.rccl(ctx, box[0], world, rank)
+    if transport != "host":
+        raise ValueError(f"unknown transport {transport!r}")
+    import torch as _torch
+
+    def exchange(mine_ptr, gathered_ptr, nbytes):
+        mine = _torch.from_numpy(ctx.download(mine_ptr, nbytes).copy())
+        out = _torch.empty(world * nbytes, dtype=_torch.uint8)
+        dist.all_gather_into_tensor(out, mine)
+        ctx.upload_into(gathered_ptr, out.numpy())
+    return Comm.callback(world, rank, exchange)

@@ -25,6 +25,15 @@ The proof is the same dict, with the same values, as
 compressed_pivot.protocol_5_prover(..., transcript="compact") and verifies with
 compressed_pivot.protocol_5_verifier.
 
+With a `comm` (verifiable_mpc_amd._native.Comm: RCCL inside a node, or a callback transport) the rounds run through
+the device-resident round context of the single-GPU prover in its sharded form (include/vmpc.h
+vmpc_p4_create_sharded, csrc/prover.hip): one C call for all rounds, the exchange enqueued on the context's own
+stream right behind the partial sums, and the fold of the generators after five rounds done block-locally - a block
+holds 2^5 / G whole strides of the fold, so a rank folds its strides into a partial vector and nothing crosses a
+link (needs 2^5 >= 2 G and blocks of >= 2^18 generators; otherwise the rounds stay on the block's table).  On one
+rank that is exactly the unsharded prover plus 20 all-gathers.  Without a comm (the `ops` stand-ins of the CPU
+tests, blocks held in one process) the rounds are driven from here, one exchange each.
+
 Everything that touches a device goes through a small `ops` object (`DeviceOps` below), so that the
 host logic - block arithmetic, which rank adds the k term, gather layout, rank-ordered combine, challenge
 derivation - also runs under `gloo` with world_size 2 on CPU, where the test supplies host `ops` built
@@ -61,7 +70,7 @@ class DeviceOps:
 
     # -- replicated scalar vectors ----------------------------------------------------------------------
     def vector(self, v):
-        return pivot._as_device(v)
+        return v if isinstance(v, ScalarVector) else ScalarVector.from_ints([pivot._residue(e) for e in v], self.ctx)
 
     def form_digest(self, L):
         return cp._form_digest(L)
@@ -143,14 +152,18 @@ class ShardedCrs:
     """g_hat = g || h in `world` blocks.  `shards` holds this process's blocks: one in the
     multi-process setting (`dist` given), all of them in loopback."""
 
-    def __init__(self, N, world, shards, h, k, dist=None, torch=None, ctx=None, ops=None):
+    def __init__(self, N, world, shards, h, k, dist=None, torch=None, ctx=None, ops=None, comm=None):
         assert N & (N - 1) == 0 and N % world == 0 and N // world >= 64, "block = whole digest chunks"
         self.N, self.world, self.shards = N, world, sorted(shards, key=lambda s: s.index)
         self.h, self.k = h, k
         self.dist, self.torch = dist, torch
         self.ops = ops or DeviceOps(ctx)
         self.ctx = getattr(self.ops, "ctx", None)
-        self.loopback = dist is None
+        # comm: the exchange runs inside the C library (one block per process, any transport); dist: through
+        # torch.distributed from here; neither: every block lives in this process
+        self.comm = comm
+        assert comm is None or (comm.world == world and len(shards) == 1 and shards[0].index == comm.rank)
+        self.loopback = dist is None and comm is None
         if self.loopback:
             assert [s.index for s in self.shards] == list(range(world)), "loopback holds every block"
         else:
@@ -161,7 +174,8 @@ class ShardedCrs:
 
     # -- construction from the exponents (tests / bench: g_i = r_i * h as create_generators does) ----
     @classmethod
-    def from_exponents(cls, h, k, exponents, world, ranks, dist=None, torch=None, ctx=None, rows=None, ops=None):
+    def from_exponents(cls, h, k, exponents, world, ranks, dist=None, torch=None, ctx=None, rows=None, ops=None,
+                       comm=None):
         """exponents: (N - 1, 32) uint8 array (the same on every rank); `ranks`: the blocks to build"""
         ops = ops or DeviceOps(ctx)
         N = len(exponents) + 1
@@ -171,7 +185,7 @@ class ShardedCrs:
             lo, hi = r * n_loc, (r + 1) * n_loc
             # the last block ends with h itself (g_hat = g || h, compressed_pivot.py:138)
             shards.append(CrsShard(r, lo, ops.make_block(h, exponents[lo:min(hi, N - 1)], hi == N, k, rows)))
-        return cls(N, world, shards, h, k, dist, torch, ctx, ops)
+        return cls(N, world, shards, h, k, dist, torch, ctx, ops, comm)
 
     # -- compact CRS digest, identical to compressed_pivot.generators_digest(g, h, k) ---------------------
     def digest(self):
@@ -179,6 +193,12 @@ class ShardedCrs:
             local = {s.index: self.ops.leaf_digests(s.points) for s in self.shards}
             if self.loopback:
                 blocks = [local[i] for i in range(self.world)]
+            elif self.comm is not None:
+                mine = local[self.shards[0].index]
+                src = self.ctx.upload(np.frombuffer(mine, np.uint8))
+                dst = self.ctx.alloc(len(mine) * self.world)
+                self.comm.allgather(self.ctx, src.ptr, dst.ptr, len(mine))
+                blocks = [self.ctx.download(dst.ptr, len(mine) * self.world).tobytes()]
             else:
                 gathered = [None] * self.world
                 self.dist.all_gather_object(gathered, local[self.shards[0].index])
@@ -195,6 +215,8 @@ class ShardedCrs:
         the commitments, identical on every rank.  One exchange for all of them: every rank contributes
         len(items) partial points of 128 bytes."""
         ops, W, K = self.ops, self.world, len(items)
+        if self.comm is not None:
+            return self._commit_blocks_comm(items)
         mine, gathered, mine_ptr, gathered_ptr = ops.buffers(W, K, None if self.loopback else self.torch)
         pending = []
         try:
@@ -214,6 +236,25 @@ class ShardedCrs:
         out = ops.combine(gathered_ptr, W, K)
         del pending
         return out
+
+    def _commit_blocks_comm(self, items):
+        """the same through the C library's exchange: partial sums, all-gather and rank-ordered add are enqueued
+        back to back on the context's stream; the host waits once, for the result"""
+        ctx, W, K, s = self.ctx, self.world, len(items), self.shards[0]
+        t = s.points._table
+        mine, scratch, res = ctx.alloc(128 * K), ctx.alloc(128 * K * W), ctx.alloc(128 * K)
+        keep = []
+        for j, (per_shard, gamma) in enumerate(items):
+            esc = ctx.upload(np.zeros(32, np.uint8))
+            if s.index == 0 and isinstance(gamma, DeviceScalar):
+                ctx.copy(esc.ptr, gamma.ptr, 32)
+            elif s.index == 0 and gamma is not None:
+                ctx.upload_into(esc.ptr, np.frombuffer(reduce_scalar(gamma).to_bytes(32, "little"), np.uint8))
+            ctx.msm_table(t.ptr, s.n, 1, per_shard[s.index].ptr, s.n, esc.ptr, mine.ptr + 128 * j, None, rows=t.rows)
+            keep.append(esc)
+        self.comm.points_allsum(ctx, mine.ptr, K, scratch.ptr, res.ptr)
+        raw = ctx.download(res.ptr, 128 * K).tobytes()
+        return [Ed25519Point.from_proj_bytes(raw[128 * j:128 * j + 96]).normalize() for j in range(K)]
 
     def commit(self, items):
         """items: [(v, gamma)] with v a full-length (N) scalar vector over g_hat"""
@@ -249,6 +290,24 @@ def protocol_5_prover(crs, P, L, y, x, gamma, gf, r, rho):
     z_hat = ops.concat(ops.axpy(c0, x, r), [gf(c0 * gamma + rho)])
     L_tilde = cp._extend_form(L, c1)
     transcript = cp._p5_setup(None, crs.k, seed, "compact", order)
+
+    if crs.comm is not None and cp.NATIVE_ROUNDS and isinstance(ops, DeviceOps):
+        # all rounds in one C call on this rank's block (vmpc_p4_create_sharded): identical A_i, B_i and challenges
+        # on every rank, one exchange per round inside the library
+        from ._native import P4Rounds
+        table = crs.shards[0].points._table
+        rounds = P4Rounds(crs.ctx, table, 0, table.extra_index(crs.k), z_hat.ptr, cp._coeffs_dev(L_tilde).ptr,
+                          n_total=crs.N, comm=crs.comm)
+        try:
+            n_rounds = crs.N.bit_length() - 2
+            _, pairs, z_prime = rounds.run_compact(transcript.state, 0, n_rounds)
+        finally:
+            rounds.close()
+        for i, (a, b) in enumerate(pairs):
+            proof["A" + str(i)] = Ed25519Point.from_affine_bytes(a)
+            proof["B" + str(i)] = Ed25519Point.from_affine_bytes(b)
+        proof["z_prime"] = [gf(v) for v in z_prime]
+        return proof
 
     log2_n = crs.N.bit_length() - 1
     n_loc = crs.N // crs.world
