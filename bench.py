@@ -264,6 +264,27 @@ def bn256_timing(vm, ctx, n_pow):
                 assert var_result == ctx.download(want.ptr, width).tobytes(), f"BN-256 {tag} MSM property check failed"
             else:
                 assert ctx.download(res.ptr, width).tobytes() == var_result, f"BN-256 {tag} table MSM differs"
+        # the bucket pass of the prepared-key sum alone, against the integer-ALU ceiling of ITS inner operation
+        # (Jacobian mixed addition on the Montgomery-form field, madd-2007-bl: 7M + 4S; G2 over F_p^2), measured
+        # in this run by a register-resident chain on every lane (vmpc_bn256_madd_rate)
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        for _ in range(3):
+            ctx.bn256_table_msm(group, table.ptr, n, ds.ptr, n, res.ptr, None)
+        stages = {k: ms / max(c, 1) for k, (ms, c) in ctx.profile_read(reset=True).items()}
+        ctx.profile(False)
+        windows = 17                                     # 256-bit scalars in signed 16-bit digits
+        peak = max(ctx.bn256_madd_rate(group, 100) for _ in range(2))
+        bucket_s = stages.get("bn_bucket", 0.0) / 1e3
+        out[f"{tag}_stages_us"] = {k: round(v * 1e3, 1) for k, v in stages.items()}
+        out[f"{tag}_alu"] = {"unit": "G mixed-additions/s", "peak": peak / 1e9,
+                             "peak_source": "vmpc_bn256_madd_rate: register-resident Jacobian mixed additions on "
+                                            "every lane, measured in this run",
+                             "mixed_additions_per_launch": n * windows,
+                             "kernel": "gk_bucket (stage bn_bucket)", "kernel_ms": bucket_s * 1e3,
+                             "achieved": n * windows / bucket_s / 1e9 if bucket_s else None,
+                             "frac": n * windows / bucket_s / peak if bucket_s else None,
+                             "whole_sum_frac": n * windows / (out[f"{tag}_prepared_key_ms"] * 1e-3) / peak}
         # algorithmic bytes per term: 32-byte scalar + affine point (64 B G1, 128 B twist)
         per_term = 32 + width
         out[f"{tag}_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_term": per_term,
@@ -355,35 +376,43 @@ def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch, comm=None):
 
 def run_steps(shard, k, scalar_vectors, pts, depth, batch):
     """k commitments, in launches of up to `batch` (prepared generators only) with up to `depth` launches in
-    flight; every result is fetched to the host.  A slot is refilled as soon as ITS launch has completed
-    (completion is polled; with a collective every rank must launch and finish in the same order).  The
+    flight; every result is fetched to the host, oldest launch first, and its slot refilled at once (with a
+    collective every rank must launch and finish in the same order anyway).  The
     commitments of one launch are over DISTINCT scalar vectors (scalar_vectors[0 .. b-1]); single launches cycle
     through the vectors.  Returns (results of the last launch, indices into scalar_vectors they belong to)."""
     per = batch if getattr(pts, "_table", None) is not None else 1
     nvec = len(scalar_vectors)
     busy, order, size, which, launched, done, last = {}, {}, {}, {}, 0, 0, None
+    trace = [] if os.environ.get("VMPC_BENCH_TRACE") else None
+    t_prev = time.perf_counter()
     while done < k:
         while launched < k and len(busy) < depth:
             slot = next(s_ for s_ in range(depth) if s_ not in busy)
             b = min(per, k - launched, nvec)
             idx = list(range(b)) if per > 1 else [launched % nvec]
+            t_l = time.perf_counter()
             busy[slot] = shard.launch([scalar_vectors[i] for i in idx] if per > 1 else scalar_vectors[idx[0]], pts, slot)
+            if trace is not None:
+                trace.append(("launch", slot, b, round((time.perf_counter() - t_l) * 1e3, 3)))
             order[slot], size[slot], which[slot] = launched, b, idx
             launched += b
-        if shard.collective:
-            # every rank must enter the all-gathers in the same order: oldest first
-            ready = [min(busy, key=lambda s_: order[s_])]
-        else:
-            ready = [s_ for s_ in busy if shard.ready(s_)]
-            if not ready:
-                if len(busy) == 1:
-                    ready = list(busy)           # nothing else to overlap with: block on it
-                else:
-                    continue
+        # Oldest launch first, always.  With a collective every rank must enter the all-gathers in the same
+        # order; without one the oldest launch is the one that completes first anyway.  (Completion used to be
+        # polled with hipStreamQuery; on this stack a stream query issued while timing events are being
+        # recorded costs ONE ~50 ms stall per process around the 250th event - scripts/loop_probe2.py -
+        # which landed in the timed region of some step counts.)
+        ready = [min(busy, key=lambda s_: order[s_])]
         for s_ in ready:
+            t_f = time.perf_counter()
             res = shard.finish(busy.pop(s_))
+            if trace is not None:
+                now = time.perf_counter()
+                trace.append(("finish", s_, round((now - t_f) * 1e3, 3), "since prev finish", round((now - t_prev) * 1e3, 3)))
+                t_prev = now
             last = (res if isinstance(res, list) else [res], which[s_])
             done += size[s_]
+    if trace is not None:
+        print("run_steps trace:", trace, file=sys.stderr, flush=True)
     return last
 
 
@@ -425,8 +454,10 @@ def main():
                          "reduction and recombination chains are paid once per batch; 1 = one commitment per launch")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one commitment in flight (default: 3 launches, on three streams of the same GPU)")
+    ap.add_argument("--depth", type=int, default=int(os.environ.get("VMPC_BENCH_DEPTH", "0")),
+                    help="launches in flight (streams of the same GPU); 0 = the measured optimum")
     ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("VMPC_BENCH_WATCHDOG_S", "1500")),
-                    help="multi-rank runs: give up (JSON line with an error entry, exit status 3) after this long")
+                    help="give up (JSON line with an error entry, exit status 3) after this long")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -442,21 +473,25 @@ def main():
     torch.cuda.set_device(device_index)
     dist = None
     state = {"line": None, "stage": "init"}
+    import threading
+    if os.environ.get("VMPC_BENCH_STACKS_AFTER_S"):          # debugging aid: Python stacks of a run that stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["VMPC_BENCH_STACKS_AFTER_S"]), repeat=True)
+
+    def give_up():
+        # a stuck kernel or collective must not look like success, nor hang the harness: report what there is
+        # and leave with a failure status
+        line = state["line"] or {"metric": "Ed25519 MSM scalar-mults/sec", "value": None, "n_gpus": world}
+        line["error"] = f"rank {rank}: no progress within {args.watchdog_s:.0f} s (stage: {state['stage']})"
+        print(json.dumps(line), flush=True)
+        os._exit(3)
+    watchdog = threading.Timer(args.watchdog_s, give_up)
+    watchdog.daemon = True
+    watchdog.start()
     if world > 1 or args.force_collective:
-        import threading
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-
-        def give_up():
-            # a stuck collective must not look like success: report what there is and leave with a failure status
-            line = state["line"] or {"metric": "Ed25519 MSM scalar-mults/sec", "value": None, "n_gpus": world}
-            line["error"] = f"rank {rank}: no progress within {args.watchdog_s:.0f} s (stage: {state['stage']})"
-            print(json.dumps(line), flush=True)
-            os._exit(3)
-        watchdog = threading.Timer(args.watchdog_s, give_up)
-        watchdog.daemon = True
-        watchdog.start()
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         else:
@@ -514,7 +549,7 @@ def main():
     if not args.variable_base:
         points = points_prepared
     shard = parallel.ShardedMsm(ctx, world, rank, dist, torch, force_collective=args.force_collective, comm=comm)
-    depth = 1 if args.no_pipeline else shard.n_slots
+    depth = 1 if args.no_pipeline else (min(args.depth, shard.n_slots) if args.depth > 0 else shard.n_slots)
 
     def steps(k, pts):
         return run_steps(shard, k, scalar_vectors, pts, depth, batch)

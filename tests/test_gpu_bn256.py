@@ -183,6 +183,13 @@ def test_compute_proof_matches_reference_fixture(vm):
     key = pn.PreparedKey(Q, evalkey)
     assert pn.compute_proof(Q, [h2i(v) for v in case["c"]], H(), key, D) == proof
     assert pn.compute_proof(Q, [h2i(v) for v in case["c"]], H(), key, None) == plain
+    # c and h handed over as (n, 32) uint8 arrays (a caller that keeps its witness out of Python ints), and
+    # scalars that are not canonical residues (negative, >= the group order)
+    c_arr = pn.scalars_to_array([h2i(v) for v in case["c"]])
+    h_arr = pn.scalars_to_array(H.coeffs)
+    assert pn.compute_proof(Q, c_arr, h_arr, key, D) == proof
+    shifted = [h2i(v) + (pn.ORDER if i % 2 else -pn.ORDER) for i, v in enumerate(case["c"])]
+    assert pn.compute_proof(Q, shifted, H(), key, D) == proof
 
 
 @pytest.mark.parametrize("gi", [0, 1])

@@ -260,8 +260,21 @@ extern "C" int vmpc_memcpy_d2d(vmpc_ctx *ctx, void *dst, const void *src, size_t
 }
 
 // ---- profiling ---------------------------------------------------------------------------------
+#define VMPC_PROFILE_EVENTS 2048
 extern "C" int vmpc_ctx_profile(vmpc_ctx *ctx, int enable) {
     if (!ctx) return VMPC_E_INVAL;
+    if (enable && ctx->event_pool.size() < VMPC_PROFILE_EVENTS) {
+        // Create the events NOW, outside whatever the caller is about to time: hipEventCreate is cheap until the
+        // runtime has to grow its pool of signals (seen: one 37-ms stall at the ~250th live event of a process,
+        // in the middle of a timed region).  2048 events = 1024 stage brackets between two profile_read calls.
+        VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+        ctx->event_pool.reserve(VMPC_PROFILE_EVENTS);
+        while (ctx->event_pool.size() < VMPC_PROFILE_EVENTS) {
+            hipEvent_t e = nullptr;
+            VMPC_HIP_CHECK(hipEventCreate(&e));
+            ctx->event_pool.push_back(e);
+        }
+    }
     ctx->profile = enable != 0;
     return VMPC_OK;
 }
@@ -277,8 +290,16 @@ static hipEvent_t take_event(vmpc_ctx *ctx) {
     return e;
 }
 
+// VMPC_DEBUG_STAGES=1 (with profiling on): every stage is announced on stderr and synchronised at its end, so a
+// kernel that never returns names itself
+static bool debug_stages() {
+    static const bool on = getenv("VMPC_DEBUG_STAGES") != nullptr;
+    return on;
+}
+
 int vmpc_stage_begin(vmpc_ctx *ctx, const char *name) {
     if (!ctx->profile) return -1;
+    if (debug_stages()) fprintf(stderr, "[vmpc] stage %s ...\n", name);
     int idx = -1;
     for (size_t i = 0; i < ctx->stages.size(); i++)
         if (strcmp(ctx->stages[i].name, name) == 0) idx = (int)i;
@@ -297,6 +318,10 @@ int vmpc_stage_begin(vmpc_ctx *ctx, const char *name) {
 void vmpc_stage_end(vmpc_ctx *ctx, int handle) {
     if (handle < 0) return;
     VMPC_IGNORE(hipEventRecord(ctx->stages[handle].pending.back().second, ctx->stream));
+    if (debug_stages()) {
+        const hipError_t e = hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[vmpc] stage %s done (%s)\n", ctx->stages[handle].name, hipGetErrorString(e));
+    }
 }
 
 extern "C" int vmpc_ctx_profile_read(vmpc_ctx *ctx, char *names, size_t names_len, double *ms,

@@ -11,11 +11,10 @@
 // explicit handling of the exceptional cases (P+P, P-P, infinity), which - unlike the complete
 // Edwards law - can occur in bucket sums.
 // Entries are affine points in Montgomery form (64 B / 128 B), accumulators Jacobian (96 B / 192 B).
-#include <vector>
-
 #include "common.h"
 #include "msm_sort.h"
 #include "sw256.h"
+#include "bn256_curve.h"
 
 #define BN_B3_MONT                                                                             \
     { 0x29d50ffdu, 0x8630a1e2u, 0x5c7373e9u, 0x583653eau, 0x1867b356u, 0xabd06066u, 0x8ace581fu,  \
@@ -28,46 +27,6 @@
       0x096c9abbu }
 static const msm_modulus BN_ORDER = {{0x57ac7261u, 0x1a2ef45bu, 0xf82b3924u, 0x2e8d8e12u, 0x6184dc21u,
                                       0xaa6fecb8u, 0x4aa387f9u, 0x8fb501e3u}};
-
-template <class F>
-struct SwCurve {
-    typedef aff<F> entry_t;
-    typedef jac<F> acc_t;
-    static constexpr int AFF_WORDS = 2 * F::WORDS;
-    static constexpr int ENTRY_WORDS = 2 * F::WORDS;
-    static constexpr int ACC_WORDS = 3 * F::WORDS;
-
-    __device__ static entry_t entry_ld(const uint32_t *p) {
-        entry_t e;
-        e.x = F::load_raw(p);
-        e.y = F::load_raw(p + F::WORDS);
-        e.inf = F::is_zero(e.x) && F::is_zero(e.y);
-        return e;
-    }
-    __device__ static void entry_st(uint32_t *p, const entry_t &e) {
-        F::store_raw(p, e.inf ? F::zero() : e.x);
-        F::store_raw(p + F::WORDS, e.inf ? F::zero() : e.y);
-    }
-    __device__ static acc_t acc_ld(const uint32_t *p) {
-        acc_t a;
-        a.X = F::load_raw(p);
-        a.Y = F::load_raw(p + F::WORDS);
-        a.Z = F::load_raw(p + 2 * F::WORDS);
-        return a;
-    }
-    __device__ static void acc_st(uint32_t *p, const acc_t &a) {
-        F::store_raw(p, a.X);
-        F::store_raw(p + F::WORDS, a.Y);
-        F::store_raw(p + 2 * F::WORDS, a.Z);
-    }
-    __device__ static acc_t identity() { return jac_identity<F>(); }
-    __device__ static acc_t madd(const acc_t &a, entry_t e, bool neg) {
-        e.y = F::select(e.y, F::neg(e.y), neg);
-        return jac_madd<F>(a, e);
-    }
-};
-typedef SwCurve<Fp1Ops> G1;
-typedef SwCurve<Fp2Ops> G2;
 
 // ---- prep: canonical affine bytes -> Montgomery-form entries ----------------------------------
 template <class C, class F>
@@ -490,59 +449,6 @@ extern "C" int vmpc_bn256_fixed_base_dev(vmpc_ctx *ctx, int group, const void *b
                                                                      (const uint32_t *)scalars, n, (uint32_t *)out_affine);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
-}
-
-// ---- ALU ceiling probe (bench.py `alu` block of the bn256 line): the bucket stage's inner operation - a Jacobian
-// mixed addition with an entry in Montgomery form - on registers only, every lane of the chip
-template <class C, class F>
-__global__ void __launch_bounds__(MSM_BLOCK)
-k_bn_madd_rate(const uint32_t *__restrict__ seed, int iters, uint32_t *__restrict__ sink) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    typename C::entry_t e = C::entry_ld(seed);            // arbitrary field elements: the generic branch runs
-    typename C::acc_t acc = C::acc_ld(seed + C::ENTRY_WORDS);
-    uint32_t w[C::ENTRY_WORDS];
-    C::entry_st(w, e);
-    w[0] ^= (uint32_t)i & 0xffu;                          // lanes differ
-    e = C::entry_ld(w);
-    for (int k = 0; k < iters; k++) acc = C::madd(acc, e, (k & 1) != 0);
-    uint32_t out[C::ACC_WORDS];
-    C::acc_st(out, acc);
-    if (out[0] == 0xffffffffu && out[1] == seed[0]) C::acc_st(sink, acc);      // keeps the chain live
-}
-
-template <class C, class F>
-static int bn_madd_rate(vmpc_ctx *ctx, int iters, double *rate) {
-    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t words = C::ENTRY_WORDS + 2 * C::ACC_WORDS;
-    VMPC_CHECK(vmpc_ws_reserve(ctx, 4 * words + 512));
-    uint32_t *buf = (uint32_t *)vmpc_ws_take(ctx, 4 * words);
-    std::vector<uint32_t> host(words);
-    for (size_t i = 0; i < words; i++) host[i] = 0x01234567u * (uint32_t)(i + 3) & 0x0fffffffu;   // < p in every limb
-    VMPC_HIP_CHECK(hipMemcpyAsync(buf, host.data(), 4 * words, hipMemcpyHostToDevice, ctx->stream));
-    VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    hipEvent_t e0, e1;
-    VMPC_HIP_CHECK(hipEventCreate(&e0));
-    VMPC_HIP_CHECK(hipEventCreate(&e1));
-    const unsigned blocks = 8u * (unsigned)ctx->cu_count;
-    uint32_t *sink = buf + C::ENTRY_WORDS + C::ACC_WORDS;
-    k_bn_madd_rate<C, F><<<blocks, MSM_BLOCK, 0, ctx->stream>>>(buf, 4, sink);     // warm-up
-    VMPC_HIP_CHECK(hipEventRecord(e0, ctx->stream));
-    k_bn_madd_rate<C, F><<<blocks, MSM_BLOCK, 0, ctx->stream>>>(buf, iters, sink);
-    VMPC_HIP_CHECK(hipEventRecord(e1, ctx->stream));
-    VMPC_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0.f;
-    VMPC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (ms <= 0.f) return VMPC_E_HIP;
-    *rate = (double)blocks * MSM_BLOCK * (double)iters / (ms * 1e-3);
-    return VMPC_OK;
-}
-
-extern "C" int vmpc_bn256_madd_rate(vmpc_ctx *ctx, int group, int iters, double *madds_per_second) {
-    if (!ctx || !madds_per_second || iters < 1 || (group != 1 && group != 2)) return VMPC_E_INVAL;
-    return group == 1 ? bn_madd_rate<G1, Fp1Ops>(ctx, iters, madds_per_second)
-                      : bn_madd_rate<G2, Fp2Ops>(ctx, iters, madds_per_second);
 }
 
 // ---- host-buffer one-shots -------------------------------------------------------------------------

@@ -200,6 +200,7 @@ class PreparedKey:
     def __init__(self, qap, evalkey, ctx=None):
         self.ctx = ctx or get_context()
         self.mid = list(qap.indices_mid)
+        self.mid_index = np.asarray(self.mid, dtype=np.int64)
         self.vectors = {}
         self.zk_missing = {}      # element -> names of zero-knowledge key points the evalkey lacks
         for name, (key_fmt, zk) in _ELEMENTS.items():
@@ -216,10 +217,40 @@ class PreparedKey:
         self.vectors["h*g1"] = _KeyVector(self.ctx, powers)
 
 
+def scalars_to_array(values):
+    """Python ints / field elements -> (n, 32) uint8 canonical residues mod the group order, as fast as the
+    interpreter allows (one to_bytes per element; the reduction only for values that need it).  (n, 32) uint8
+    arrays pass through untouched: a caller that keeps its witness in numpy pays nothing here - at 2^18 terms
+    this conversion (2 x 17 ms for c and h) is otherwise longer than the eight sums on the GPU."""
+    if isinstance(values, np.ndarray):
+        return _native.as_bytes_array(values, 32)
+    vals = values if isinstance(values, list) else list(values)
+    if not vals:
+        return np.zeros((0, 32), np.uint8)
+    if type(vals[0]) is not int:
+        vals = [int(v) for v in vals]
+    try:
+        raw = b"".join([v.to_bytes(32, "little") for v in vals])       # (negatives and values >= 2^256 raise)
+    except OverflowError:
+        raw = b"".join([(v % ORDER).to_bytes(32, "little") for v in vals])
+        return np.frombuffer(raw, np.uint8).reshape(-1, 32)
+    arr = np.frombuffer(raw, np.uint8).reshape(-1, 32)
+    big = np.nonzero(arr[:, 31] >= 0x8f)[0]          # order = 0x8fb5...: only these rows can be >= order
+    if len(big):
+        arr = arr.copy()
+        for i in big:
+            arr[i] = np.frombuffer((vals[i] % ORDER).to_bytes(32, "little"), np.uint8)
+    return arr
+
+
 def _compute_proof_prepared(key, c, h, deltas):
-    """The eight sums over a prepared key: the shared `c_mid` scalars are converted and uploaded once,
-    the sums run on three streams (their bucket reductions and recombinations are latency chains that
-    overlap the next sum's bucket pass)."""
+    """The eight sums over a prepared key.  The shared `c_mid` scalars are converted and uploaded once and the
+    seven sums over them enqueued on three streams (their bucket reductions and recombinations are latency
+    chains that overlap the next sum's bucket pass); ONLY THEN are h's coefficients converted - on the host,
+    while the GPU works through those seven - and the last sum enqueued.
+    c: indexable by qap.indices_mid (the reference's list of ints / field elements), or an (n_wires, 32) uint8
+    array of canonical residues (rows taken by index); h: the reference's polynomial (.coeffs), a list, or an
+    (len, 32) uint8 array."""
     from .device import get_aux_context
     ctx = key.ctx
     n_mid = len(key.mid)
@@ -227,7 +258,11 @@ def _compute_proof_prepared(key, c, h, deltas):
         # the dict path fails with KeyError on the first absent name (pynocchio.py:229-246)
         raise KeyError("zero-knowledge deltas given but the prepared key lacks "
                        + ", ".join(sorted(n for names in key.zk_missing.values() for n in names)))
-    head = ctx.upload(_native.ints_to_array([int(c[i]) % ORDER for i in key.mid], 32)) if n_mid else None
+    if isinstance(c, np.ndarray):
+        c_mid = np.ascontiguousarray(_native.as_bytes_array(c, 32)[key.mid_index])
+    else:
+        c_mid = scalars_to_array([c[i] for i in key.mid])
+    head = ctx.upload(c_mid) if n_mid else None
     streams = [ctx, get_aux_context(20), get_aux_context(21)]
     pending = {}
     for idx, (name, (_, zk)) in enumerate(_ELEMENTS.items()):
@@ -237,9 +272,10 @@ def _compute_proof_prepared(key, c, h, deltas):
         tail = [int(getattr(deltas, attr)) for attr, _ in zk] if deltas is not None else []
         pending[name] = key.vectors[name].launch(cctx, head, n_mid, tail)
     hv = key.vectors["h*g1"]
-    h_scalars = [int(h.coeffs[i]) for i in range(0, len(h))]
-    h_head = ctx.upload(_native.ints_to_array([s % ORDER for s in h_scalars], 32)) if h_scalars else None
-    pending["h*g1"] = hv.launch(ctx, h_head, len(h_scalars))
+    h_coeffs = h if isinstance(h, (np.ndarray, list)) else h.coeffs
+    h_arr = scalars_to_array(h_coeffs if isinstance(h_coeffs, np.ndarray) else [h_coeffs[i] for i in range(len(h))])
+    h_head = ctx.upload(h_arr) if len(h_arr) else None
+    pending["h*g1"] = hv.launch(ctx, h_head, len(h_arr))
     return {name: key.vectors[name].result(p) for name, p in pending.items()}
 
 
