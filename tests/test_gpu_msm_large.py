@@ -194,8 +194,10 @@ def test_config4_total_size_2_24_as_eight_cyclic_shards(vm):
     ctx.points_sum(gathered.ptr, world, None, out.ptr)
     ctx.sync()
     assert vm.Ed25519Point.from_affine_bytes(ctx.download(out.ptr, 64).tobytes()) == whole
-    # and a spot check of the whole against the exponent identity on a 2^16-term slice of the same vectors
-    m = 1 << 16
-    part = vm.pivot.vector_commitment(x[:m], 0, g[:m], vm.Ed25519Point.identity)
-    tot = sum(a * b for a, b in zip(vm._native.array_to_ints(sc[:m]), vm._native.array_to_ints(exps[:m]))) % ELL
-    assert part == vm.Ed25519Point.repeat(group.generator, tot)
+    # the exponent identity on the WHOLE 2^24-term commitment: sum_i s_i (e_i B) == (sum_i s_i e_i mod l) B
+    tot = 0
+    step = 1 << 20
+    for lo in range(0, n, step):
+        tot += sum(a * b for a, b in zip(vm._native.array_to_ints(sc[lo:lo + step]),
+                                         vm._native.array_to_ints(exps[lo:lo + step])))
+    assert whole == vm.Ed25519Point.repeat(group.generator, tot % ELL)

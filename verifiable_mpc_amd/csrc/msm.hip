@@ -55,6 +55,9 @@ __device__ __forceinline__ ge_niels niels_ld(const uint32_t *niels, uint32_t e) 
 }
 
 // one lane = one segment of <= MSM_SEG sorted entries
+#ifndef MSM_IDX_BATCH
+#define MSM_IDX_BATCH 4
+#endif
 #ifndef MSM_BUCKET_WAVES
 #define MSM_BUCKET_WAVES 4
 #endif
@@ -78,23 +81,45 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
     uint32_t len = cnt - sidx * seg;
     if (len > (uint32_t)seg) len = seg;
     ge_ext acc = ge_ext_identity();
-    uint32_t e = sorted[lo];
+    // Sorted indices in groups of MSM_IDX_BATCH.  A lane walks its own segment, so the lanes' 4-byte index loads
+    // are >= 256 bytes apart - one cache line per lane - and with 2^18 lanes in flight (64 MB of lines in use
+    // against 32 MB of L2) that line has usually left the L2 by the time the lane comes back for its next
+    // index: one index at a time, the kernel moved 3.7 GB per launch over the fabric for 2.2 GB of table lines
+    // and 0.07 GB of indices (profiles/r03a_pmc_summary.json).  Asking for a group's indices back to back lets
+    // them share the line the first request brings in: 3.0 GB (scripts/pmc_ab.sh).  The kernel's TIME does not
+    // change (integer-ALU bound; 8 at a time is slower: registers) - this only stops wasting fabric bandwidth
+    // that the sort kernels of the next commitment in flight can use.
+    // The next table entry is requested one addition ahead, but the compiler hoists its sign selection to right
+    // behind the load, so in effect the gather latency is hidden by the 4 waves per SIMD, not by this
+    // "prefetch".  A hand-scheduled version (inline-asm loads + manual s_waitcnt after the 7 multiplications,
+    // 140 VGPRs, 3 waves) measured the same 0.61 ms for this kernel and 0.76 instead of 0.85 ms on the 2 GiB
+    // fixed-base table: not worth carrying loads the compiler cannot see.  Staging the gather through LDS with
+    // LDS-DMA (global_load_lds_dwordx4 into a [piece][lane] stage, no VGPR cost) measured 1.07 ms.
+    // Initialising the accumulator from the first term (1M instead of 7M) lost to register pressure.
+    uint32_t ev[MSM_IDX_BATCH];
+#pragma unroll
+    for (int k = 0; k < MSM_IDX_BATCH; k++) ev[k] = sorted[lo + ((uint32_t)k < len ? (uint32_t)k : len - 1)];
+    uint32_t e = ev[0];
     ge_niels q = niels_ld(niels, e);
-    for (uint32_t j = 0; j < len; j++) {
-        // The next term is requested here, but the compiler hoists its sign selection to right behind
-        // the load, so in effect the gather latency is hidden by the 4 waves per SIMD, not by this
-        // "prefetch".  A hand-scheduled version (inline-asm loads + manual s_waitcnt after the 7
-        // multiplications, 140 VGPRs, 3 waves) measured the same 0.61 ms for this kernel and 0.76
-        // instead of 0.85 ms on the 2 GiB fixed-base table: not worth carrying loads the compiler
-        // cannot see.  Staging the gather through LDS with LDS-DMA (global_load_lds_dwordx4 into a
-        // [piece][lane] stage, no VGPR cost) measured 1.07 ms.  Initialising the accumulator from the
-        // first term (1M instead of 7M) lost to register pressure.
-        uint32_t jn = j + 1 < len ? j + 1 : j;
-        uint32_t en = sorted[lo + jn];
-        ge_niels qn = niels_ld(niels, en);
-        acc = ge_madd(acc, ge_niels_select_neg(q, (e >> 31) != 0));
-        e = en;
-        q = qn;
+    for (uint32_t j0 = 0; j0 < len; j0 += MSM_IDX_BATCH) {
+        uint32_t en_v[MSM_IDX_BATCH];
+#pragma unroll
+        for (int k = 0; k < MSM_IDX_BATCH; k++) {
+            const uint32_t jj = j0 + MSM_IDX_BATCH + (uint32_t)k;
+            en_v[k] = sorted[lo + (jj < len ? jj : len - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < MSM_IDX_BATCH; k++) {
+            if (j0 + (uint32_t)k < len) {
+                const uint32_t en = k + 1 < MSM_IDX_BATCH ? ev[k + 1 < MSM_IDX_BATCH ? k + 1 : 0] : en_v[0];
+                ge_niels qn = niels_ld(niels, en);
+                acc = ge_madd(acc, ge_niels_select_neg(q, (e >> 31) != 0));
+                e = en;
+                q = qn;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MSM_IDX_BATCH; k++) ev[k] = en_v[k];
     }
     if (nseg[ci] == 1)
         ext_st(buckets + EXT_WORDS * msm_bucket_slot(ci, nb1), acc);
