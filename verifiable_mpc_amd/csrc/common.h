@@ -54,6 +54,9 @@ struct vmpc_ctx {
     int reduce_max_chunks = 32768; // most chunk-lanes per bucket set in the bucket reduction (msm_sort.hip)
     int seg_shift_min = -3;        // shortest bucket segments the plan may choose: 64 >> 3 entries (msm_sort.hip)
     int sort_fine_bits = -1;       // fine bits of the two-level bucket sort; -1 = automatic (msm_sort.hip)
+    int plan_fill_shift = 0;       // the next plan's digit rows are only 1 / 2^shift populated (the A_i, B_i pair of a
+                                   // prover round: each scalar vector is zero on half of its positions): the segment
+                                   // length follows the expected number of entries, not the number of positions
     int cu_count = 256;
     hipEvent_t xevent = nullptr;   // cross-context ordering (vmpc_ctx_wait_for)
     // pinned staging for small host -> device parameter blocks (vmpc_stage_h2d)

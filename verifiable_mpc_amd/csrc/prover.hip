@@ -174,6 +174,8 @@ struct vmpc_p4 {
     size_t block_lo, block_n;
     char *mine, *gathered;            // 2 partial points of this rank; world x 2 gathered ones
     bool poisoned;                    // a call failed after the fold state advanced: only destroy is valid
+    const void *table0;               // the caller's table (the unfolded CRS / block)
+    int small_window;                 // digit width on a folded vector's table (0: the context's default)
 };
 
 // All device buffers of a context are carved from one arena that stays with the vmpc_ctx between proofs
@@ -241,7 +243,10 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     p->rank = rank;
     p->block_lo = (size_t)rank * block_n;
     p->block_n = block_n;
-    p->table = table;
+    p->table = p->table0 = table;
+    p->small_window = 0;
+    if (const char *e = getenv("VMPC_P4_SMALL_WINDOW")) p->small_window = atoi(e);
+    if (p->small_window != 4 && p->small_window != 8 && p->small_window != 16) p->small_window = 0;
     p->table_n = table_n;
     p->table_extra = table_extra;
     p->rows = rows;
@@ -476,15 +481,27 @@ static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
     // the recombination kernel writes the 2 x 128 bytes straight into pinned host memory: no copy command at all
     // (a pageable destination costs a staged copy, 20 us a round)
     VMPC_CHECK(vmpc_pinned_reserve(ctx, 0));
+    // v_a and v_b are each zero on half of their positions (z_l against g_r, z_r against g_l): tell the planner
+    ctx->plan_fill_shift = 1;
+    // digit width of the commitments over a FOLDED vector's table (VMPC_P4_SMALL_WINDOW, tuning knob)
+    const int saved_window = ctx->window_override;
+    if (p->small_window && p->table != p->table0) ctx->window_override = p->small_window;
+    int rc;
     if (p->comm) {
         // partial sums over this rank's block, then the round's one exchange: all-gather + rank-ordered add on
         // the same stream, the result lands in the pinned block
-        VMPC_CHECK(vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
-                                            p->mine, nullptr));
+        rc = vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2, p->mine,
+                                      nullptr);
+        ctx->plan_fill_shift = 0;
+        ctx->window_override = saved_window;
+        VMPC_CHECK(rc);
         VMPC_CHECK(vmpc_comm_points_allsum_dev(p->comm, ctx, p->mine, 2, p->gathered, ctx->pin_out_dev, nullptr));
     } else {
-        VMPC_CHECK(vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
-                                            ctx->pin_out_dev, nullptr));
+        rc = vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
+                                      ctx->pin_out_dev, nullptr);
+        ctx->plan_fill_shift = 0;
+        ctx->window_override = saved_window;
+        VMPC_CHECK(rc);
     }
     const uint8_t *ext = (const uint8_t *)ctx->pin_out;
     VMPC_CHECK(vmpc_ctx_sync(ctx));
