@@ -434,6 +434,56 @@ def test_protocol4_over_a_prefix_of_a_tabulated_crs(vm, n_table, with_h):
         vm._native.P4Rounds(g.ctx, g._table, 0, g._table.extra_index(k), z_hat.ptr, z_hat.ptr, n_total=m)
 
 
+@pytest.mark.parametrize("log_n,direct_log2,jump_k,min_log2,rows", [
+    (10, 5, 5, 30, 16),     # small vector: one fold straight down to 2^5 generators, then bucket-free commitments
+    (12, 6, 3, 9, 16),      # two folds by the large-block rule (2^12 -> 2^9 -> 2^6), bucket-free from there
+    (13, 11, 5, 30, 8),     # the default threshold: 2^13 -> 2^11 after two rounds
+    (7, 11, 0, 30, 16),     # no folds at all: bucket-free from round 0 on the CRS's own table (h among the extras)
+    (7, 11, 0, 30, 8),      # ... with 32-bit digits (8-row table)
+    (6, 11, 5, 30, 4),      # a 4-row table keeps the bucket method (64-bit digits would be a 64-step ladder)
+])
+def test_bucket_free_short_rounds(vm, monkeypatch, log_n, direct_log2, jump_k, min_log2, rows):
+    """csrc/prover.hip k_p4_direct: once the vector is short, A_i / B_i are computed without buckets (one lane per
+    generator and table row) and the context folds down to that size as soon as it can.  Same proofs as with
+    every commitment by the bucket method and no fold."""
+    rng = random.Random(7700 + 13 * log_n + direct_log2)
+    n = (1 << log_n) - 1
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    h, k = group.generator, vm.Ed25519Point.repeat(group.generator, rng.randrange(1, ELL))
+    g = vm.PointVector.fixed_base(h, [rng.randrange(1, ELL) for _ in range(n)], keep_proj=False)
+    g.precompute([h, k], rows=rows)
+    gens = {"g": g, "h": h, "k": k}
+    xs = vm.ScalarVector.from_ints([rng.randrange(ELL) for _ in range(n)])
+    Lf = vm.pivot.LinearForm(vm.ScalarVector.from_ints([rng.randrange(ELL) for _ in range(n)]))
+    gamma, rho = rng.randrange(1, ELL), rng.randrange(ELL)
+    r = [rng.randrange(ELL) for _ in range(n)]
+    P = vm.pivot.vector_commitment(xs, gamma, g, h)
+    y = gf(Lf(xs))
+    proofs, stages = [], []
+    ctx = vm.get_context()
+    for setting in ((str(direct_log2), str(jump_k), str(min_log2)), ("0", "0", "30")):
+        monkeypatch.setenv("VMPC_P4_DIRECT_LOG2", setting[0])
+        monkeypatch.setenv("VMPC_P4_FOLD_TO_DIRECT", "1")       # the fold-down-to-the-short-form rule (off by default)
+        monkeypatch.setenv("VMPC_P4_JUMP", setting[1])
+        monkeypatch.setenv("VMPC_P4_JUMP_MIN_LOG2", setting[2])
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        proof = vm.compressed_pivot.protocol_5_prover(gens, P, Lf, y, xs, gamma, gf, transcript="compact",
+                                                      r=list(r), rho=rho)
+        stages.append({name: cnt for name, (ms, cnt) in ctx.profile_read(reset=True).items() if cnt})
+        ctx.profile(False)
+        assert vm.compressed_pivot.protocol_5_verifier(gens, P, Lf, y, proof, gf, transcript="compact") is True
+        proofs.append({key: (tuple(v.normalize().coords) if hasattr(v, "normalize") else
+                             [int(e) for e in v] if isinstance(v, list) else int(v)) for key, v in proof.items()})
+    assert proofs[0] == proofs[1]
+    assert "p4_direct" not in stages[1] and "table_fold" not in stages[1]
+    if rows >= 8:
+        assert stages[0].get("p4_direct", 0) >= 1            # the bucket-free kernel really ran
+    else:
+        assert "p4_direct" not in stages[0]
+
+
 def test_two_round_contexts_on_one_vmpc_ctx(vm):
     """The first context takes the arena pooled in the vmpc_ctx, a second one alive at the same time gets a
     private one (csrc/prover.hip); interleaved rounds give what each gives alone, and the pool is free again

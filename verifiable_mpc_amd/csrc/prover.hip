@@ -29,6 +29,13 @@
 // the parts are never added up: later rounds commit to part_r with the full (short, replicated) scalar vector and
 // the exchange sums the partial commitments as before.  No generator ever crosses a link.
 //
+// The short end.  Once the vector is down to 2^11 generators (VMPC_P4_DIRECT_LOG2) a commitment skips the bucket
+// method: with the folded vector's 16-row table a term v * G is 16 independent 16-bit products d_r * (2^(16 r) G), so one
+// lane per (generator, row) runs a 16-step double-and-add on its table entry and a workgroup tree adds them up
+// (k_p4_direct) - 0.15 ms per round where the sort -> bucket -> reduce -> recombine pipeline costs 0.3 ms of
+// latency whatever the size (N = 2^10: 3.4 -> 2.7 ms per proof).  Folding a longer vector down to that size just to
+// get there does not pay (p4_next_jump), so this serves vectors that are short to begin with.
+//
 // Built entirely on the public C-ABI of this library (include/vmpc.h) plus the host-callable field code.
 #include <stdlib.h>
 
@@ -39,6 +46,7 @@
 #include "fe25519.h"
 #include "fr.h"
 #include "ge25519.h"
+#include "ptio.h"
 
 
 // ---- the scalar side of one round in two launches ------------------------------------------------
@@ -141,6 +149,63 @@ k_p4_extras(const uint32_t *__restrict__ partials, int n_partials, const uint32_
     }
 }
 
+// ---- commitments over a short tabulated vector without buckets ---------------------------------------------------
+// A_i (workgroups [0, blocks_per)) and B_i ([blocks_per, 2 blocks_per)) over the table's n_cols = generators + extras
+// columns: lane t of a commitment handles row r = t / n_cols of column t % n_cols, i.e. the digit
+// d = bits [r dbits, (r+1) dbits) of the column's scalar against the table entry 2^(r dbits) * G (dbits = 256 / rows),
+// by a dbits-step double-and-add; the workgroup then adds its 256 results in an LDS tree.
+#define P4D_BLOCK 256
+
+__device__ __forceinline__ void p4d_tree(uint32_t *lds, const ge_ext &mine, uint32_t *dst, bool packed) {
+    ext_st(lds + EXT_WORDS * threadIdx.x, mine);
+    __syncthreads();
+    for (uint32_t stride = P4D_BLOCK / 2; stride >= 1; stride >>= 1) {
+        if (threadIdx.x < stride)
+            ext_st(lds + EXT_WORDS * threadIdx.x,
+                   ge_add(ext_ld(lds + EXT_WORDS * threadIdx.x), ext_ld(lds + EXT_WORDS * (threadIdx.x + stride))));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (packed) ext_st8(dst, ext_ld(lds));
+        else ext_st(dst, ext_ld(lds));
+    }
+}
+
+__global__ void __launch_bounds__(P4D_BLOCK)
+k_p4_direct(const uint32_t *__restrict__ table, size_t stride, int rows, size_t table_n, size_t n_cols,
+            const uint32_t *__restrict__ va, const uint32_t *__restrict__ vb, const uint32_t *__restrict__ ex_a,
+            const uint32_t *__restrict__ ex_b, unsigned blocks_per, uint32_t *__restrict__ partial) {
+    __shared__ uint32_t lds[P4D_BLOCK * EXT_WORDS];
+    const unsigned which = blockIdx.x / blocks_per;
+    const size_t t = (size_t)(blockIdx.x % blocks_per) * P4D_BLOCK + threadIdx.x;
+    const int dbits = 256 / rows;                      // 16 or 32
+    ge_ext acc = ge_ext_identity();
+    if (t < n_cols * (size_t)rows) {
+        const int r = (int)(t / n_cols);
+        const size_t col = t % n_cols;
+        const uint32_t *sc = col < table_n ? (which ? vb : va) + 8 * col : (which ? ex_b : ex_a) + 8 * (col - table_n);
+        const uint32_t d = dbits == 32 ? sc[r] : (sc[r >> 1] >> (16 * (r & 1))) & 0xffffu;
+        if (d) {
+            const ge_niels q = niels_ld_line(table + NIELS_WORDS * ((size_t)r * stride + col));
+            for (int b = dbits - 1; b >= 0; b--) {
+                acc = ge_dbl(acc);
+                if ((d >> b) & 1u) acc = ge_madd(acc, q);
+            }
+        }
+    }
+    p4d_tree(lds, acc, partial + EXT_WORDS * (size_t)blockIdx.x, false);
+}
+
+// the blocks_per partial sums of each commitment -> its sum, 128 bytes X || Y || Z || T at out + 128 * blockIdx.x
+__global__ void __launch_bounds__(P4D_BLOCK)
+k_p4_direct_sum(const uint32_t *__restrict__ partial, unsigned blocks_per, uint32_t *__restrict__ out_ext) {
+    __shared__ uint32_t lds[P4D_BLOCK * EXT_WORDS];
+    const uint32_t *src = partial + EXT_WORDS * (size_t)blockIdx.x * blocks_per;
+    ge_ext acc = ge_ext_identity();
+    for (unsigned j = threadIdx.x; j < blocks_per; j += P4D_BLOCK) acc = ge_add(acc, ext_ld(src + EXT_WORDS * (size_t)j));
+    p4d_tree(lds, acc, out_ext + 32 * blockIdx.x, true);
+}
+
 int vmpc_table_fold_table_with_block(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
                                      size_t n_cols, int k, const uint8_t *scalars, size_t n_extra, int out_rows,
                                      const void *extras_block, void *out_table);   // fold_jump.hip
@@ -161,8 +226,12 @@ struct vmpc_p4 {
     std::vector<std::array<uint8_t, 32>> pending;
     int jump_k;
     size_t jump_min;
-    char *k_aff, *jump_g, *jump_table;
-    size_t jump_g_bytes, jump_table_bytes;
+    char *k_aff;
+    // the folds this proof will make, fixed at creation (p4_next_jump): their tables come out of the arena
+    struct jump_slot { int k; size_t m_out, bytes; char *table; };
+    std::vector<jump_slot> jumps;
+    size_t jumps_done;
+    int direct_log2;                  // commitments over <= 2^direct_log2 generators skip the bucket method (0: never)
     char *arena;
     bool arena_pooled;
     std::vector<char *> extra;        // buffers of second and later jumps
@@ -206,6 +275,24 @@ static int p4_log2(size_t v) {
     return l;
 }
 
+// How many rounds' challenges the next fold of the generators applies, for a vector of 2^log2_n generators of which
+// this rank's table holds block_n (spread over `spread` ranks before the first fold, 1 afterwards); 0 = no further
+// fold.  Two rules: a large block is folded after jump_k rounds (64 additions per generator whatever k, and the
+// rounds before it cost a full commitment each); a vector of at most 2^17 generators is folded once more (or for
+// the first time), straight down to the 2^direct_log2 generators the bucket-free commitment handles.  Sharded,
+// a block must hold at least two strides of the fold: 2^k >= 2 * spread.
+static int p4_next_jump(int jump_k, size_t jump_min, int direct_log2, bool fold_to_direct, int log2_n, size_t block_n,
+                        size_t spread) {
+    if (!jump_k) return 0;
+    if (block_n >= jump_min && log2_n - jump_k >= 2 && ((size_t)1 << jump_k) >= 2 * spread) return jump_k;
+    // (the second rule is off by default: the fold itself - a chain of rows x 2^k table entries per lane plus a
+    // 240-doubling table build, 1.2 ms at any size - costs what the cheaper rounds save: 18.9 ms either way at
+    // N = 2^20, 7.2 against 6.6 ms at 2^16; VMPC_P4_FOLD_TO_DIRECT=1 turns it on)
+    const int k = log2_n - direct_log2;
+    if (fold_to_direct && direct_log2 && k >= 1 && k <= 6 && ((size_t)1 << k) >= 2 * spread) return k;
+    return 0;
+}
+
 // table: fixed-base table over table_n generators followed by table_extra extras, of which extras
 // 0 .. h_slots-1 are the tail of g_hat (g_hat = g || h: h_slots = 1) and extra `k_slot` is k.  The table's
 // generators (and tail) are block `rank` of g_hat's `world` equal blocks (comm = NULL: the whole of g_hat).
@@ -226,7 +313,7 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     vmpc_p4 *p = new vmpc_p4();
     p->z[0] = p->z[1] = p->L[0] = p->L[1] = p->products = p->va = p->vb = p->ex_a = p->ex_b = p->out = nullptr;
-    p->k_aff = p->jump_g = p->jump_table = p->partials = p->mine = p->gathered = nullptr;
+    p->k_aff = p->partials = p->mine = p->gathered = nullptr;
     p->arena = nullptr;
     p->arena_pooled = false;
     p->poisoned = false;
@@ -237,6 +324,10 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     if (p->jump_k < 0 || p->jump_k > 6) p->jump_k = 0;
     p->jump_min = (size_t)1 << 18;
     if (const char *e = getenv("VMPC_P4_JUMP_MIN_LOG2")) p->jump_min = (size_t)1 << atoi(e);
+    p->direct_log2 = 11;                         // VMPC_P4_DIRECT_LOG2=0: every commitment by the bucket method
+    if (const char *e = getenv("VMPC_P4_DIRECT_LOG2")) p->direct_log2 = atoi(e);
+    if (p->direct_log2 < 2 || p->direct_log2 > 14) p->direct_log2 = 0;
+    p->jumps_done = 0;
     p->ctx = ctx;
     p->comm = comm;
     p->world = world;
@@ -255,23 +346,35 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     p->m = N;
     p->log2_n = p4_log2(N);
     p->total_rounds = p->log2_n - 1;
-    // jump buffers, if this rank's block is large enough to be folded (sizes of the FIRST jump; a later one is
-    // smaller): the block must hold at least two strides of the k-round fold (2^k >= 2 world)
-    p->jump_g_bytes = p->jump_table_bytes = 0;
-    if (p->jump_k && block_n >= p->jump_min && p->log2_n - p->jump_k >= 2 && ((size_t)1 << p->jump_k) >= 2 * (size_t)world) {
-        const size_t m_out = N >> p->jump_k;
-        p->jump_g_bytes = 64 * m_out;
-        if (vmpc_msm_table_bytes(m_out, 1, p4_jump_rows(m_out), &p->jump_table_bytes) != VMPC_OK) {
-            delete p;
-            return VMPC_E_INVAL;
+    // the folds of this proof and the tables they leave, all from the arena
+    {
+        int l2 = p->log2_n;
+        size_t bn = block_n, spread = (size_t)world;
+        const char *f2d = getenv("VMPC_P4_FOLD_TO_DIRECT");
+        while (int k = p4_next_jump(p->jump_k, p->jump_min, p->direct_log2, f2d && atoi(f2d) != 0, l2, bn, spread)) {
+            vmpc_p4::jump_slot js;
+            js.k = k;
+            js.m_out = ((size_t)1 << l2) >> k;
+            js.table = nullptr;
+            if (vmpc_msm_table_bytes(js.m_out, 1, p4_jump_rows(js.m_out), &js.bytes) != VMPC_OK) {
+                delete p;
+                return VMPC_E_INVAL;
+            }
+            p->jumps.push_back(js);
+            l2 -= k;
+            bn = js.m_out;
+            spread = 1;
         }
     }
     const size_t per_gen = 32 * block_n;          // products, v_a, v_b: one entry per local column (fewer after a jump)
-    const size_t sizes[] = {32 * N, 32 * N, 32 * N, 32 * N, per_gen, per_gen, per_gen, 32 * table_extra + 32,
-                            32 * table_extra + 32, 256, (size_t)2 * P4_MAX_GRID * 32, 64, p->jump_g_bytes,
-                            p->jump_table_bytes, 256, (size_t)256 * world};
-    char **slots[] = {&p->z[0], &p->z[1], &p->L[0], &p->L[1], &p->products, &p->va, &p->vb, &p->ex_a,
-                      &p->ex_b, &p->out, &p->partials, &p->k_aff, &p->jump_g, &p->jump_table, &p->mine, &p->gathered};
+    std::vector<size_t> sizes = {32 * N, 32 * N, 32 * N, 32 * N, per_gen, per_gen, per_gen, 32 * table_extra + 32,
+                                 32 * table_extra + 32, 256, (size_t)2 * P4_MAX_GRID * 32, 64, 256, (size_t)256 * world};
+    std::vector<char **> slots = {&p->z[0], &p->z[1], &p->L[0], &p->L[1], &p->products, &p->va, &p->vb, &p->ex_a,
+                                  &p->ex_b, &p->out, &p->partials, &p->k_aff, &p->mine, &p->gathered};
+    for (auto &js : p->jumps) {
+        sizes.push_back(js.bytes);
+        slots.push_back(&js.table);
+    }
     size_t total = 0;
     for (size_t b : sizes) total += p4_align(b);
     if (!ctx->p4_pool_busy) {
@@ -298,7 +401,7 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     }
     {
         size_t off = 0;
-        for (size_t i = 0; i < sizeof sizes / sizeof sizes[0]; i++) {
+        for (size_t i = 0; i < sizes.size(); i++) {
             *slots[i] = sizes[i] ? p->arena + off : nullptr;
             off += p4_align(sizes[i]);
         }
@@ -368,11 +471,9 @@ static int p4_fold_dots(vmpc_p4 *p, const uint8_t *c) {
     return VMPC_OK;
 }
 
-// the jump is due: enough pending challenges, a block worth folding, and at least two of the fold's strides in it
+// the next fold of the schedule is due: its challenges are all there
 static bool p4_jump_due(const vmpc_p4 *p) {
-    const size_t spread = p->block_n < ((size_t)1 << p->log2_n) ? (size_t)p->world : 1;   // ranks g_hat is cut over
-    return p->jump_k && (int)p->pending.size() == p->jump_k && p->block_n >= p->jump_min &&
-           p->log2_n - p->jump_k >= 2 && ((size_t)1 << p->jump_k) >= 2 * spread;
+    return p->jumps_done < p->jumps.size() && (int)p->pending.size() == p->jumps[p->jumps_done].k;
 }
 
 // Apply the pending challenges to the generators: g' = k folds of the table's vector, then a table for g' || k.
@@ -397,16 +498,9 @@ static int p4_jump(vmpc_p4 *p) {
     const int rows = p4_jump_rows(m_out);
     size_t bytes = 0;
     VMPC_CHECK(vmpc_msm_table_bytes(m_out, 1, rows, &bytes));
-    // the arena holds the first jump's buffers; a later jump (CRS of 2^23 and more) allocates its own
-    char *g = p->jump_g, *t = p->jump_table;
-    if (p->table == p->jump_table || 64 * m_out > p->jump_g_bytes || bytes > p->jump_table_bytes) {
-        g = t = nullptr;
-        if (hipMalloc((void **)&g, 64 * m_out) != hipSuccess) return VMPC_E_NOMEM;
-        p->extra.push_back(g);
-        if (hipMalloc((void **)&t, bytes) != hipSuccess) return VMPC_E_NOMEM;
-        p->extra.push_back(t);
-    }
-    (void)g;
+    if (p->jumps_done >= p->jumps.size() || p->jumps[p->jumps_done].m_out != m_out || p->jumps[p->jumps_done].bytes < bytes)
+        return VMPC_E_INVAL;                                  // (the schedule fixed at creation)
+    char *t = p->jumps[p->jumps_done].table;
     if (m_out % 8 == 0) {
         // k's columns of the new table: the same for every proof over this CRS
         if (!ctx->p4_kblock || ctx->p4_kblock_rows != rows || memcmp(ctx->p4_kblock_key, p->k_host, 64) != 0) {
@@ -431,6 +525,7 @@ static int p4_jump(vmpc_p4 *p) {
     p->log2_n -= k;
     p->block_lo = 0;                  // every rank now holds a full-length (partial) vector
     p->block_n = m_out;
+    p->jumps_done++;
     p->pending.clear();
     return VMPC_OK;
 }
@@ -478,31 +573,39 @@ static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
         VMPC_KERNEL_CHECK();
     }
     const void *sc[2] = {p->va, p->vb}, *ex[2] = {p->ex_a, p->ex_b};
-    // the recombination kernel writes the 2 x 128 bytes straight into pinned host memory: no copy command at all
+    // the last kernel writes the 2 x 128 bytes straight into pinned host memory: no copy command at all
     // (a pageable destination costs a staged copy, 20 us a round)
     VMPC_CHECK(vmpc_pinned_reserve(ctx, 0));
-    // v_a and v_b are each zero on half of their positions (z_l against g_r, z_r against g_l): tell the planner
-    ctx->plan_fill_shift = 1;
-    // digit width of the commitments over a FOLDED vector's table (VMPC_P4_SMALL_WINDOW, tuning knob)
-    const int saved_window = ctx->window_override;
-    if (p->small_window && p->table != p->table0) ctx->window_override = p->small_window;
-    int rc;
-    if (p->comm) {
-        // partial sums over this rank's block, then the round's one exchange: all-gather + rank-ordered add on
-        // the same stream, the result lands in the pinned block
-        rc = vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2, p->mine,
-                                      nullptr);
-        ctx->plan_fill_shift = 0;
-        ctx->window_override = saved_window;
-        VMPC_CHECK(rc);
-        VMPC_CHECK(vmpc_comm_points_allsum_dev(p->comm, ctx, p->mine, 2, p->gathered, ctx->pin_out_dev, nullptr));
+    void *pair_out = p->comm ? (void *)p->mine : ctx->pin_out_dev;       // partial sums go through the exchange
+    if (p->direct_log2 && p->table_n <= ((size_t)1 << p->direct_log2) && p->rows >= 8) {
+        // short vector: no buckets (k_p4_direct)
+        const size_t n_cols = p->table_n + p->table_extra, stride = (n_cols + 7) & ~(size_t)7;
+        const unsigned blocks_per = (unsigned)((n_cols * (size_t)p->rows + P4D_BLOCK - 1) / P4D_BLOCK);
+        VMPC_CHECK(vmpc_ws_reserve(ctx, (size_t)2 * blocks_per * EXT_WORDS * 4 + 512));
+        uint32_t *part = (uint32_t *)vmpc_ws_take(ctx, (size_t)2 * blocks_per * EXT_WORDS * 4);
+        vmpc_stage_scope s(ctx, "p4_direct");
+        k_p4_direct<<<2 * blocks_per, P4D_BLOCK, 0, st>>>((const uint32_t *)p->table, stride, p->rows, p->table_n, n_cols,
+                                                          (const uint32_t *)p->va, (const uint32_t *)p->vb,
+                                                          (const uint32_t *)p->ex_a, (const uint32_t *)p->ex_b, blocks_per,
+                                                          part);
+        VMPC_KERNEL_CHECK();
+        k_p4_direct_sum<<<2, P4D_BLOCK, 0, st>>>(part, blocks_per, (uint32_t *)pair_out);
+        VMPC_KERNEL_CHECK();
     } else {
-        rc = vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
-                                      ctx->pin_out_dev, nullptr);
+        // v_a and v_b are each zero on half of their positions (z_l against g_r, z_r against g_l): tell the planner
+        ctx->plan_fill_shift = 1;
+        // digit width of the commitments over a FOLDED vector's table (VMPC_P4_SMALL_WINDOW, tuning knob)
+        const int saved_window = ctx->window_override;
+        if (p->small_window && p->table != p->table0) ctx->window_override = p->small_window;
+        const int rc = vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
+                                                pair_out, nullptr);
         ctx->plan_fill_shift = 0;
         ctx->window_override = saved_window;
         VMPC_CHECK(rc);
     }
+    // the round's one exchange: all-gather + rank-ordered add on the same stream, the result lands in the pinned block
+    if (p->comm)
+        VMPC_CHECK(vmpc_comm_points_allsum_dev(p->comm, ctx, p->mine, 2, p->gathered, ctx->pin_out_dev, nullptr));
     const uint8_t *ext = (const uint8_t *)ctx->pin_out;
     VMPC_CHECK(vmpc_ctx_sync(ctx));
     p->committed++;
