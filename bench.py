@@ -631,6 +631,29 @@ def main():
         iso = {k: ms / max(c, 1) for k, (ms, c) in c0.profile_read(reset=True).items()}
         c0.profile(False)
         alu_peak = max(c0.madd_rate(400) for _ in range(3))
+    # one commitment alone over a 4-row fixed-base table of the same generators (PointVector.precompute: what a CRS
+    # that serves many commitments holds; 3 extra multiples per generator): the recombination chain is 48 doublings
+    # instead of 240 and the reduction covers 4 bucket sets instead of 16
+    alone_table = None
+    if rank == 0 and not args.variable_base and os.environ.get("VMPC_BENCH_ALONE_TABLE", "1") != "0":
+        try:
+            tab = vm.PointVector(points_plain.a, None, ctx).precompute([], rows=4)
+            t_, res_ = tab._table, ctx.alloc(128)
+            for _ in range(2):
+                ctx.msm_table(t_.ptr, t_.n, 0, scalar_vectors[0].ptr, n, None, res_.ptr, None, rows=4)
+            ctx.sync()
+            t3 = time.perf_counter()
+            for _ in range(iso_steps):
+                ctx.msm_table(t_.ptr, t_.n, 0, scalar_vectors[0].ptr, n, None, res_.ptr, None, rows=4)
+                ctx.sync()
+            alone_table = {"rows": 4, "table_MiB": (4 * n * 128) >> 20,
+                           "ms_per_commitment": round((time.perf_counter() - t3) / iso_steps * 1e3, 4)}
+            got = vm.Ed25519Point.from_proj_bytes(ctx.download(res_.ptr, 128).tobytes()[:96]).normalize()
+            alone_table["same_point_as_prepared_form"] = bool(got == shard.finish(shard.launch(scalar_vectors[0], points, 0))) \
+                if not shard.collective else None
+            del tab, t_, res_
+        except Exception as e:
+            alone_table = {"error": f"{type(e).__name__}: {e}"}
     # the other generator form, same K steps, same brackets
     state["stage"] = "other generator form"
     other_pts = points_plain if points is points_prepared else points_prepared
@@ -697,6 +720,8 @@ def main():
                        "scalar_vectors": f"{len(scalar_vectors)} distinct (one per commitment of a launch)",
                        "timing": {"throughput_ms_per_commitment": round(elapsed / args.steps * 1e3, 4),
                                   "latency_ms_one_commitment_alone": round(iso_ms, 4),
+                                  "latency_ms_one_commitment_alone_over_4row_table":
+                                      (alone_table or {}).get("ms_per_commitment"),
                                   "what": "value = pipelined throughput (launches_in_flight x commitments_per_launch "
                                           "commitments in flight); a prover's commitments are sequential and cost "
                                           "the latency figure"},
@@ -736,7 +761,8 @@ def main():
                 "note": "same K steps and brackets with the generators in the other form"},
             "stages_us": {k: round(ms / max(c, 1) * 1e3, 1) for k, (ms, c) in prof.items()},
             "alone": {"ms_per_commitment": round(iso_ms, 4),
-                      "stages_us": {k: round(v * 1e3, 1) for k, v in iso.items()}},
+                      "stages_us": {k: round(v * 1e3, 1) for k, v in iso.items()},
+                      "over_fixed_base_table": alone_table},
         }
         if comm_note:
             line["config"]["native_comm_error"] = comm_note
