@@ -441,8 +441,8 @@ def exponent_sum(scalars_arr, exps_arr, order):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)       # 60 ms timed region per generator form
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--log2n", type=int, default=20, help="MSM terms per GPU = 2^log2n")
     ap.add_argument("--cpu-log2n", type=int, default=17, help="cpu_baseline sample size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
