@@ -588,3 +588,21 @@ def test_table_fold_argument_checks(nat, ctx):
         nat._check(lib.vmpc_msm_table_fold_dev(ctx.handle, ctypes.c_void_p(table.ptr), 8, 0, 4, 8, 1, raw,
                                                ctypes.c_void_p(out.ptr)), "fold")
     assert e.value.code == nat.E_NONCANON
+
+
+def test_measurement_probes(nat, ctx):
+    """the probes bench.py prices the kernels against: integer-ALU ceilings (Ed25519 7M mixed addition; BN-256
+    Jacobian mixed addition over F_p and F_p^2) and the known-size gather the HBM counter is calibrated on"""
+    ed_rate = ctx.madd_rate(50)
+    g1, g2 = ctx.bn256_madd_rate(1, 20), ctx.bn256_madd_rate(2, 10)
+    assert 5e9 < ed_rate < 1e11, ed_rate             # ~3e10 on an MI355X
+    assert 1e9 < g1 < ed_rate and 1e8 < g2 < g1, (ed_rate, g1, g2)   # Jacobian 11-multiplication additions, generic prime
+    lines = (8 << 20) >> 7
+    table = ctx.alloc(lines * 128)
+    for mode in (0, 1, 2):
+        ms = ctx.gather_probe(table.ptr, lines, 1 << 20, mode, seed=3)
+        assert 0 < ms < 100, (mode, ms)
+    with pytest.raises(nat.VmpcError):
+        ctx.gather_probe(table.ptr, lines, 1 << 20, 3)
+    with pytest.raises(nat.VmpcError):
+        ctx.bn256_madd_rate(3, 10)

@@ -454,10 +454,13 @@ def test_bucket_free_short_rounds(vm, monkeypatch, log_n, direct_log2, jump_k, m
     g = vm.PointVector.fixed_base(h, [rng.randrange(1, ELL) for _ in range(n)], keep_proj=False)
     g.precompute([h, k], rows=rows)
     gens = {"g": g, "h": h, "k": k}
-    xs = vm.ScalarVector.from_ints([rng.randrange(ELL) for _ in range(n)])
+    # the witness distribution of the demo circuit: mostly zeros and small values, masks likewise,
+    # so that whole digits - and whole scalars - of the round's commitment scalars are zero
+    small = lambda: rng.choice([0, 0, 0, 1, 2, ELL - 1, rng.randrange(ELL)])
+    xs = vm.ScalarVector.from_ints([small() for _ in range(n)])
     Lf = vm.pivot.LinearForm(vm.ScalarVector.from_ints([rng.randrange(ELL) for _ in range(n)]))
     gamma, rho = rng.randrange(1, ELL), rng.randrange(ELL)
-    r = [rng.randrange(ELL) for _ in range(n)]
+    r = [0 if rng.random() < 0.6 else rng.randrange(ELL) for _ in range(n)]
     P = vm.pivot.vector_commitment(xs, gamma, g, h)
     y = gf(Lf(xs))
     proofs, stages = [], []
