@@ -470,6 +470,9 @@ def main():
                          "reduction and recombination chains are paid once per batch; 1 = one commitment per launch")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one commitment in flight (default: 3 launches, on three streams of the same GPU)")
+    ap.add_argument("--table-rows", type=int, default=int(os.environ.get("VMPC_BENCH_TABLE_ROWS", "1")),
+                    help="rows of the resident generator table (1 = prepared form only, no multiples; 2/4/8/16 = "
+                         "fixed-base table with rows - 1 extra multiples per generator, PointVector.precompute)")
     ap.add_argument("--depth", type=int, default=int(os.environ.get("VMPC_BENCH_DEPTH", "0")),
                     help="launches in flight (streams of the same GPU); 0 = the measured optimum")
     ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("VMPC_BENCH_WATCHDOG_S", "1500")),
@@ -560,7 +563,7 @@ def main():
     # each affine point, one 128-byte line, computed once at CRS load (untimed) - a representation of the same
     # 2^20 points, no multiples of them.  `variable_base` = the same commitment from plain affine points,
     # converted inside every call (k_msm_prep); both modes are timed and reported.
-    points_prepared = vm.PointVector(points.a, None, ctx).precompute([], rows=1)
+    points_prepared = vm.PointVector(points.a, None, ctx).precompute([], rows=args.table_rows)
     points_plain = points
     if not args.variable_base:
         points = points_prepared
@@ -592,8 +595,9 @@ def main():
     torch.cuda.synchronize()
     barrier()
     prof_ctxs = list(getattr(shard.backend, "ctxs", [ctx]))[:depth]
+    timed_profile = os.environ.get("VMPC_BENCH_TIMED_PROFILE", "1") != "0"    # (A/B: what the stage events cost)
     for c_ in prof_ctxs:
-        c_.profile(True)
+        c_.profile(timed_profile)
         c_.profile_read(reset=True)
     torch.cuda.synchronize()
     state["stage"] = "timed region"
@@ -620,13 +624,18 @@ def main():
     state["stage"] = "one commitment alone"
     iso, alu_peak, iso_ms, iso_steps = {}, None, None, 5
     c0 = prof_ctxs[0]
+    # (every rank: with a collective the launches are collective too)
+    for _ in range(2):
+        shard.finish(shard.launch(scalar_vectors[0], points, 0))
+    t1 = time.perf_counter()
+    for _ in range(iso_steps):             # latency: no stage events on the stream (they cost ~0.1 ms per commitment)
+        shard.finish(shard.launch(scalar_vectors[0], points, 0))
+    iso_ms = (time.perf_counter() - t1) / iso_steps * 1e3
     if rank == 0:
         c0.profile(True)
         c0.profile_read(reset=True)
-    t1 = time.perf_counter()
-    for _ in range(iso_steps):             # (every rank: with a collective the launches are collective too)
+    for _ in range(iso_steps):             # the same again with the per-stage HIP events: the roofline's kernel time
         shard.finish(shard.launch(scalar_vectors[0], points, 0))
-    iso_ms = (time.perf_counter() - t1) / iso_steps * 1e3
     if rank == 0:
         iso = {k: ms / max(c, 1) for k, (ms, c) in c0.profile_read(reset=True).items()}
         c0.profile(False)
@@ -727,7 +736,9 @@ def main():
                                           "the latency figure"},
                        "generators": ("plain affine points, prepared inside every call" if args.variable_base else
                                       "resident in prepared form (128-byte niels image of each point, made once "
-                                      "at CRS load, untimed)"),
+                                      "at CRS load, untimed)" if args.table_rows == 1 else
+                                      f"resident as a {args.table_rows}-row fixed-base table ({args.table_rows - 1} extra "
+                                      f"multiples per generator, made once at CRS load, untimed)"),
                        "variable_base_scalar_mults_per_s": round(var_value, 1),
                        "collective": (f"all_gather(128 B/rank and commitment) + rank-ordered add, transport: {comm_kind}"
                                       if shard.collective else "none"),
