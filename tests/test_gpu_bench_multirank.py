@@ -54,6 +54,24 @@ def test_two_ranks_of_bench_py_over_gloo():
     assert sp["rounds_in"].startswith("libvmpc_hip")
 
 
+def test_eight_ranks_of_bench_py_over_gloo():
+    """the world size the driver's scaling run ends with: eight ranks (all on this one GPU), eight cyclic shards of
+    one commitment, the sharded prover on eight blocks of 512 with a block-local fold of 2^5 / 8 = 4 strides"""
+    env = dict(os.environ, VMPC_P4_JUMP_MIN_LOG2="8", HSA_ENABLE_IPC_MODE_LEGACY="0", VMPC_MSM_SLOTS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "1", "--log2n", "11",
+           "--dist-backend", "gloo", "--sharded-log2n", "12", "--watchdog-s", "900"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    d = last_json_line(out.stdout)
+    assert d["n_gpus"] == 8 and d["checked"] is True and "error" not in d
+    assert d["config"]["total_terms"] == 8 << 11
+    sp = d["ac20_n2^12_sharded"]
+    assert "error" not in sp, sp
+    assert sp["blocks"] == 8 and sp["ranks_agree"] is True and sp["verified"] is True
+
+
 def test_one_rank_over_rccl_force_collective():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(free_port()))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "1", "--log2n", "14",
