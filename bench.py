@@ -4,14 +4,18 @@
 One "step" = one Pedersen-commitment MSM (the hot loop of pivot.vector_commitment,
 verifiable_mpc/ac20/pivot.py:143-144) over n = 2^20 terms PER GPU, inputs resident in HBM.
 With --gpus N > 1 the N ranks hold the cyclic shards of one (N * 2^20)-term commitment: each
-computes its partial point, one RCCL all-gather of the 128-byte extended points follows and
-every rank adds them in rank order ("weak" scaling).
+computes its partial point, one all-gather of the 128-byte extended points follows inside the
+library (include/vmpc.h vmpc_comm_*: ncclAllGather on the MSM's own stream) and every rank adds
+them in rank order ("weak" scaling).  The commitments of a launch are over DISTINCT
+scalar vectors.  For N > 1 the result is checked across ranks (exponent identity), `"checked": true`.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_msm_bucket), timed
-with HIP events on the kernel's own stream inside the timed region; `cpu_baseline` is the C
-restatement of the REFERENCE algorithm (per-term double-and-add + product tree) on one host
-core over a bounded sample.  At N = 1 the line also carries the AC20 Protocol-5 prove time
-at N = 2^20 in both transcript modes (extra keys, not the headline value).
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_msm_bucket), timed with HIP
+events on the kernel's own stream (alone on the GPU after the timed region, and inside it);
+`cpu_baseline` is the C restatement of the REFERENCE algorithm (per-term double-and-add + product
+tree) on one host core over a bounded sample.  At N = 1 the line also carries the AC20 Protocol-5
+prove time at N = 2^20 in both transcript modes (extra keys, not the headline value); at N > 1 the
+sharded prover's.  A run that makes no progress for --watchdog-s seconds prints the line with an
+`error` entry and exits with status 3.
 """
 import argparse
 import json
