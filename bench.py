@@ -268,6 +268,16 @@ def bn256_timing(vm, ctx, n_pow):
                 assert var_result == ctx.download(want.ptr, width).tobytes(), f"BN-256 {tag} MSM property check failed"
             else:
                 assert ctx.download(res.ptr, width).tobytes() == var_result, f"BN-256 {tag} table MSM differs"
+        # what pynocchio.PreparedKey asks for: the sum in Jacobian coordinates (the affine conversion's inversion chain
+        # is a single-lane job the host does in microseconds)
+        jac = ctx.alloc(3 * width // 2)
+        ctx.bn256_table_msm(group, table.ptr, n, ds.ptr, n, None, jac.ptr)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.bn256_table_msm(group, table.ptr, n, ds.ptr, n, None, jac.ptr)
+        ctx.sync()
+        out[f"{tag}_prepared_key_jacobian_out_ms"] = (time.perf_counter() - t0) / 3 * 1e3
         # the bucket pass of the prepared-key sum alone, against the integer-ALU ceiling of ITS inner operation
         # (Jacobian mixed addition on the Montgomery-form field, madd-2007-bl: 7M + 4S; G2 over F_p^2), measured
         # in this run by a register-resident chain on every lane (vmpc_bn256_madd_rate)
