@@ -28,3 +28,9 @@ def test_bench_line_contract():
         assert key in r, key
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert d["value"] > 0 and abs(d["value"] - (1 << 14) * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    # the result of the timed steps is checked (exponent identity) and the line says how to read `value`
+    assert d["checked"] is True and "error" not in d
+    t = d["config"]["timing"]
+    assert t["throughput_ms_per_commitment"] > 0 and t["latency_ms_one_commitment_alone"] > 0
+    assert d["config"]["variable_base_scalar_mults_per_s"] > 0 and "distinct" in d["config"]["scalar_vectors"]
+    assert r["alu"]["frac"] > 0 and r["traffic_source"]
