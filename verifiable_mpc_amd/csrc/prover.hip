@@ -607,7 +607,11 @@ static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
     if (p->comm)
         VMPC_CHECK(vmpc_comm_points_allsum_dev(p->comm, ctx, p->mine, 2, p->gathered, ctx->pin_out_dev, nullptr));
     const uint8_t *ext = (const uint8_t *)ctx->pin_out;
-    VMPC_CHECK(vmpc_ctx_sync(ctx));
+    // The first round's synchronisation also fetches the device status words (a non-canonical scalar in the caller's
+    // z_hat / L~ shows up in this round's recoding); later rounds only consume scalars this context produced, so
+    // they just wait for the stream - vmpc_p4_finish checks the status once more at the end.
+    if (p->committed == 0 || getenv("VMPC_P4_FULL_SYNC")) VMPC_CHECK(vmpc_ctx_sync(ctx));
+    else VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     p->committed++;
     p4_affine_pair(ext, out_A, out_B);
     return VMPC_OK;
