@@ -5,12 +5,16 @@
 //
 // Transports behind one vmpc_comm:
 //   * RCCL: ncclAllGather on the context's own stream (xGMI inside a node).  librccl is opened with dlopen at the
-//     first use - the library has no link-time dependency on it, and inside a torch process the soname resolves to
-//     the RCCL that torch already loaded.  The communicator is bootstrapped from a 128-byte unique id that the
-//     caller moves between the ranks (any side channel: torch.distributed, MPI, a file).
+//     first use - the library has no link-time dependency on it - and an RCCL that is already in the process (torch
+//     brings its own, next to the HIP runtime it was built against) is preferred to loading a second one.  The
+//     communicator is bootstrapped from a 128-byte unique id that the caller moves between the ranks (any side
+//     channel: torch.distributed, MPI, a file).
 //   * callback: the caller moves the bytes (host-staged gloo in the tests; any other fabric).  The stream is
 //     synchronised before the callback runs; the callback reads `mine` and fills `gathered` (device pointers).
 //   * self: world = 1, the gather is a device copy.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <stdlib.h>
@@ -34,12 +38,22 @@ int rccl_load() {
     if (g_rccl.tried) return VMPC_E_NODEV;
     g_rccl.tried = true;
     const char *override_path = getenv("VMPC_RCCL_LIB");
-    const char *names[] = {override_path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
-    for (const char *n : names) {
-        if (!n || !*n) continue;
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
+    if (override_path && *override_path) {
+        h = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+    } else {
+        // an RCCL that is already in the process first (torch brings its own, built against the HIP runtime it also
+        // brings, under the name "librccl.so"): a second copy from another ROCm release next to it is asking for trouble
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (const char *n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+            if (h) break;
+        }
+        const char *fresh[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : fresh) {
+            if (h) break;
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        }
     }
     if (!h) {
         snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "librccl not found: %s", dlerror());
@@ -56,6 +70,10 @@ int rccl_load() {
         return VMPC_E_NODEV;
     }
     g_rccl.handle = h;
+    if (getenv("VMPC_DEBUG_STAGES")) {
+        Dl_info info;
+        if (dladdr((void *)g_rccl.AllGather, &info) && info.dli_fname) fprintf(stderr, "[vmpc] RCCL from %s\n", info.dli_fname);
+    }
     return VMPC_OK;
 }
 
