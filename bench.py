@@ -404,6 +404,57 @@ def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch, comm=None):
     return out
 
 
+def config4_timing(vm, parallel, shard, total_log2, world, rank, dist, barrier, torch):
+    """BASELINE config 4 as stated: ONE commitment of 2^total_log2 terms (2^24), cyclic shards of 2^total_log2 / world
+    terms per rank (2^21 at 8 ranks), one exchange of a 128-byte point per rank + rank-ordered add (SURVEY.md 8e,
+    pivot.py:143-144).  Timed one commitment at a time (barrier + device synchronisation on both sides, max over
+    ranks) and checked by the cross-rank exponent identity  sum_i s_i (e_i B) == (sum_i s_i e_i mod l) B."""
+    n4 = (1 << total_log2) // world
+    assert n4 >= 8 and n4 * world == 1 << total_log2, "config 4 needs a power-of-two world size"
+    group = vm.EllipticCurve("Ed25519", "projective")
+    rng = np.random.default_rng(20200152 + 4 + 1000 * rank)
+    exps_arr, sc_arr = rand_scalars(rng, n4), rand_scalars(rng, n4)
+    pts = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(exps_arr), keep_proj=False)
+    prepared = vm.PointVector(pts.a, None, shard.backend.ctxs[0]).precompute([], rows=1)
+    sc = vm.ScalarVector.from_array(sc_arr)
+    out = {"total_terms": 1 << total_log2, "terms_per_gpu": n4, "n_gpus": world, "sharding": "cyclic by index",
+           "generators": "resident in prepared form"}
+    times = {}
+    for label, p_ in (("prepared", prepared), ("variable_base", pts)):
+        res = shard.commit(sc, p_)                       # grows the workspace; the result that gets checked
+        runs = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            got = shard.commit(sc, p_)
+            torch.cuda.synchronize()
+            barrier()
+            runs.append(time.perf_counter() - t0)
+            assert got == res, "config 4: the commitment is not reproducible"
+        dt = sorted(runs)[len(runs) // 2]
+        if dist:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times[label] = (dt, res)
+        out[f"ms_per_commitment_{label}"] = round(dt * 1e3, 4)
+        out[f"scalar_mults_per_s_{label}"] = round((1 << total_log2) / dt, 1)
+    mine = exponent_sum(sc_arr, exps_arr, vm.groups.ORDER)
+    if dist:
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        tot = sum(every) % vm.groups.ORDER
+    else:
+        tot = mine
+    want = vm.PointVector.fixed_base(group.generator, [tot], keep_proj=False)[0]
+    for label, (_, res) in times.items():
+        assert res == want, f"config 4 ({label}): exponent identity failed on rank {rank}"
+    out["checked"] = True
+    out["check"] = "cross-rank exponent identity: sum_i s_i (e_i B) == (sum over all ranks of s_i e_i mod l) B"
+    return out
+
+
 def run_steps(shard, k, scalar_vectors, pts, depth, batch):
     """k commitments, in launches of up to `batch` (prepared generators only) with up to `depth` launches in
     flight; every result is fetched to the host, oldest launch first, and its slot refilled at once (with a
@@ -412,6 +463,17 @@ def run_steps(shard, k, scalar_vectors, pts, depth, batch):
     through the vectors.  Returns (results of the last launch, indices into scalar_vectors they belong to)."""
     per = batch if getattr(pts, "_table", None) is not None else 1
     nvec = len(scalar_vectors)
+    backend = getattr(shard, "backend", None)
+    if hasattr(backend, "pipelined"):
+        backend.pipelined = depth > 1          # phase pipelining over a shared bucket stream (parallel.HipBackend)
+    try:
+        return _run_steps(shard, k, scalar_vectors, pts, depth, per, nvec)
+    finally:
+        if hasattr(backend, "pipelined"):
+            backend.pipelined = False
+
+
+def _run_steps(shard, k, scalar_vectors, pts, depth, per, nvec):
     busy, order, size, which, launched, done, last = {}, {}, {}, {}, 0, 0, None
     trace = [] if os.environ.get("VMPC_BENCH_TRACE") else None
     t_prev = time.perf_counter()
@@ -452,11 +514,92 @@ def exponent_sum(scalars_arr, exps_arr, order):
                for x, y in zip(scalars_arr, exps_arr)) % order
 
 
+def self_launch(args, argv):
+    """`python3 bench.py --gpus N` started as ONE plain process (no WORLD_SIZE): be the launcher.  N child processes,
+    one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment - what torch.distributed.run
+    would set), started BEFORE anything in this process touches the GPU; never exec.  Rank 0's JSON line is relayed
+    as the LAST line of stdout, everything else the children print goes to stderr, and the exit status is the worst
+    child's.  If the native (RCCL) exchange fails on the first attempt the run is repeated ONCE with the partial
+    points carried by torch.distributed (--comm torch), so a launch detail cannot cost the whole measurement."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+
+    def free_port():
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            return sk.getsockname()[1]
+
+    def attempt(extra):
+        env0 = dict(os.environ)
+        env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+        env0.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "WORLD_SIZE": str(args.gpus),
+                     "LOCAL_WORLD_SIZE": str(args.gpus), "VMPC_BENCH_SELF_LAUNCHED": "1"})
+        procs, last = [], {"line": None}
+        for r in range(args.gpus):
+            env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + extra, env=env,
+                                          stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True))
+
+        def pump(r, pr):
+            for ln in pr.stdout:
+                ln = ln.rstrip("\n")
+                if r == 0 and ln.startswith('{"metric"'):
+                    last["line"] = ln
+                else:
+                    print(f"[rank {r}] {ln}", file=sys.stderr, flush=True)
+        pumps = [threading.Thread(target=pump, args=(r, pr), daemon=True) for r, pr in enumerate(procs)]
+        for t_ in pumps:
+            t_.start()
+        # one rank gone with an error: the others cannot finish a collective - give them a grace period, then end
+        # exactly the processes started here (by pid / process group, never by pattern)
+        deadline = None
+        while any(pr.poll() is None for pr in procs):
+            time.sleep(0.2)
+            codes = [pr.poll() for pr in procs]
+            if deadline is None and any(c not in (None, 0) for c in codes):
+                deadline = time.time() + 30.0
+            if deadline is not None and time.time() > deadline:
+                for pr in procs:
+                    if pr.poll() is None:
+                        try:
+                            os.killpg(pr.pid, signal.SIGKILL)
+                        except Exception:
+                            pr.kill()
+        for t_ in pumps:
+            t_.join(timeout=5.0)
+        codes = [pr.wait() for pr in procs]
+        worst = max((abs(c) for c in codes), default=0)
+        return worst, last["line"], codes
+
+    worst, line, codes = attempt([])
+    failed = worst != 0 or line is None or "error" in json.loads(line)
+    if failed and args.comm == "native" and args.dist_backend == "nccl" and "--comm" not in argv:
+        print(f"bench.py launcher: first attempt failed (exit codes {codes}); repeating with --comm torch",
+              file=sys.stderr, flush=True)
+        worst2, line2, codes2 = attempt(["--comm", "torch"])
+        if line2 is not None and worst2 == 0:
+            d = json.loads(line2)
+            d.setdefault("config", {})["launcher_note"] = \
+                f"native exchange failed on the first attempt (exit codes {codes}); this line is the --comm torch rerun"
+            worst, line = worst2, json.dumps(d)
+    if line is None:
+        line = json.dumps({"metric": "Ed25519 MSM scalar-mults/sec", "value": None, "unit": "scalar-mults/s",
+                           "n_gpus": args.gpus, "error": f"no rank-0 line; child exit codes {codes}"})
+        worst = worst or 1
+    sys.stderr.flush()
+    print(line, flush=True)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)       # 60 ms timed region per generator form
     ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="back-to-back repetitions of the K-step timed region; the line reports their median")
     ap.add_argument("--log2n", type=int, default=20, help="MSM terms per GPU = 2^log2n")
     ap.add_argument("--cpu-log2n", type=int, default=17, help="cpu_baseline sample size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -475,7 +618,12 @@ def main():
                     help="time the sharded compact prover also with one rank (--force-collective); with more "
                          "than one rank it is timed by default (--no-sharded-prove to skip)")
     ap.add_argument("--no-sharded-prove", action="store_true")
-    ap.add_argument("--sharded-log2n", type=int, default=20, help="N of the sharded prove section")
+    ap.add_argument("--sharded-log2n", type=int, default=20,
+                    help="N of the sharded prove section; with more than one rank it is also timed at N * world "
+                         "(2^20 generators per rank: weak scaling - at N = 2^20 over 8 ranks the rounds are latency-bound)")
+    ap.add_argument("--config4-log2n", type=int, default=24,
+                    help="with more than one rank: total terms (log2) of the BASELINE config-4 commitment, sharded "
+                         "cyclically over the ranks (2^24 over 8 GPUs = 2^21 per rank); 0 = skip")
     ap.add_argument("--variable-base", action="store_true",
                     help="headline on generators given as plain affine points (prepared per call) instead of "
                          "generators resident in prepared form; the other mode is always reported beside it")
@@ -493,6 +641,9 @@ def main():
                     help="give up (JSON line with an error entry, exit status 3) after this long")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plain (as the N = 1 line is): start the N ranks ourselves, as children, before any GPU call
+        sys.exit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -511,15 +662,33 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["VMPC_BENCH_STACKS_AFTER_S"]), repeat=True)
 
-    def give_up():
-        # a stuck kernel or collective must not look like success, nor hang the harness: report what there is
-        # and leave with a failure status
-        line = state["line"] or {"metric": "Ed25519 MSM scalar-mults/sec", "value": None, "n_gpus": world}
-        line["error"] = f"rank {rank}: no progress within {args.watchdog_s:.0f} s (stage: {state['stage']})"
+    # A stuck kernel or collective must not look like success, nor hang the harness: report what there is and leave
+    # with a failure status.  Stages that contain a first collective have a budget of their own, so that a launch that
+    # cannot communicate is over in minutes (the self-launcher then repeats the run with --comm torch).
+    stage_budget = {"init": 300.0, "communicator": 300.0, "warm-up": 420.0}
+    t_start = time.time()
+
+    def enter(stage):
+        state["stage"], state["since"] = stage, time.time()
+    state["since"] = t_start
+
+    def give_up(why):
+        line = state["line"] or {"metric": "Ed25519 MSM scalar-mults/sec", "value": None, "unit": "scalar-mults/s",
+                                 "n_gpus": world}
+        line["error"] = f"rank {rank}: {why} (stage: {state['stage']})"
         print(json.dumps(line), flush=True)
         os._exit(3)
-    watchdog = threading.Timer(args.watchdog_s, give_up)
-    watchdog.daemon = True
+
+    def watch():
+        while True:
+            time.sleep(1.0)
+            now = time.time()
+            if now - t_start > args.watchdog_s:
+                give_up(f"no result within {args.watchdog_s:.0f} s")
+            budget = stage_budget.get(state["stage"])
+            if budget is not None and now - state["since"] > budget:
+                give_up(f"stage made no progress within {budget:.0f} s")
+    watchdog = threading.Thread(target=watch, daemon=True)
     watchdog.start()
     if world > 1 or args.force_collective:
         import torch.distributed as dist
@@ -541,24 +710,38 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     # ---- the exchange: inside the C library when possible -------------------------------------------------
-    comm, comm_kind, comm_note = None, "none", None
+    # one communicator PER commitment slot (each slot = a stream of its own): parallel.make_comms
+    comm, comms, comm_kind, comm_note, comm_info = None, [], "none", None, None
+    n_slots_env = int(os.environ.get("VMPC_MSM_SLOTS", "3"))
     if dist:
-        state["stage"] = "communicator"
+        enter("communicator")
         want = "host" if args.dist_backend == "gloo" else ("rccl" if args.comm == "native" else None)
         if want:
             try:
-                comm = parallel.make_comm(ctx, world, rank, dist, torch, transport=want)
+                comms = parallel.make_comms(ctx, world, rank, dist, torch, transport=want,
+                                            count=1 if args.no_pipeline else n_slots_env)
             except Exception as e:
-                comm, comm_note = None, f"{type(e).__name__}: {e}"
-            # all or nothing: one rank without the native communicator puts every rank on torch.distributed
+                comms, comm_note = [], f"{type(e).__name__}: {e}"
+            # all or nothing: one rank without the native communicators puts every rank on torch.distributed
             flags = [None] * world
-            dist.all_gather_object(flags, comm is not None)
+            dist.all_gather_object(flags, bool(comms))
             if not all(flags):
-                if comm is not None:
-                    comm.close()
-                comm = None
+                for c_ in comms:
+                    c_.close()
+                comms = []
                 assert args.dist_backend == "nccl", f"host-staged communicator failed: {comm_note}"
+        comm = comms[0] if comms else None
         comm_kind = comm.kind if comm is not None else "torch.distributed"
+        # what the LIBRARY says about its communicators (an RCCL one asks ncclCommCount / ncclCommUserRank): the
+        # answer to "did the exchange really span N ranks" does not rest on WORLD_SIZE
+        if comms:
+            infos = [c_.info() for c_ in comms]
+            assert all(i["world"] == world and i["rank"] == rank for i in infos), f"communicator disagrees: {infos}"
+            comm_info = {"kind": infos[0]["kind"], "world": infos[0]["world"], "communicators": len(infos),
+                         "source": "vmpc_comm_info"}
+        else:
+            comm_info = {"kind": "torch.distributed", "world": dist.get_world_size(), "communicators": 0,
+                         "source": "torch.distributed.get_world_size"}
 
     n = 1 << args.log2n
     rng = np.random.default_rng(20200152 + 1 + rank)
@@ -581,7 +764,8 @@ def main():
     points_plain = points
     if not args.variable_base:
         points = points_prepared
-    shard = parallel.ShardedMsm(ctx, world, rank, dist, torch, force_collective=args.force_collective, comm=comm)
+    shard = parallel.ShardedMsm(ctx, world, rank, dist, torch, force_collective=args.force_collective,
+                                comm=comms if comms else None)
     depth = 1 if args.no_pipeline else (min(args.depth, shard.n_slots) if args.depth > 0 else shard.n_slots)
 
     def steps(k, pts):
@@ -602,40 +786,62 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    state["stage"] = "warm-up"
+    enter("warm-up")
     grow_workspaces(points)
     if args.warmup:
         steps(args.warmup, points)
     torch.cuda.synchronize()
     barrier()
     prof_ctxs = list(getattr(shard.backend, "ctxs", [ctx]))[:depth]
-    timed_profile = os.environ.get("VMPC_BENCH_TIMED_PROFILE", "1") != "0"    # (A/B: what the stage events cost)
-    for c_ in prof_ctxs:
-        c_.profile(timed_profile)
-        c_.profile_read(reset=True)
-    torch.cuda.synchronize()
-    state["stage"] = "timed region"
-    t0 = time.perf_counter()
-    results, result_idx = steps(args.steps, points)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    def timed(pts, reps):
+        """`reps` repetitions of EXACTLY K steps, each bracketed by barrier + device synchronisation on both sides,
+        max over ranks; no stage events on the streams.  Returns (seconds per repetition, result of the last)."""
+        runs, res = [], None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            res = steps(args.steps, pts)
+            torch.cuda.synchronize()
+            barrier()
+            dt = time.perf_counter() - t0
+            if dist:
+                t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            runs.append(dt)
+        return runs, res
+
+    enter("timed region")
+    # the headline: median of `--repeats` back-to-back repetitions of the K-step region (one 20-60 ms window used to
+    # decide it; boxes and windows differ by several per cent), min / max reported beside it
+    elapsed_runs, (results, result_idx) = timed(points, args.repeats)
+    elapsed = sorted(elapsed_runs)[len(elapsed_runs) // 2]
+    # once more with the per-stage HIP events on every stream the kernels are launched on: the in-region kernel
+    # durations of the roofline entry (not part of the headline: the events themselves cost time)
+    timed_profile = os.environ.get("VMPC_BENCH_TIMED_PROFILE", "1") != "0"
     prof = {}
-    for c_ in prof_ctxs:       # HIP events on each stream the kernels were launched on
-        for name, (ms, cnt) in c_.profile_read(reset=True).items():
-            a, b = prof.get(name, (0.0, 0))
-            prof[name] = (a + ms, b + cnt)
-        c_.profile(False)
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if timed_profile:
+        for c_ in prof_ctxs:
+            c_.profile(True)
+            c_.profile_read(reset=True)
+        torch.cuda.synchronize()
+        barrier()
+        steps(args.steps, points)
+        torch.cuda.synchronize()
+        barrier()
+        for c_ in prof_ctxs:       # HIP events on each stream the kernels were launched on
+            for name, (ms, cnt) in c_.profile_read(reset=True).items():
+                a, b = prof.get(name, (0.0, 0))
+                prof[name] = (a + ms, b + cnt)
+            c_.profile(False)
     ctx.sync()
 
     # outside the timed region: the same commitment alone on the GPU (one in flight), so that
     # the per-stage durations are not stretched by the other in-flight commitments' kernels,
     # and the integer-ALU ceiling the bucket stage is priced against (DESIGN.md section 5)
-    state["stage"] = "one commitment alone"
+    enter("one commitment alone")
     iso, alu_peak, iso_ms, iso_steps = {}, None, None, 5
     c0 = prof_ctxs[0]
     # (every rank: with a collective the launches are collective too)
@@ -678,23 +884,18 @@ def main():
         except Exception as e:
             alone_table = {"error": f"{type(e).__name__}: {e}"}
     # the other generator form, same K steps, same brackets
-    state["stage"] = "other generator form"
+    enter("other generator form")
     other_pts = points_plain if points is points_prepared else points_prepared
     grow_workspaces(other_pts)
     if args.warmup:
         steps(args.warmup, other_pts)
-    torch.cuda.synchronize()
-    barrier()
-    t2 = time.perf_counter()
-    other_results, other_idx = steps(args.steps, other_pts)
-    torch.cuda.synchronize()
-    barrier()
-    other_elapsed = time.perf_counter() - t2
+    other_runs, (other_results, other_idx) = timed(other_pts, args.repeats)
+    other_elapsed = sorted(other_runs)[len(other_runs) // 2]
     no_check = bool(os.environ.get("BENCH_NO_CHECK"))          # (developer A/B builds that break the result)
 
     # size-independent correctness property at full size, for every commitment of the last launch:
     #     sum_i s_i * (e_i * B) == (sum_i s_i e_i mod l) * B,     the sum running over ALL ranks' shards
-    state["stage"] = "result check"
+    enter("result check")
     checked = False
     if not no_check:
         need = sorted(set(result_idx) | set(other_idx))
@@ -742,6 +943,12 @@ def main():
                        "commitments_per_launch": batch,
                        "scalar_vectors": f"{len(scalar_vectors)} distinct (one per commitment of a launch)",
                        "timing": {"throughput_ms_per_commitment": round(elapsed / args.steps * 1e3, 4),
+                                  "repeats": len(elapsed_runs),
+                                  "ms_per_step_of_each_repeat": [round(e / args.steps * 1e3, 4) for e in elapsed_runs],
+                                  "ms_per_step_min": round(min(elapsed_runs) / args.steps * 1e3, 4),
+                                  "ms_per_step_max": round(max(elapsed_runs) / args.steps * 1e3, 4),
+                                  "headline": "median of the repeats (each: EXACTLY K steps between barrier + device "
+                                              "synchronisation, max over ranks)",
                                   "latency_ms_one_commitment_alone": round(iso_ms, 4),
                                   "latency_ms_one_commitment_alone_over_4row_table":
                                       (alone_table or {}).get("ms_per_commitment"),
@@ -756,7 +963,10 @@ def main():
                        "variable_base_scalar_mults_per_s": round(var_value, 1),
                        "collective": (f"all_gather(128 B/rank and commitment) + rank-ordered add, transport: {comm_kind}"
                                       if shard.collective else "none"),
-                       "dist_backend": args.dist_backend if dist else None},
+                       "dist_backend": args.dist_backend if dist else None,
+                       "comm": comm_info,
+                       "launched_by": ("bench.py itself (child processes)" if os.environ.get("VMPC_BENCH_SELF_LAUNCHED")
+                                       else "external launcher" if "WORLD_SIZE" in os.environ else "plain process")},
             "roofline": {"bound": "hbm", "kernel": "k_msm_bucket", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic["bytes"], "traffic_source": traffic["source"],
@@ -817,20 +1027,38 @@ def main():
                                        for k, v in bn256_timing(vm, ctx, 18).items()}
             except Exception as e:
                 line["bn256_n2^18"] = {"error": f"{type(e).__name__}: {e}"}
-    sharded_info = None
+    sharded_info, sharded_weak, cfg4 = None, None, None
+    if dist and world > 1 and args.config4_log2n > 0:
+        enter("config 4")
+        try:
+            cfg4 = config4_timing(vm, parallel, shard, args.config4_log2n, world, rank, dist, barrier, torch)
+        except Exception as e:
+            cfg4 = {"error": f"{type(e).__name__}: {e}"}
     if dist and (args.sharded_prove or (world > 1 and not args.no_sharded_prove)):
         # every rank takes part; a failure here must not cost the headline line (a stuck collective ends in the
         # watchdog: line + error entry, exit status 3)
-        state["stage"] = "sharded prove"
-        try:
-            sharded_info = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in
-                            sharded_prove_timing(vm, ctx, args.sharded_log2n, world, rank, dist, torch, comm).items()}
-        except Exception as e:
-            sharded_info = {"error": f"{type(e).__name__}: {e}"}
-    state["stage"] = "done"
+        enter("sharded prove")
+
+        def run_sharded(lg):
+            try:
+                return {k: (round(v, 2) if isinstance(v, float) else v) for k, v in
+                        sharded_prove_timing(vm, ctx, lg, world, rank, dist, torch, comm).items()}
+            except Exception as e:
+                return {"error": f"{type(e).__name__}: {e}"}
+        sharded_info = run_sharded(args.sharded_log2n)
+        if world > 1 and (world & (world - 1)) == 0:
+            # weak scaling: 2^sharded_log2n generators PER RANK (the size at which a block is folded locally and the
+            # rounds are not latency-bound)
+            enter("sharded prove, weak scaling")
+            sharded_weak = run_sharded(args.sharded_log2n + world.bit_length() - 1)
+    enter("done")
     if rank == 0:
         if sharded_info is not None:
             line[f"ac20_n2^{args.sharded_log2n}_sharded"] = sharded_info
+        if sharded_weak is not None:
+            line[f"ac20_n2^{args.sharded_log2n + world.bit_length() - 1}_sharded_weak_scaling"] = sharded_weak
+        if cfg4 is not None:
+            line[f"msm_config4_n2^{args.config4_log2n}_over_{world}_gpus"] = cfg4
         try:        # RCCL's version banner sits in the C stdio buffer: push it out first, the JSON line is the last line
             import ctypes
             ctypes.CDLL(None).fflush(None)
@@ -839,8 +1067,8 @@ def main():
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()
-        if comm is not None:
-            comm.close()
+        for c_ in comms:
+            c_.close()
         dist.destroy_process_group()
 
 

@@ -72,6 +72,15 @@ int vmpc_ctx_profile(vmpc_ctx *ctx, int enable);
 /* sums since the last reset; names is a ';'-separated list matching ms[] */
 int vmpc_ctx_profile_read(vmpc_ctx *ctx, char *names, size_t names_len, double *ms,
                           uint64_t *launches, int max_stages, int reset);
+/* Phase pipelining of a stream of commitments (pivot.py:139-145 called proof after proof): the contexts of a pipeline
+ * share ONE bucket stream (vmpc_stream_create; priority < 0 = lowest).  Every commitment's bucket stage is then
+ * enqueued there - bucket kernels run one at a time, back to back, as persistent launches of `wgs_per_cu` 256-lane
+ * workgroups per CU (0 = the whole grid) that leave register-file room on every SIMD - while the sort of the next
+ * commitment and the reduction / recombination of the previous one run beside it on the contexts' own streams.
+ * Ordering is by events on the device; results and vmpc_ctx_sync behave as before.  NULL = off. */
+int vmpc_stream_create(int device, int priority, void **out_hip_stream);
+int vmpc_stream_destroy(void *hip_stream);
+int vmpc_ctx_set_bucket_stream(vmpc_ctx *ctx, void *hip_stream, int wgs_per_cu);
 /* Pippenger window width override (0 = automatic); for tuning / tests */
 int vmpc_ctx_set_window(vmpc_ctx *ctx, int c_bits);
 /* the window width and window count the planner uses for an n-term Ed25519 MSM */
@@ -173,7 +182,8 @@ int vmpc_comm_create_rccl(vmpc_ctx *ctx, const uint8_t unique_id[VMPC_COMM_ID_BY
 typedef int (*vmpc_exchange_fn)(void *user, const void *mine, void *gathered, size_t bytes_per_rank);
 int vmpc_comm_create_callback(int world, int rank, vmpc_exchange_fn fn, void *user, vmpc_comm **out);
 int vmpc_comm_destroy(vmpc_comm *comm);
-/* kind: 0 = self (world 1), 1 = RCCL, 2 = callback */
+/* kind: 0 = self (world 1), 1 = RCCL, 2 = callback.  For an RCCL communicator world / rank are what RCCL itself
+ * reports (ncclCommCount / ncclCommUserRank), not the values passed at creation. */
 int vmpc_comm_info(const vmpc_comm *comm, int *world, int *rank, int *kind);
 /* gathered (world x bytes_per_rank, device) = every rank's `mine`, in rank order; enqueued on ctx's stream */
 int vmpc_comm_allgather_dev(vmpc_comm *comm, vmpc_ctx *ctx, const void *mine, void *gathered, size_t bytes_per_rank);

@@ -237,3 +237,30 @@ def test_sharded_round_context_argument_checks(vm):
     plain = _native.P4Rounds(ctx, g2._table, 1, 1, z.ptr, z.ptr)
     assert plain.round(None) == (a0, b0) and plain.round(5) == (a1, b1) and plain.finish(7) == (z0, z1)
     plain.close()
+
+
+def test_round_context_rejects_noncanonical_witness_on_the_bucket_free_path(vm):
+    """N = 128 with a 16-row table: the rounds commit without buckets (k_p4_direct) and never recode a scalar, so the
+    canonical-residue check has to come from vmpc_p4_create itself: a z_hat entry >= l must surface as
+    VMPC_E_NONCANON at the first round's synchronisation, on this path like on the bucket path."""
+    import numpy as np
+    from verifiable_mpc_amd import _native
+    ctx = vm.get_context()
+    h = vm.EllipticCurve("Ed25519", "projective").generator
+    k = vm.Ed25519Point.repeat(h, 99)
+    g = vm.PointVector.fixed_base(h, list(range(2, 129)), keep_proj=False)       # 127 generators + h = 128
+    g.precompute([h, k], rows=16)
+    good = vm.ScalarVector.from_ints(list(range(1, 129)))
+    rounds = _native.P4Rounds(ctx, g._table, 1, 1, good.ptr, good.ptr)
+    rounds.round(None)                                                            # canonical input: accepted
+    rounds.close()
+    raw = np.zeros((128, 32), np.uint8)
+    raw[:, 0] = 3
+    raw[77] = 0xff                                                                # 2^256 - 1 >= l
+    bad = vm.ScalarVector.from_array(raw)
+    for z_ptr, l_ptr in ((bad.ptr, good.ptr), (good.ptr, bad.ptr)):
+        rounds = _native.P4Rounds(ctx, g._table, 1, 1, z_ptr, l_ptr)
+        with pytest.raises(_native.VmpcError) as e:
+            rounds.round(None)
+        assert e.value.code == _native.E_NONCANON
+        rounds.close()

@@ -39,6 +39,7 @@ SYMBOLS = [
     "vmpc_msm_table_fold_dev", "vmpc_msm_table_fold_table_dev", "vmpc_p4_create", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_run_compact", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
     "vmpc_comm_unique_id", "vmpc_comm_create_rccl", "vmpc_comm_create_callback", "vmpc_comm_destroy", "vmpc_comm_info",
     "vmpc_comm_allgather_dev", "vmpc_comm_points_allsum_dev", "vmpc_p4_create_sharded", "vmpc_gather_probe_dev", "vmpc_bn256_madd_rate",
+    "vmpc_stream_create", "vmpc_stream_destroy", "vmpc_ctx_set_bucket_stream",
 ]
 
 
@@ -82,6 +83,9 @@ def load_library():
         "vmpc_ctx_profile": (i32, [vp, i32]),
         "vmpc_ctx_profile_read": (i32, [vp, cp, sz, ctypes.POINTER(ctypes.c_double), u64p, i32, i32]),
         "vmpc_ctx_set_window": (i32, [vp, i32]),
+        "vmpc_stream_create": (i32, [i32, i32, ctypes.POINTER(vp)]),
+        "vmpc_stream_destroy": (i32, [vp]),
+        "vmpc_ctx_set_bucket_stream": (i32, [vp, vp, i32]),
         "vmpc_ed25519_msm_plan": (i32, [vp, sz, vp, vp]),
         "vmpc_ed25519_madd_rate": (i32, [vp, i32, vp]),
         "vmpc_ed25519_msm": (i32, [vp, vp, sz, vp]),
@@ -358,7 +362,9 @@ class Context:
                     b.free()
             self._pinned = {}
             self.trim()
-            self.lib.vmpc_ctx_destroy(self.handle)
+            # VMPC_E_INVAL while a round context (vmpc_p4) of this context is alive: keep the handle, so that the
+            # stream, workspace, event pool and arena are released by a later close() instead of leaking
+            _check(self.lib.vmpc_ctx_destroy(self.handle), "vmpc_ctx_destroy")
             self.handle = None
 
     def __del__(self):
@@ -412,6 +418,12 @@ class Context:
     def set_stream(self, stream_ptr):
         _check(self.lib.vmpc_ctx_set_stream(self.handle, ctypes.c_void_p(stream_ptr)),
                "vmpc_ctx_set_stream")
+
+    def set_bucket_stream(self, stream, wgs_per_cu=0):
+        """phase pipelining: bucket stages of this context run on the shared `stream` (a SharedStream or None)"""
+        _check(self.lib.vmpc_ctx_set_bucket_stream(self.handle, stream.handle if stream is not None else None,
+                                                   int(wgs_per_cu)), "vmpc_ctx_set_bucket_stream")
+        self._bucket_stream = stream        # keep it alive as long as this context points at it
 
     def set_window(self, c_bits):
         _check(self.lib.vmpc_ctx_set_window(self.handle, int(c_bits)), "vmpc_ctx_set_window")
@@ -704,6 +716,27 @@ class PendingDigests:
         return res
 
 
+class SharedStream:
+    """a HIP stream several contexts enqueue their bucket stages on (vmpc_stream_create; priority < 0: lowest)"""
+
+    def __init__(self, device=0, priority=-1):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self.lib.vmpc_stream_create(int(device), int(priority), ctypes.byref(h)), "vmpc_stream_create")
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.lib.vmpc_stream_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Comm:
     """vmpc_comm: the exchange step of the multi-GPU path (all-gather of partial points + rank-ordered add).
 
@@ -758,6 +791,12 @@ class Comm:
         k = ctypes.c_int()
         _check(self.lib.vmpc_comm_info(self.handle, None, None, ctypes.byref(k)), "vmpc_comm_info")
         return self.KINDS[k.value]
+
+    def info(self):
+        """{"kind", "world", "rank"} as the library reports them (an RCCL communicator asks RCCL itself)"""
+        w, r, k = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(self.lib.vmpc_comm_info(self.handle, ctypes.byref(w), ctypes.byref(r), ctypes.byref(k)), "vmpc_comm_info")
+        return {"kind": self.KINDS[k.value], "world": w.value, "rank": r.value}
 
     def allgather(self, ctx, mine_ptr, gathered_ptr, bytes_per_rank):
         _check(self.lib.vmpc_comm_allgather_dev(self.handle, ctx.handle, ctypes.c_void_p(mine_ptr),

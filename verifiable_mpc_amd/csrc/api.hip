@@ -66,6 +66,8 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
     if (sf && atoi(sf) >= 0) c->sort_fine_bits = atoi(sf);
     const char *rc = getenv("VMPC_REDUCE_MAX_CHUNKS");
     if (rc && atoi(rc) >= 256 && atoi(rc) <= 32768) c->reduce_max_chunks = atoi(rc);
+    const char *ro = getenv("VMPC_REDUCE_CHUNKS");
+    if (ro && atoi(ro) >= 64 && atoi(ro) <= 32768 && (atoi(ro) & (atoi(ro) - 1)) == 0) c->reduce_chunks_override = atoi(ro);
     const char *ss = getenv("VMPC_SEG_SHIFT_MIN");
     if (ss && atoi(ss) <= 0 && atoi(ss) >= -5) c->seg_shift_min = atoi(ss);
     *out = c;
@@ -87,6 +89,8 @@ extern "C" int vmpc_ctx_destroy(vmpc_ctx *ctx) {
         }
     for (auto e : ctx->event_pool) VMPC_IGNORE(hipEventDestroy(e));
     if (ctx->xevent) VMPC_IGNORE(hipEventDestroy(ctx->xevent));
+    if (ctx->ev_sorted) VMPC_IGNORE(hipEventDestroy(ctx->ev_sorted));
+    if (ctx->ev_bucketed) VMPC_IGNORE(hipEventDestroy(ctx->ev_bucketed));
     if (ctx->pin_event) VMPC_IGNORE(hipEventDestroy(ctx->pin_event));
     if (ctx->pin) VMPC_IGNORE(hipHostFree(ctx->pin));
     if (ctx->ws) VMPC_IGNORE(hipFree(ctx->ws));
@@ -157,6 +161,40 @@ extern "C" int vmpc_ctx_wait_for(vmpc_ctx *waiter, vmpc_ctx *other) {
     if (!other->xevent) VMPC_HIP_CHECK(hipEventCreateWithFlags(&other->xevent, hipEventDisableTiming));
     VMPC_HIP_CHECK(hipEventRecord(other->xevent, other->stream));
     VMPC_HIP_CHECK(hipStreamWaitEvent(waiter->stream, other->xevent, 0));
+    return VMPC_OK;
+}
+
+// ---- phase pipelining: a bucket stream shared by several contexts ------------------------------------------------
+extern "C" int vmpc_stream_create(int device, int priority, void **out) {
+    if (!out) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(device));
+    int lo = 0, hi = 0;                       // numerically lower = higher priority
+    VMPC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    int pr = priority > 0 ? hi : priority < 0 ? lo : (lo + hi) / 2;
+    hipStream_t st = nullptr;
+    VMPC_HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr));
+    *out = (void *)st;
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_stream_destroy(void *hip_stream) {
+    if (!hip_stream) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipStreamSynchronize((hipStream_t)hip_stream));
+    VMPC_HIP_CHECK(hipStreamDestroy((hipStream_t)hip_stream));
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_ctx_set_bucket_stream(vmpc_ctx *ctx, void *hip_stream, int wgs_per_cu) {
+    if (!ctx || wgs_per_cu < 0 || wgs_per_cu > 8) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    // (no synchronisation: the setting only affects calls made after it, and every call orders its own stages with
+    // events - a driver may switch it per call)
+    ctx->bucket_stream = (hipStream_t)hip_stream;
+    ctx->bucket_wgs_per_cu = wgs_per_cu;
+    if (hip_stream && !ctx->ev_sorted) {
+        VMPC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sorted, hipEventDisableTiming));
+        VMPC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_bucketed, hipEventDisableTiming));
+    }
     return VMPC_OK;
 }
 
@@ -310,16 +348,17 @@ int vmpc_stage_begin(vmpc_ctx *ctx, const char *name) {
         idx = (int)ctx->stages.size() - 1;
     }
     hipEvent_t a = take_event(ctx), b = take_event(ctx);
-    VMPC_IGNORE(hipEventRecord(a, ctx->stream));
+    VMPC_IGNORE(hipEventRecord(a, ctx->stage_stream ? ctx->stage_stream : ctx->stream));
     ctx->stages[idx].pending.push_back({a, b});
     return idx;
 }
 
 void vmpc_stage_end(vmpc_ctx *ctx, int handle) {
     if (handle < 0) return;
-    VMPC_IGNORE(hipEventRecord(ctx->stages[handle].pending.back().second, ctx->stream));
+    hipStream_t on = ctx->stage_stream ? ctx->stage_stream : ctx->stream;
+    VMPC_IGNORE(hipEventRecord(ctx->stages[handle].pending.back().second, on));
     if (debug_stages()) {
-        const hipError_t e = hipStreamSynchronize(ctx->stream);
+        const hipError_t e = hipStreamSynchronize(on);
         fprintf(stderr, "[vmpc] stage %s done (%s)\n", ctx->stages[handle].name, hipGetErrorString(e));
     }
 }
@@ -329,6 +368,7 @@ extern "C" int vmpc_ctx_profile_read(vmpc_ctx *ctx, char *names, size_t names_le
     if (!ctx) return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->bucket_stream) VMPC_HIP_CHECK(hipStreamSynchronize(ctx->bucket_stream));
     std::string all;
     int k = 0;
     for (auto &s : ctx->stages) {

@@ -19,6 +19,8 @@
 #include <rccl/rccl.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -27,16 +29,17 @@ struct rccl_api {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;          // optional: the communicator's own view
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;       // optional
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    bool tried = false;
+    int rc = VMPC_E_NODEV;          // outcome of the one load attempt
+    char error[256] = {0};          // ... and its diagnostic, repeated to every later caller
 };
 rccl_api g_rccl;
+std::once_flag g_rccl_once;
 
-int rccl_load() {
-    if (g_rccl.handle) return VMPC_OK;
-    if (g_rccl.tried) return VMPC_E_NODEV;
-    g_rccl.tried = true;
+void rccl_load_once() {
     const char *override_path = getenv("VMPC_RCCL_LIB");
     void *h = nullptr;
     if (override_path && *override_path) {
@@ -56,25 +59,36 @@ int rccl_load() {
         }
     }
     if (!h) {
-        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "librccl not found: %s", dlerror());
-        return VMPC_E_NODEV;
+        const char *why = dlerror();
+        snprintf(g_rccl.error, sizeof g_rccl.error, "librccl not found: %s", why ? why : "(no dlerror)");
+        return;
     }
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(h, "ncclCommUserRank");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
-        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "librccl lacks a required symbol");
+        snprintf(g_rccl.error, sizeof g_rccl.error, "librccl lacks a required symbol");
         dlclose(h);
-        return VMPC_E_NODEV;
+        return;
     }
-    g_rccl.handle = h;
     if (getenv("VMPC_DEBUG_STAGES")) {
         Dl_info info;
         if (dladdr((void *)g_rccl.AllGather, &info) && info.dli_fname) fprintf(stderr, "[vmpc] RCCL from %s\n", info.dli_fname);
     }
-    return VMPC_OK;
+    g_rccl.handle = h;
+    g_rccl.rc = VMPC_OK;
+}
+
+// One attempt per process, safe from any number of threads (the in-process tests run one context per thread); a
+// failed attempt is remembered WITH its diagnostic, so every later caller gets the same message.
+int rccl_load() {
+    std::call_once(g_rccl_once, rccl_load_once);
+    if (g_rccl.rc != VMPC_OK) snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "%s", g_rccl.error);
+    return g_rccl.rc;
 }
 
 int rccl_fail(const char *what, ncclResult_t r) {
@@ -150,8 +164,20 @@ extern "C" int vmpc_comm_destroy(vmpc_comm *c) {
 
 extern "C" int vmpc_comm_info(const vmpc_comm *c, int *world, int *rank, int *kind) {
     if (!c) return VMPC_E_INVAL;
-    if (world) *world = c->world;
-    if (rank) *rank = c->rank;
+    int w = c->world, r = c->rank;
+    if (c->kind == COMM_RCCL && c->nccl) {
+        // what RCCL itself says about this communicator, not what the caller passed at creation
+        if (g_rccl.CommCount) {
+            const ncclResult_t e = g_rccl.CommCount(c->nccl, &w);
+            if (e != ncclSuccess) return rccl_fail("ncclCommCount", e);
+        }
+        if (g_rccl.CommUserRank) {
+            const ncclResult_t e = g_rccl.CommUserRank(c->nccl, &r);
+            if (e != ncclSuccess) return rccl_fail("ncclCommUserRank", e);
+        }
+    }
+    if (world) *world = w;
+    if (rank) *rank = r;
     if (kind) *kind = c->kind;
     return VMPC_OK;
 }

@@ -52,6 +52,7 @@ struct vmpc_ctx {
     int window_override = 0;
     int bucket_wgs_per_cu = 0;     // > 0: persistent bucket kernel with this many 256-thread workgroups per CU
     int reduce_max_chunks = 32768; // most chunk-lanes per bucket set in the bucket reduction (msm_sort.hip)
+    int reduce_chunks_override = 0; // > 0: chunk-lanes per bucket set, fixed (power of two)
     int seg_shift_min = -3;        // shortest bucket segments the plan may choose: 64 >> 3 entries (msm_sort.hip)
     int sort_fine_bits = -1;       // fine bits of the two-level bucket sort; -1 = automatic (msm_sort.hip)
     int plan_fill_shift = 0;       // the next plan's digit rows are only 1 / 2^shift populated (the A_i, B_i pair of a
@@ -59,6 +60,13 @@ struct vmpc_ctx {
                                    // length follows the expected number of entries, not the number of positions
     int cu_count = 256;
     hipEvent_t xevent = nullptr;   // cross-context ordering (vmpc_ctx_wait_for)
+    // Phase pipelining (vmpc_ctx_set_bucket_stream): the bucket stage of every commitment of this context runs on a
+    // stream SHARED by the contexts of a pipeline - bucket kernels then run back to back, one at a time, and the sort
+    // of the next pass / the reduction and recombination of the previous one run beside them on the contexts' own
+    // streams (msm_accumulate).  Not owned.
+    hipStream_t bucket_stream = nullptr;
+    hipEvent_t ev_sorted = nullptr, ev_bucketed = nullptr;
+    hipStream_t stage_stream = nullptr;   // stream the next stage bracket's events are recorded on (nullptr: `stream`)
     // pinned staging for small host -> device parameter blocks (vmpc_stage_h2d)
     void *pin = nullptr;
     size_t pin_bytes = 0;

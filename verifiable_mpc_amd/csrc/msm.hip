@@ -405,15 +405,33 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
                           void *out_affine) {
     const int batch = p.W / p.period;        // commitments sharing this pass (1 unless vmpc_msm_table_batch_dev)
     hipStream_t st = ctx->stream;
+    // Phase pipelining: with a shared bucket stream the bucket kernels of a pipeline's contexts run one at a time,
+    // back to back, and leave room on every SIMD (persistent launch of bucket_wgs_per_cu workgroups per CU) for the
+    // sort of the next pass and the reduction / recombination of the previous one on the contexts' own streams.
+    hipStream_t bst = ctx->bucket_stream ? ctx->bucket_stream : st;
+    if (ctx->bucket_stream) {
+        VMPC_HIP_CHECK(hipEventRecord(ctx->ev_sorted, st));
+        VMPC_HIP_CHECK(hipStreamWaitEvent(bst, ctx->ev_sorted, 0));
+    }
     {
+        ctx->stage_stream = ctx->bucket_stream;
         vmpc_stage_scope s(ctx, "msm_bucket");
         unsigned grid = (unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK);
         if (ctx->bucket_wgs_per_cu > 0 && (unsigned)(ctx->bucket_wgs_per_cu * ctx->cu_count) < grid)
             grid = (unsigned)(ctx->bucket_wgs_per_cu * ctx->cu_count);
-        k_msm_bucket<<<grid, MSM_BLOCK, 0, st>>>(
+        k_msm_bucket<<<grid, MSM_BLOCK, 0, bst>>>(
             entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
             (int)msm_seg_len(p), w.buckets, w.seg_partial);
-        VMPC_KERNEL_CHECK();
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            ctx->stage_stream = nullptr;
+            VMPC_HIP_CHECK(e);
+        }
+    }
+    ctx->stage_stream = nullptr;
+    if (ctx->bucket_stream) {
+        VMPC_HIP_CHECK(hipEventRecord(ctx->ev_bucketed, bst));
+        VMPC_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_bucketed, 0));
     }
     {
         vmpc_stage_scope s(ctx, "msm_bucket_finish");

@@ -646,6 +646,7 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
     // (with few windows - fixed-base tables - more chunk-lanes per window keep the same ~64 K lanes busy)
     int chunks = MSM_REDUCE_CHUNKS;
     while (chunks * 2 * p.W <= MSM_REDUCE_CHUNKS * 16 && chunks * 2 <= ctx->reduce_max_chunks) chunks *= 2;
+    if (ctx->reduce_chunks_override >= 64) chunks = ctx->reduce_chunks_override;        // (experiment / throughput mode)
     if (chunks > p.nb) chunks = p.nb;
     p.chunks = chunks;
     p.chunk_len = p.nb / chunks;

@@ -206,6 +206,8 @@ k_p4_direct_sum(const uint32_t *__restrict__ partial, unsigned blocks_per, uint3
     p4d_tree(lds, acc, out_ext + 32 * blockIdx.x, true);
 }
 
+int vmpc_fr_check_dev(vmpc_ctx *ctx, const void *v, size_t n);      // frvec.hip: bumps the status word, no sync
+
 int vmpc_table_fold_table_with_block(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
                                      size_t n_cols, int k, const uint8_t *scalars, size_t n_extra, int out_rows,
                                      const void *extras_block, void *out_table);   // fold_jump.hip
@@ -410,6 +412,11 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     int rc = vmpc_memcpy_h2d(ctx, p->k_aff, k_affine, 64);
     if (rc == VMPC_OK) rc = vmpc_memcpy_d2d(ctx, p->z[0], z_hat, 32 * N);
     if (rc == VMPC_OK) rc = vmpc_memcpy_d2d(ctx, p->L[0], L_tilde, 32 * N);
+    // canonical residues?  Counted into the context's status word here, for EVERY path the rounds may take (the
+    // bucket-free commitments of short vectors never recode, so they would not notice); the first round's
+    // vmpc_ctx_sync reports it as VMPC_E_NONCANON.  Two streaming reads of 32 N bytes.
+    if (rc == VMPC_OK) rc = vmpc_fr_check_dev(ctx, p->z[0], N);
+    if (rc == VMPC_OK) rc = vmpc_fr_check_dev(ctx, p->L[0], N);
     if (rc != VMPC_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         p4_release(p);
@@ -594,6 +601,7 @@ static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
     } else {
         // v_a and v_b are each zero on half of their positions (z_l against g_r, z_r against g_l): tell the planner
         ctx->plan_fill_shift = 1;
+        if (const char *e = getenv("VMPC_P4_FILL_SHIFT")) ctx->plan_fill_shift = atoi(e);       // (experiment)
         // digit width of the commitments over a FOLDED vector's table (VMPC_P4_SMALL_WINDOW, tuning knob)
         const int saved_window = ctx->window_override;
         if (p->small_window && p->table != p->table0) ctx->window_override = p->small_window;

@@ -48,8 +48,24 @@ class HipBackend:
         from .device import get_aux_context
         if n_slots is None:
             n_slots = int(os.environ.get("VMPC_MSM_SLOTS", "3"))
+        # comm: one communicator for every slot, or a list with one PER SLOT (make_comms) - each slot's exchange
+        # then has a communicator and a stream of its own, the shape RCCL is run in everywhere (one communicator
+        # per stream); slots beyond the list share its last entry
+        self.comms = list(comm) if isinstance(comm, (list, tuple)) else ([comm] if comm is not None else [])
+        comm = self.comms[0] if self.comms else None
         self.torch, self.comm = torch, comm
         self.ctxs = [ctx] + [get_aux_context(10 + i) for i in range(max(0, n_slots - 1))]
+        # Phase pipelining (include/vmpc.h vmpc_ctx_set_bucket_stream): the slots share one bucket stream, so their
+        # bucket kernels run back to back, one at a time, each a persistent launch that leaves register-file room
+        # for the sort of the next pass and the reduction / recombination of the previous one.
+        # VMPC_BUCKET_STREAM=0 turns it off (each slot's whole pipeline on its own stream, as in rounds 1-3).
+        self.bucket_stream = None
+        wgs = int(os.environ.get("VMPC_PIPE_BUCKET_WGS_PER_CU", "3"))
+        if n_slots > 1 and os.environ.get("VMPC_BUCKET_STREAM", "1") != "0":
+            from ._native import SharedStream
+            self.bucket_stream = SharedStream(ctx.device, int(os.environ.get("VMPC_BUCKET_STREAM_PRIORITY", "-1")))
+        self.bucket_wgs = wgs
+        self.pipelined = False      # set by a driver that keeps several launches in flight (bench.run_steps)
         self.max_batch = 16
         world = comm.world if comm is not None else 1
         if comm is not None or torch is None:
@@ -77,8 +93,23 @@ class HipBackend:
         # the partial (or, single-GPU, final) sum stays in extended coordinates on the device;
         # normalising one point is O(1) host glue
         ctx = self.ctxs[slot]
-        if ctx is not self.ctxs[0]:
+        if ctx is not self.ctxs[0] and not self.pipelined:
+            # inputs produced on the main context's stream just before this call (a prover's scalars).  A driver
+            # that keeps several launches in flight (pipelined) has completed its inputs beforehand - there this
+            # wait would chain every slot behind the main slot's commitment IN FLIGHT and march the slots in
+            # lockstep (round 4 trace: profiles/r04_probes/timeline_lockstep.txt)
             ctx.wait_for(self.ctxs[0])
+        if self.bucket_stream is not None and self.pipelined:
+            # for this call only: the contexts also serve callers that run one commitment at a time (the prover),
+            # whose bucket stage should have the whole chip
+            ctx.set_bucket_stream(self.bucket_stream, self.bucket_wgs)
+            try:
+                return self._launch_partial(ctx, scalars, points, slot)
+            finally:
+                ctx.set_bucket_stream(None, 0)
+        return self._launch_partial(ctx, scalars, points, slot)
+
+    def _launch_partial(self, ctx, scalars, points, slot):
         table = getattr(points, "_table", None)
         if isinstance(scalars, (list, tuple)):
             # a BATCH of commitments over the same prepared generators in one pass (vmpc_msm_table_batch_dev):
@@ -98,8 +129,9 @@ class HipBackend:
 
     def enqueue_allsum(self, slot):
         """the single curve-point exchange + ordered add of this slot's batch, behind its MSM on its stream"""
-        self.comm.points_allsum(self.ctxs[slot], self.partial_ptrs[slot], self.batch_of[slot], self.scratch_ptrs[slot],
-                                self.combine_ptrs[slot])
+        comm = self.comms[min(slot, len(self.comms) - 1)]
+        comm.points_allsum(self.ctxs[slot], self.partial_ptrs[slot], self.batch_of[slot], self.scratch_ptrs[slot],
+                           self.combine_ptrs[slot])
 
     def allsum_result(self, slot):
         self.ctxs[slot].sync()
@@ -149,20 +181,21 @@ class ShardedMsm:
     finish in the same order."""
 
     def __init__(self, ctx, world, rank, dist=None, torch=None, backend=None, force_collective=False, comm=None):
-        self.world, self.rank, self.dist, self.comm = world, rank, dist, comm
-        assert comm is None or (comm.world == world and comm.rank == rank)
+        first = comm[0] if isinstance(comm, (list, tuple)) else comm
+        self.world, self.rank, self.dist, self.comm = world, rank, dist, first
+        assert first is None or (first.world == world and first.rank == rank)
         self.backend = backend if backend is not None else HipBackend(ctx, torch, comm=comm)
         self.collective = world > 1 or force_collective
         # wait for the collective only: RCCL runs on torch's current stream; a device-wide
         # synchronize here would also drain the other commitments in flight on their own streams
         self.sync_device = None
-        if torch is not None and backend is None and comm is None:
+        if torch is not None and backend is None and first is None:
             def _wait_collective():
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
                 ev.synchronize()
             self.sync_device = _wait_collective
-        self.gathered = self.backend.new_gather_buffer(world) if self.collective and comm is None else None
+        self.gathered = self.backend.new_gather_buffer(world) if self.collective and first is None else None
 
     @property
     def n_slots(self):
@@ -194,6 +227,12 @@ class ShardedMsm:
 
     def commit(self, scalars, points):
         return self.finish(self.launch(scalars, points, 0))
+
+
+def make_comms(ctx, world, rank, dist, torch=None, transport="rccl", count=1):
+    """`count` independent communicators of the same process group (one per commitment slot of HipBackend): every
+    rank creates them in the same order, each from its own unique id."""
+    return [make_comm(ctx, world, rank, dist, torch, transport) for _ in range(count)]
 
 
 def make_comm(ctx, world, rank, dist, torch=None, transport="rccl"):

@@ -231,6 +231,9 @@ def scalars_to_array(values):
         vals = [int(v) for v in vals]
     try:
         raw = b"".join([v.to_bytes(32, "little") for v in vals])       # (negatives and values >= 2^256 raise)
+    except AttributeError:                                             # field elements after a leading int
+        vals = [int(v) for v in vals]
+        return scalars_to_array(vals)
     except OverflowError:
         raw = b"".join([(v % ORDER).to_bytes(32, "little") for v in vals])
         return np.frombuffer(raw, np.uint8).reshape(-1, 32)
