@@ -65,6 +65,19 @@ def pmc_traffic_calibrated(kernel):
                              "fetch_factor": cal["fetch_factor"], "factor_from": cal["factor_from"],
                              "structural_bytes": cal.get("structural_bytes"),
                              "revision": d.get("revision")}
+            # is the kernel the counters were taken on the kernel of THIS tree?  (sha-256 of its sources, recorded by
+            # scripts/profile_round.sh in the same pass - the GPU box has no .git to diff against)
+            import hashlib
+            recorded, changed = d.get("kernel_sources_sha256") or {}, []
+            for rel, digest in recorded.items():
+                try:
+                    with open(os.path.join(ROOT, rel), "rb") as fsrc:
+                        if hashlib.sha256(fsrc.read()).hexdigest() != digest:
+                            changed.append(rel)
+                except OSError:
+                    changed.append(rel)
+            out["detail"]["kernel_sources_changed_since_the_pmc_pass"] = (changed if recorded else
+                                                                          "unknown (summary older than round 4)")
         else:       # summaries of earlier rounds: the guide's streaming-read factor, uncalibrated for a gather
             out["bytes"] = k["hbm_bytes_per_launch_corrected"]
             out["detail"] = {"note": "2 x FETCH_SIZE (streaming-read correction), not calibrated for this pattern"}
@@ -185,19 +198,51 @@ def prove_timing(vm, ctx, n_pow, rng):
         for attempt in range(4):                 # the first call grows the stream workspaces; then 3 timed
             r = vm.ScalarVector.from_array(rand_scalars(rng, n))
             ctx.sync()
+            vm.pivot.hash_stats(reset=True)
             t0 = time.perf_counter()
             proof = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, gamma, gf, transcript=mode,
                                                           r=r, rho=0x1111)
             ctx.sync()
             runs.append((time.perf_counter() - t0) * 1e3)
+        prove_hash = vm.pivot.hash_stats(reset=True)
         out[f"prove_ms_{mode}_first_call"] = runs[0]
         out[f"prove_ms_{mode}"] = sorted(runs[1:])[1]            # median of the three steady runs
         out[f"prove_ms_{mode}_min"] = min(runs[1:])
         for key in (f"verify_ms_{mode}_first_call", f"verify_ms_{mode}"):     # second call: contexts and buffers exist
+            vm.pivot.hash_stats(reset=True)
             t0 = time.perf_counter()
             ok = vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, proof, gf, transcript=mode)
             out[key] = (time.perf_counter() - t0) * 1e3
             assert ok is True
+        if mode == "reference":
+            # The floor of the reference's transcript: one sequential SHA-256 over the decimal text of every round's
+            # generators and form (pivot.py:131-136) on ONE host core.  Measured, not asserted: the same number of
+            # bytes through hashlib alone (64-MiB pieces of a resident buffer), and the time the prover itself spent
+            # inside update().
+            import hashlib
+            nbytes = prove_hash["bytes"]
+            buf = np.random.default_rng(1).integers(48, 58, size=min(nbytes, 64 << 20), dtype=np.uint8)   # digits
+            floors = []
+            for _ in range(3):
+                h = hashlib.sha256()
+                t0 = time.perf_counter()
+                left = nbytes
+                while left > 0:
+                    h.update(memoryview(buf)[:min(left, len(buf))])
+                    left -= len(buf)
+                h.digest()
+                floors.append((time.perf_counter() - t0) * 1e3)
+            floor = min(floors)
+            vh = vm.pivot.hash_stats(reset=True)
+            out["hash_floor"] = {
+                "bytes_hashed_per_prove": nbytes, "hash_floor_ms": round(floor, 2),
+                "host_sha256_GBps": round(nbytes / floor / 1e6, 3),
+                "prove_ms_inside_sha256_update": round(prove_hash["seconds"] * 1e3, 2),
+                "prove_over_floor": round(out["prove_ms_reference"] / floor, 4),
+                "verify_bytes_hashed": vh["bytes"],
+                "verify_over_floor": round(out["verify_ms_reference"] / (floor * vh["bytes"] / max(nbytes, 1)), 4),
+                "what": "floor = hashlib.sha256 alone over the same number of bytes on one host core (best of 3); "
+                        "the reference's transcript format makes this sequential hash inherent (pivot.py:131-136)"}
         # a Protocol-5 prove moves ~768 * N algorithmic bytes (two N-term commitments + per round
         # two half-size commitments, the fold and the scalar folds); Fiat-Shamir text excluded
         alg = 768 * N

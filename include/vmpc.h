@@ -256,6 +256,12 @@ int vmpc_fr_dot_dev(vmpc_ctx *ctx, const void *a, const void *b, size_t n, uint8
 /* the same, result left in device memory (32 bytes at out_dev, asynchronous) */
 int vmpc_fr_dot_to_dev(vmpc_ctx *ctx, const void *a, const void *b, size_t n, void *out_dev);
 
+/* How the reference's str(input_list) prints a curve point is recalled from MPyC, not observed:
+ * the bracket pair ('[' ']' or '(' ')') and whether a coordinate c > (p - 1) / 2 prints as -(p - c).  Process-wide,
+ * effective for every later formatting call, no rebuild (scripts/check_against_mpyc.py names the call to make when
+ * real MPyC prints otherwise).  Scalar signedness travels with each call (is_signed below).  Defaults: '[' ']' 0. */
+int vmpc_set_reference_format(char point_open, char point_close, int coord_signed);
+int vmpc_get_reference_format(char *point_open, char *point_close, int *coord_signed);
 /* Text of the Fiat-Shamir pre-image (pivot.py:134 str(input_list)) produced on device:
  * "item0, item1, ..., item{n-1}, " (every item followed by ", ").  Synchronous; *len gets
  * the number of bytes written, VMPC_E_NOMEM if cap is too small. */
@@ -263,7 +269,7 @@ int vmpc_format_points_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *out_
                            uint64_t *len);
 int vmpc_format_scalars_dev(vmpc_ctx *ctx, const void *scalars, size_t n, int is_signed,
                             void *out_text, size_t cap, uint64_t *len);
-/* Asynchronous forms: text is produced into `dev_text` (cap >= n * 242 for points, n * 81 for
+/* Asynchronous forms: text is produced into `dev_text` (cap >= n * 245 for points, n * 81 for
  * scalars) and copied, with its length, into PINNED host memory (vmpc_host_alloc) on the context's
  * stream; nothing is valid until that stream has been synchronised (vmpc_ctx_sync). */
 int vmpc_format_points_async_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *dev_text, size_t cap,

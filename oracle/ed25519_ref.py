@@ -21,8 +21,8 @@ MPyC's *published* algorithm as recalled [mpyc-recall]:
                        printed as an unsigned decimal integer;
   * repr(scalar in GF(l)) = SIGNED decimal integer in (-l/2, l/2].
 
-PARITY STATUS: the curve layer is pinned by RFC 8032 constants/KATs
-(tests/test_oracle_ed25519.py); the byte-level formats of real MPyC (repr
+PARITY STATUS: the curve layer is pinned by RFC 8032 constants/KATs and by 256 OpenSSL-made key pairs and
+signatures (tests/test_oracle_golden.py, tests/test_oracle_openssl.py); the byte-level formats of real MPyC (repr
 brackets, signedness, exact projective formulas) are "parity unpinned" - they
 cannot be checked in this container.  Group elements are canonical once
 affine-normalised, so affine-level results do not depend on that recall.
@@ -40,7 +40,16 @@ SQRT_M1 = pow(2, (P - 1) // 4, P)
 # representation switches of the [mpyc-recall] formats (one place to change)
 POINT_REPR_OPEN = "["
 POINT_REPR_CLOSE = "]"
+COORD_REPR_SIGNED = False       # a coordinate c > (p - 1) / 2 printed as -(p - c)
 SCALAR_REPR_SIGNED = True
+
+
+def set_format(point_brackets="[]", coord_signed=False, scalar_signed=True):
+    """the oracle's side of verifiable_mpc_amd.set_reference_format (same arguments, same meaning)"""
+    global POINT_REPR_OPEN, POINT_REPR_CLOSE, COORD_REPR_SIGNED, SCALAR_REPR_SIGNED
+    assert point_brackets in ("[]", "()")
+    POINT_REPR_OPEN, POINT_REPR_CLOSE = point_brackets[0], point_brackets[1]
+    COORD_REPR_SIGNED, SCALAR_REPR_SIGNED = bool(coord_signed), bool(scalar_signed)
 
 
 def _recover_x(y, sign):
@@ -166,8 +175,11 @@ def pt_eq(p1, p2):
 
 def pt_repr(p1):
     """repr() of a point as it enters str(input_list) in pivot.py:134 [mpyc-recall]."""
+    def c(v):
+        v %= P
+        return v - P if COORD_REPR_SIGNED and v > P // 2 else v
     x, y, z = p1
-    return f"{POINT_REPR_OPEN}{x}, {y}, {z}{POINT_REPR_CLOSE}"
+    return f"{POINT_REPR_OPEN}{c(x)}, {c(y)}, {c(z)}{POINT_REPR_CLOSE}"
 
 
 def scalar_repr(v):

@@ -42,6 +42,7 @@ def first_diff(a, b):
 class Report:
     def __init__(self):
         self.failed = 0
+        self.format_note = None
 
     def check(self, what, got, want):
         if got == want:
@@ -97,6 +98,34 @@ def main():
     ogf = our_fields.GF(ed.ELL)
     ogroup = our_groups.EllipticCurve("Ed25519", "projective")
 
+    # 0. Which of the three recalled printing choices does THIS MPyC make?  They are runtime switches of the product
+    # (verifiable_mpc_amd.set_reference_format) and of the oracle (oracle.ed25519_ref.set_format): a difference here is
+    # fixed by the call printed below, not by editing a kernel - and the rest of the comparison runs with it applied.
+    import verifiable_mpc_amd as vm
+    print("0. printing choices of this MPyC (brackets of a point, signed coordinates, signed scalars)")
+    rg = repr(group.generator)            # the generator's y coordinate is > (p - 1) / 2: signed printing shows a '-'
+    seen = {"point_brackets": {"[": "[]", "(": "()"}.get(rg[:1]),
+            "coord_signed": "-" in rg,
+            "scalar_signed": repr(gf(-1)) == "-1"}
+    ours = vm.get_reference_format()
+    if seen["point_brackets"] is None:
+        rep.failed += 1
+        print(f"  DIFF  a point prints as {rg[:40]!r}...: neither '[x, y, z]' nor '(x, y, z)' - the point format needs "
+              "a new variant in csrc/fmt.h (fmt_point_style) and groups.Ed25519Point.__repr__")
+        seen["point_brackets"] = ours["point_brackets"]
+    if seen == ours:
+        print(f"  ok    same as this build's defaults {ours}")
+    else:
+        call = ", ".join(f"{k}={v!r}" for k, v in seen.items() if v != ours[k])
+        print(f"  NOTE  real MPyC prints {seen}, this build assumes {ours}.")
+        print(f"        The fix is ONE call, before any proof is made:   verifiable_mpc_amd.set_reference_format({call})")
+        print(f"        (tests: oracle.ed25519_ref.set_format{tuple(seen.values())!r}); make it the default in "
+              "verifiable_mpc_amd/formats.py _DEFAULT, csrc/format.hip g_point_style, oracle/ed25519_ref.py.")
+        print("        The comparisons below run WITH that setting applied.")
+        vm.set_reference_format(**seen)
+        ed.set_format(seen["point_brackets"], seen["coord_signed"], seen["scalar_signed"])
+        ogf = our_fields.GF(ed.ELL)
+        rep.format_note = call
     print("1. element formats (pivot.py:134 hashes str(input_list))")
     rep.check("group.order", int(group.order), ed.ELL)
     for v in (0, 1, 5, -1, ed.ELL - 1, ed.ELL // 2, ed.ELL // 2 + 1, 2**200 + 12345):
@@ -145,21 +174,44 @@ def main():
         with open(os.path.join(REPO, "tests", "golden", "ac20_ed25519_small.json")) as f:
             want = json.load(f)["p5"][0]
         got = json.loads(json.dumps(mf.p5_case(3, mf.SEED, keep_text=True, keep_proj=True), sort_keys=True))
-        for key in sorted(want):
-            if key == "hashes":
-                continue
-            rep.check(f"fixture[{key!r}]", got.get(key), want[key])
-        rep.check("number of Fiat-Shamir hashes", len(got["hashes"]), len(want["hashes"]))
-        for i, (hg, hw) in enumerate(zip(got["hashes"], want["hashes"])):
-            if rep.check(f"pre-image {i}: text ({hw['len']} bytes)", hg.get("text"), hw.get("text")):
-                rep.check(f"pre-image {i}: challenge", hg["c"], hw["c"])
-            else:
-                print("        (later challenges differ as a consequence)")
-                break
+        if rep.format_note:
+            # the stored pre-image texts are in the default format: under the switched format the ORACLE recomputes the
+            # case from the fixture's inputs (same switches), and real MPyC's proof and challenges must equal that
+            h2i = lambda v: int(v, 16)
+            hx = lambda v: format(v % (1 << 256), "x")
+            ogens = ac.create_generators([h2i(v) for v in want["gen_exponents"]], h2i(want["gen_exponent_k"]))
+            x, coeffs = [h2i(v) for v in want["x"]], [h2i(v) for v in want["L"]]
+            oP = ac.vector_commitment(x, h2i(want["gamma"]), ogens["g"], ogens["h"])
+            tr = {}
+            op = ac.protocol_5_prover(ogens, oP, coeffs, 0, h2i(want["y"]), x, h2i(want["gamma"]),
+                                      [h2i(v) for v in want["r"]], h2i(want["rho"]), "reference", trace=tr)
+            aff = lambda pt: [hx(c) for c in ed.pt_affine(pt)]
+            rep.check("proof t (oracle, switched format)", got["proof"]["t"], hx(op["t"]))
+            rep.check("proof A", got["proof"]["A"], aff(op["A"]))
+            rep.check("proof A_0, B_0", [got["proof"]["A_i"][0], got["proof"]["B_i"][0]], [aff(op["A0"]), aff(op["B0"])])
+            rep.check("proof z'", got["proof"]["z_prime"], [hx(v) for v in op["z_prime"]])
+            rep.check("challenges c0, c1, c (oracle, switched format)", [h["c"] for h in got["hashes"]],
+                      [hx(tr["c0"]), hx(tr["c1"])] + [hx(c) for c in tr["c"]])
+        else:
+            for key in sorted(want):
+                if key == "hashes":
+                    continue
+                rep.check(f"fixture[{key!r}]", got.get(key), want[key])
+            rep.check("number of Fiat-Shamir hashes", len(got["hashes"]), len(want["hashes"]))
+            for i, (hg, hw) in enumerate(zip(got["hashes"], want["hashes"])):
+                if rep.check(f"pre-image {i}: text ({hw['len']} bytes)", hg.get("text"), hw.get("text")):
+                    rep.check(f"pre-image {i}: challenge", hg["c"], hw["c"])
+                else:
+                    print("        (later challenges differ as a consequence)")
+                    break
     print()
     if rep.failed:
         print(f"{rep.failed} difference(s): the [mpyc-recall] format layer (oracle/ed25519_ref.py switches, "
               "verifiable_mpc_amd/groups.py, fields.py, csrc/fmt.h) needs the adjustments shown above.")
+        return 1
+    if rep.format_note:
+        print(f"all equal ONCE the format is switched: verifiable_mpc_amd.set_reference_format({rep.format_note}) "
+              "- parity with real MPyC holds under that setting; change the defaults as noted under 0.")
         return 1
     print("all equal over the build's own stand-in (self-test of this script; nothing pinned)." if self_test else
           "all equal: parity with real MPyC's byte formats is pinned on this machine.")

@@ -32,6 +32,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$TAG" -- \
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_calib_$TAG" -- \
     python3 "$REPO/scripts/traffic_calibration.py" "$OUT/pmc_calib_$TAG/manifest.json" > "$OUT/pmc_calib_$TAG.log" 2> "$OUT/pmc_calib_$TAG.err"
 (cd "$REPO" && git rev-parse --short HEAD 2>/dev/null || cat "$REPO/.revision" 2>/dev/null) > "$OUT/revision_$TAG.txt"
+# the sources of the kernel the traffic figure is about, as they were for THIS pass (bench.py compares them with the
+# tree it runs from and says so when they differ: the GPU box has no .git)
+(cd "$REPO" && sha256sum verifiable_mpc_amd/csrc/msm.hip verifiable_mpc_amd/csrc/msm_sort.hip verifiable_mpc_amd/csrc/ge25519.h verifiable_mpc_amd/csrc/fe25519.h) > "$OUT/sources_$TAG.txt"
 # (--batch 1 in the PMC passes: every k_msm_bucket launch is then ONE commitment, the unit the roofline figure uses)
 # keep what travels back small: stats + counter csv only
 find "$OUT" -name '*kernel_trace.csv' -delete

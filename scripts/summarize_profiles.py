@@ -111,7 +111,13 @@ def main():
             "structural_bytes": windows * n * (128 + 4) + windows * (1 << 15) * 160,
             "structural_note": "16 windows x 2^20 terms x (128-B table line + 4-B sorted index) read, "
                                "16 x 2^15 buckets x 160 B written"}
-    summary = {"revision": rev, "calibration": calib, "calibrated": calibrated, "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 4 --warmup 2 "
+    sources = {}
+    if os.path.exists(os.path.join(out, f"sources_{tag}.txt")):
+        with open(os.path.join(out, f"sources_{tag}.txt")) as f:
+            for ln in f:
+                h, name = ln.split()
+                sources[name] = h
+    summary = {"revision": rev, "kernel_sources_sha256": sources, "calibration": calib, "calibrated": calibrated, "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 4 --warmup 2 "
                           "--batch 1 --no-cpu-baseline --no-prove (one pass per counter, one commitment per launch; "
                           "scripts/profile_round.sh)",
                "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE tallies 128-B "

@@ -2,6 +2,18 @@
 import functools
 
 
+def _alt_format():
+    """(brackets, coordinates signed, scalars signed).  VMPC_SHIM_FORMAT="()|1|0" makes this stand-in print the OTHER
+    way - only tests/test_mpyc_conformance_script.py sets it, to see scripts/check_against_mpyc.py detect and name the
+    difference; unset, the stand-in prints the recalled formats and the fixtures regenerate byte for byte."""
+    import os
+    v = os.environ.get("VMPC_SHIM_FORMAT")
+    if not v:
+        return "[]", False, True
+    b, c, s_ = v.split("|")
+    return b, c == "1", s_ == "1"
+
+
 class FiniteFieldElement:
     __slots__ = ("value",)
     modulus = None
@@ -105,7 +117,7 @@ def _pfield(modulus):
     cls.modulus = modulus
     cls.order = modulus
     cls.characteristic = modulus
-    cls.is_signed = True      # [mpyc-recall] GF() default
+    cls.is_signed = _alt_format()[2]      # [mpyc-recall] GF() default: signed
     return cls
 
 

@@ -53,7 +53,11 @@ class FiniteGroupElement:
         return hash(repr(self))
 
     def __repr__(self):
-        return repr(self.value)
+        from mpyc.finfields import _alt_format
+        b = _alt_format()[0]
+        if b == "[]":
+            return repr(self.value)
+        return b[0] + ", ".join(repr(v) for v in self.value) + b[1]
 
 
 class EllipticCurvePoint(FiniteGroupElement):
@@ -72,7 +76,8 @@ def _make_ed25519():
     both with a textbook affine law and with OpenSSL-made vectors)."""
     p = 2**255 - 19
     field = GF(p)
-    field.is_signed = False   # [mpyc-recall] fingroups sets is_signed = False on its fields
+    from mpyc.finfields import _alt_format
+    field.is_signed = _alt_format()[1]   # [mpyc-recall] fingroups sets is_signed = False on its fields
     a = field(-1)
     d = field(-121665) / field(121666)
     gy = field(4) / field(5)

@@ -207,7 +207,8 @@ int main() {
             int n = u256_write_decimal(w, buf);
             buf[n] = 0;
             std::cout << buf << " " << u256_decimal_len(w) << "\n";
-        } else if (cmd == "padd" || cmd == "pdbl" || cmd == "prepeat" || cmd == "prepr") {
+        } else if (cmd == "padd" || cmd == "pdbl" || cmd == "prepeat" || cmd == "prepr" || cmd == "preprs" ||
+                   cmd == "preprp") {
             ge_proj p;
             p.X = rd_fe(is);
             p.Y = rd_fe(is);
@@ -228,9 +229,12 @@ int main() {
             } else {
                 fe8 cx = fe_pack(p.X), cy = fe_pack(p.Y), cz = fe_pack(p.Z);
                 char buf[300];
-                int n = proj_repr_write(cx.w, cy.w, cz.w, buf);
+                // prepr: "[X, Y, Z]" unsigned; preprs: signed coordinates; preprp: "(X, Y, Z)" signed
+                const fmt_point_style style = {cmd == "preprp" ? '(' : '[', cmd == "preprp" ? ')' : ']',
+                                               cmd == "prepr" ? 0 : 1};
+                int n = proj_repr_write(cx.w, cy.w, cz.w, style, buf);
                 buf[n] = 0;
-                std::cout << buf << "|" << proj_repr_len(cx.w, cy.w, cz.w) << "\n";
+                std::cout << buf << "|" << proj_repr_len(cx.w, cy.w, cz.w, style) << "\n";
                 continue;
             }
             std::cout << fehex(r.X) << " " << fehex(r.Y) << " " << fehex(r.Z) << "\n";

@@ -467,6 +467,7 @@ def test_bucket_free_short_rounds(vm, monkeypatch, log_n, direct_log2, jump_k, m
     ctx = vm.get_context()
     for setting in ((str(direct_log2), str(jump_k), str(min_log2)), ("0", "0", "30")):
         monkeypatch.setenv("VMPC_P4_DIRECT_LOG2", setting[0])
+        monkeypatch.setenv("VMPC_EXPERIMENTAL", "1")            # measured losers are only read behind this switch
         monkeypatch.setenv("VMPC_P4_FOLD_TO_DIRECT", "1")       # the fold-down-to-the-short-form rule (off by default)
         monkeypatch.setenv("VMPC_P4_JUMP", setting[1])
         monkeypatch.setenv("VMPC_P4_JUMP_MIN_LOG2", setting[2])

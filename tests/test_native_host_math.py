@@ -145,6 +145,15 @@ def test_projective_replay(harness):
     pts = [ed.IDENTITY, ed.BASE] + [rand_point(rng) for _ in range(6)]
     pts += [ed.pt_add(pts[2], pts[3]), ed.pt_dbl(pts[4])]          # Z != 1
     f3 = lambda t: " ".join(hx(c) for c in t)
+    half = (ed.P - 1) // 2                  # the sign boundary of a coordinate: (p - 1) / 2 prints positive
+    for fake in ((half, half + 1, ed.P - 1), (half - 1, 0, 1), (2**254 - 1, 2**254, 2**254 - 9)):
+        for cmd, fmt in (("prepr", ("[]", False)), ("preprs", ("[]", True)), ("preprp", ("()", True))):
+            ed.set_format(*fmt)
+            try:
+                lines.append(f"{cmd} {f3(fake)}")
+                want.append(ed.pt_repr(fake) + "|" + str(len(ed.pt_repr(fake))))
+            finally:
+                ed.set_format()
     for p in pts:
         for q in pts[:5]:
             lines.append(f"padd {f3(p)} {f3(q)}")
@@ -153,6 +162,14 @@ def test_projective_replay(harness):
         want.append(f3(ed.pt_dbl(p)))
         lines.append(f"prepr {f3(p)}")
         want.append(ed.pt_repr(p) + "|" + str(len(ed.pt_repr(p))))
+        # the other recalled formats of a point: signed coordinates, round brackets (runtime switches of fmt.h)
+        for cmd, fmt in (("preprs", ("[]", True)), ("preprp", ("()", True))):
+            ed.set_format(*fmt)
+            try:
+                lines.append(f"{cmd} {f3(p)}")
+                want.append(ed.pt_repr(p) + "|" + str(len(ed.pt_repr(p))))
+            finally:
+                ed.set_format()
         for n in [0, 1, 2, 3, 2**32 - 1, 2**32, 2**33 + 1, ELL - 1, ELL, 2**253 - 1,
                   rng.randrange(ELL), rng.randrange(ELL) ** 2 % 2**256, rng.getrandbits(64)]:
             lines.append(f"prepeat {f3(p)} {hx(n)}")

@@ -9,6 +9,7 @@ from . import circuit_sat, compressed_pivot, pivot  # noqa: F401
 from .circuit_sat import PivotChoice, create_generators  # noqa: F401
 from .device import PointVector, ScalarVector, get_context  # noqa: F401
 from .fields import GF  # noqa: F401
+from .formats import get_reference_format, reset_reference_format, set_reference_format  # noqa: F401
 from .groups import Ed25519Point, EllipticCurve, EllipticCurvePoint  # noqa: F401
 
 __version__ = "0.1.0"

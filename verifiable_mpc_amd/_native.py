@@ -40,6 +40,7 @@ SYMBOLS = [
     "vmpc_comm_unique_id", "vmpc_comm_create_rccl", "vmpc_comm_create_callback", "vmpc_comm_destroy", "vmpc_comm_info",
     "vmpc_comm_allgather_dev", "vmpc_comm_points_allsum_dev", "vmpc_p4_create_sharded", "vmpc_gather_probe_dev", "vmpc_bn256_madd_rate",
     "vmpc_stream_create", "vmpc_stream_destroy", "vmpc_ctx_set_bucket_stream",
+    "vmpc_set_reference_format", "vmpc_get_reference_format",
 ]
 
 
@@ -83,6 +84,8 @@ def load_library():
         "vmpc_ctx_profile": (i32, [vp, i32]),
         "vmpc_ctx_profile_read": (i32, [vp, cp, sz, ctypes.POINTER(ctypes.c_double), u64p, i32, i32]),
         "vmpc_ctx_set_window": (i32, [vp, i32]),
+        "vmpc_set_reference_format": (i32, [ctypes.c_char, ctypes.c_char, i32]),
+        "vmpc_get_reference_format": (i32, [cp, cp, ctypes.POINTER(i32)]),
         "vmpc_stream_create": (i32, [i32, i32, ctypes.POINTER(vp)]),
         "vmpc_stream_destroy": (i32, [vp]),
         "vmpc_ctx_set_bucket_stream": (i32, [vp, vp, i32]),
@@ -153,7 +156,16 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError if the export is missing
         fn.restype, fn.argtypes = sig[name]
     _lib = lib
+    # a reference format chosen before the library was first needed (formats.set_reference_format) takes effect now
+    from . import formats
+    f = formats.get_reference_format()
+    if f != formats._DEFAULT:
+        set_reference_format(f["point_brackets"][0], f["point_brackets"][1], f["coord_signed"])
     return lib
+
+
+def library_loaded():
+    return _lib is not None
 
 
 def _check(rc, where):
@@ -311,7 +323,7 @@ class Context:
     def format_begin(self, kind, src_ptr, n, is_signed=True, keepalive=None):
         """enqueue formatting + D2H of a vector's transcript text; returns a PendingText.
         `keepalive`: the owner of `src_ptr` when it lives in another context's block cache"""
-        per = (3 * 78 + 8) if kind == "points" else (78 + 3)
+        per = (3 * 79 + 8) if kind == "points" else (78 + 3)       # 78 digits + a sign per coordinate
         cap = n * per + 16
         pinned = self._take_pinned(cap + 16)
         dev = DeviceBuffer(self, cap)
@@ -698,7 +710,7 @@ class Context:
     def format_points(self, proj_ptr, n):
         """uint8 array 'item0, item1, ..., ' for n projective points."""
         return self._format(self.lib.vmpc_format_points_dev, "vmpc_format_points_dev", proj_ptr, n,
-                            3 * 78 + 8)
+                            3 * 79 + 8)
 
     def format_scalars(self, sc_ptr, n, is_signed=True):
         return self._format(self.lib.vmpc_format_scalars_dev, "vmpc_format_scalars_dev", sc_ptr, n,
@@ -714,6 +726,18 @@ class PendingDigests:
         self.out.free()
         self.keepalive = None
         return res
+
+
+def set_reference_format(point_open, point_close, coord_signed):
+    """how csrc/format.hip prints a curve point (process-wide; formats.set_reference_format is the caller)"""
+    _check(load_library().vmpc_set_reference_format(point_open.encode(), point_close.encode(), 1 if coord_signed else 0),
+           "vmpc_set_reference_format")
+
+
+def get_reference_format():
+    o, c, s = ctypes.create_string_buffer(1), ctypes.create_string_buffer(1), ctypes.c_int()
+    _check(load_library().vmpc_get_reference_format(o, c, ctypes.byref(s)), "vmpc_get_reference_format")
+    return o.raw.decode(), c.raw.decode(), bool(s.value)
 
 
 class SharedStream:

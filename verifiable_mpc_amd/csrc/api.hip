@@ -11,6 +11,11 @@ int vmpc_fr_check_dev(vmpc_ctx *ctx, const void *v, size_t n);  // frvec.hip
 
 extern "C" const char *vmpc_last_error(void) { return vmpc_err_buf; }
 
+const char *vmpc_getenv_experimental(const char *name) {
+    const char *on = getenv("VMPC_EXPERIMENTAL");
+    return (on && atoi(on) != 0) ? getenv(name) : nullptr;
+}
+
 extern "C" int vmpc_backend_info(char *buf, size_t buflen) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -60,15 +65,16 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
     }
     const char *w = getenv("VMPC_MSM_WINDOW");
     if (w) c->window_override = atoi(w);
-    const char *bw = getenv("VMPC_BUCKET_WGS_PER_CU");
+    // measured and left at their defaults (only with VMPC_EXPERIMENTAL=1):
+    const char *bw = vmpc_getenv_experimental("VMPC_BUCKET_WGS_PER_CU");
     if (bw && atoi(bw) >= 0) c->bucket_wgs_per_cu = atoi(bw);
-    const char *sf = getenv("VMPC_SORT_FINE_BITS");   // tuning knob: fine bits of the two-level bucket sort
+    const char *sf = vmpc_getenv_experimental("VMPC_SORT_FINE_BITS");   // fine bits of the two-level bucket sort
     if (sf && atoi(sf) >= 0) c->sort_fine_bits = atoi(sf);
-    const char *rc = getenv("VMPC_REDUCE_MAX_CHUNKS");
+    const char *rc = vmpc_getenv_experimental("VMPC_REDUCE_MAX_CHUNKS");
     if (rc && atoi(rc) >= 256 && atoi(rc) <= 32768) c->reduce_max_chunks = atoi(rc);
-    const char *ro = getenv("VMPC_REDUCE_CHUNKS");
+    const char *ro = vmpc_getenv_experimental("VMPC_REDUCE_CHUNKS");
     if (ro && atoi(ro) >= 64 && atoi(ro) <= 32768 && (atoi(ro) & (atoi(ro) - 1)) == 0) c->reduce_chunks_override = atoi(ro);
-    const char *ss = getenv("VMPC_SEG_SHIFT_MIN");
+    const char *ss = vmpc_getenv_experimental("VMPC_SEG_SHIFT_MIN");
     if (ss && atoi(ss) <= 0 && atoi(ss) >= -5) c->seg_shift_min = atoi(ss);
     *out = c;
     return VMPC_OK;

@@ -43,17 +43,17 @@ gk_bucket(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ sor
     if (t >= *n_tasks) return;
     uint2 tk = tasks[t];
     uint32_t ci = tk.x, sidx = tk.y;
-    uint32_t cnt = counts[ci];
-    uint32_t lo = starts[ci] + sidx * seg;
-    uint32_t len = cnt - sidx * seg;
-    if (len > (uint32_t)seg) len = seg;
+    const uint32_t ns = nseg[ci];
+    uint32_t lo, len;
+    msm_seg_range(counts[ci], ns, sidx, lo, len);      // equal segments (msm_sort.h)
+    lo += starts[ci];
     typename C::acc_t acc = C::identity();
     for (uint32_t j = 0; j < len; j++) {
         uint32_t e = sorted[lo + j];
         typename C::entry_t q = C::entry_ld(entries + (size_t)C::ENTRY_WORDS * (e & 0x7fffffffu));
         acc = C::madd(acc, q, (e >> 31) != 0);
     }
-    if (nseg[ci] == 1)
+    if (ns == 1)
         C::acc_st(buckets + (size_t)C::ACC_WORDS * msm_bucket_slot(ci, nb1), acc);
     else
         C::acc_st(partial + (size_t)C::ACC_WORDS * (seg_starts[ci] + sidx), acc);

@@ -113,5 +113,9 @@ struct vmpc_stage_scope {
     ~vmpc_stage_scope() { vmpc_stage_end(ctx, h); }
 };
 
+// Tuning knobs whose A/B has been lost (DESIGN.md section 10 keeps the numbers) are read only when
+// VMPC_EXPERIMENTAL=1 is set as well: a stray variable in a caller's environment cannot switch a slower path on.
+const char *vmpc_getenv_experimental(const char *name);
+
 #define VMPC_IGNORE(expr) ((void)(expr))
 #define VMPC_KERNEL_CHECK() VMPC_HIP_CHECK(hipGetLastError())

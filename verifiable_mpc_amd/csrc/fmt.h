@@ -8,6 +8,9 @@
 //   point  -> "[X, Y, Z]"   (un-normalised projective coordinates, unsigned decimals)
 //   scalar -> signed decimal of the residue in (-l/2, l/2]
 // [mpyc-recall: formats as restated in oracle/ed25519_ref.py pt_repr / scalar_repr]
+// The recalled choices - bracket pair, signed or unsigned coordinates, signed or unsigned scalars - are RUNTIME
+// settings (vmpc_repr_format, include/vmpc.h vmpc_set_reference_format): a mismatch with real MPyC found by
+// scripts/check_against_mpyc.py is one call, not a kernel edit.
 #pragma once
 #include "fe25519.h"
 #include "fr.h"
@@ -66,23 +69,69 @@ VMPC_HD int u256_write_decimal(const uint32_t v[8], char *dst) {
     return len;
 }
 
-// "[X, Y, Z]" for canonical coordinates
-VMPC_HD int proj_repr_len(const uint32_t X[8], const uint32_t Y[8], const uint32_t Z[8]) {
-    return 6 + u256_decimal_len(X) + u256_decimal_len(Y) + u256_decimal_len(Z);
+// how a point is printed: bracket pair and whether a coordinate c > (p - 1) / 2 appears as -(p - c)
+struct fmt_point_style {
+    char open, close;
+    int coord_signed;
+};
+
+// canonical coordinate c of GF(2^255 - 19): is it printed negative, and its magnitude
+VMPC_HD bool fe8_signed_abs(const uint32_t c[8], uint32_t mag[8]) {
+    // (p - 1) / 2 = 2^254 - 10: c > that  <=>  c >= 2^254 - 9
+    bool big = (c[7] >> 30) != 0;                       // c >= 2^254 (c < p < 2^255)
+    if (!big && c[7] == 0x3fffffffu) {
+        bool all = true;
+        for (int i = 1; i < 7; i++) all = all && c[i] == 0xffffffffu;
+        big = all && c[0] >= 0xfffffff7u;               // 2^254 - 9 .. 2^254 - 1
+    }
+    if (!big) {
+        for (int i = 0; i < 8; i++) mag[i] = c[i];
+        return false;
+    }
+    const uint32_t pw[8] = {0xffffffedu, 0xffffffffu, 0xffffffffu, 0xffffffffu,
+                            0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu};
+    uint64_t borrow = 0;
+    for (int i = 0; i < 8; i++) {
+        const uint64_t d = (uint64_t)pw[i] - c[i] - borrow;
+        mag[i] = (uint32_t)d;
+        borrow = (d >> 63) & 1;
+    }
+    return true;
 }
 
-VMPC_HD int proj_repr_write(const uint32_t X[8], const uint32_t Y[8], const uint32_t Z[8],
+VMPC_HD int coord_repr_len(const uint32_t c[8], int coord_signed) {
+    if (!coord_signed) return u256_decimal_len(c);
+    uint32_t mag[8];
+    const bool neg = fe8_signed_abs(c, mag);
+    return (neg ? 1 : 0) + u256_decimal_len(mag);
+}
+
+VMPC_HD int coord_repr_write(const uint32_t c[8], int coord_signed, char *dst) {
+    if (!coord_signed) return u256_write_decimal(c, dst);
+    uint32_t mag[8];
+    const bool neg = fe8_signed_abs(c, mag);
+    int o = 0;
+    if (neg) dst[o++] = '-';
+    return o + u256_write_decimal(mag, dst + o);
+}
+
+// "[X, Y, Z]" for canonical coordinates (brackets and coordinate signedness from the style)
+VMPC_HD int proj_repr_len(const uint32_t X[8], const uint32_t Y[8], const uint32_t Z[8], const fmt_point_style &st) {
+    return 6 + coord_repr_len(X, st.coord_signed) + coord_repr_len(Y, st.coord_signed) + coord_repr_len(Z, st.coord_signed);
+}
+
+VMPC_HD int proj_repr_write(const uint32_t X[8], const uint32_t Y[8], const uint32_t Z[8], const fmt_point_style &st,
                             char *dst) {
     int o = 0;
-    dst[o++] = '[';
-    o += u256_write_decimal(X, dst + o);
+    dst[o++] = st.open;
+    o += coord_repr_write(X, st.coord_signed, dst + o);
     dst[o++] = ',';
     dst[o++] = ' ';
-    o += u256_write_decimal(Y, dst + o);
+    o += coord_repr_write(Y, st.coord_signed, dst + o);
     dst[o++] = ',';
     dst[o++] = ' ';
-    o += u256_write_decimal(Z, dst + o);
-    dst[o++] = ']';
+    o += coord_repr_write(Z, st.coord_signed, dst + o);
+    dst[o++] = st.close;
     return o;
 }
 

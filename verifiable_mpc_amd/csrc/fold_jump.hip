@@ -34,6 +34,11 @@ int vmpc_normalize_launch(vmpc_ctx *ctx, const void *proj, size_t n, void *out_a
 // Registers: the running sum and one table entry live in VGPRs (as in k_msm_bucket: 4 waves per SIMD); the
 // outer accumulator is touched only at the <= 8 steps down in |digit|, so it lives in its output slot in memory.
 // (A first version with both accumulators in registers and a prefetched entry needed 255 VGPRs + 68 spilled.)
+// S > 1 (short vectors): the schedule of an (output, offset) is dealt out to S lanes - workgroup blockIdx.y takes the
+// entries e = blockIdx.y mod S of the sorted list - and every lane reduces its share with the same running-sum form;
+// the bucket reduction is linear in the set of entries, so the S results simply add up (k_fold_jump_table /
+// _combine sum the S slots of an offset).  With 2^11 outputs the pass is 8192 lanes walking 256 table entries each;
+// eight lanes walking 32 took the second fold of a proof from 1.2 to 0.5 ms.
 __global__ void __launch_bounds__(FJ_BLOCK, 4)
 k_fold_jump(const uint32_t *__restrict__ table, size_t stride, size_t m_out, int O, int e1,
             const uint32_t *__restrict__ sched, unsigned n_blocks, uint32_t *__restrict__ partial) {
@@ -44,10 +49,11 @@ k_fold_jump(const uint32_t *__restrict__ table, size_t stride, size_t m_out, int
     const int o = __builtin_amdgcn_readfirstlane((int)((l % og) * FJ_WAVES + (threadIdx.x >> 6)));
     const size_t j = (size_t)(l / og) * 64 + (threadIdx.x & 63);
     if (j >= m_out) return;                                               // whole waves only when m_out < 64
+    const uint32_t S = gridDim.y, share = blockIdx.y;
     const uint32_t *sc = sched + (size_t)o * e1;
     const uint32_t cnt = sc[0];
     const uint32_t *col = table + NIELS_WORDS * j;
-    uint32_t *slot = partial + EXT_WORDS * (j * (size_t)O + o);
+    uint32_t *slot = partial + EXT_WORDS * ((j * (size_t)O + o) * S + share);
     ge_ext run = ge_ext_identity();
     ext_st(slot, run);
     bool have = false;
@@ -61,6 +67,7 @@ k_fold_jump(const uint32_t *__restrict__ table, size_t stride, size_t m_out, int
             cur = v;
         }
         if (e == cnt) break;
+        if (S > 1 && e % S != share) continue;                            // (wave-uniform)
         const ge_niels q = niels_ld_line(col + NIELS_WORDS * (((ent >> 8) & 0x1f) * stride + (size_t)(ent & 0xff) * m_out));
         run = ge_madd(run, ge_niels_select_neg(q, ((ent >> 15) & 1) != 0));
         have = true;
@@ -68,14 +75,15 @@ k_fold_jump(const uint32_t *__restrict__ table, size_t stride, size_t m_out, int
 }
 
 __global__ void __launch_bounds__(FJ_BLOCK)
-k_fold_jump_combine(const uint32_t *__restrict__ partial, size_t m_out, int O, uint32_t *__restrict__ out_proj) {
+k_fold_jump_combine(const uint32_t *__restrict__ partial, size_t m_out, int O, int S, uint32_t *__restrict__ out_proj) {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m_out) return;
-    const uint32_t *src = partial + EXT_WORDS * j * (size_t)O;
-    ge_ext acc = ext_ld(src + EXT_WORDS * (size_t)(O - 1));
-    for (int o = O - 2; o >= 0; o--) {
-        for (int d = 0; d < 4; d++) acc = ge_dbl(acc);
-        acc = ge_add(acc, ext_ld(src + EXT_WORDS * (size_t)o));
+    const uint32_t *src = partial + EXT_WORDS * j * (size_t)O * S;
+    ge_ext acc = ge_ext_identity();
+    for (int o = O - 1; o >= 0; o--) {
+        if (o != O - 1)
+            for (int d = 0; d < 4; d++) acc = ge_dbl(acc);
+        for (int sh = 0; sh < S; sh++) acc = ge_add(acc, ext_ld(src + EXT_WORDS * ((size_t)o * S + sh)));
     }
     fe_st8(out_proj + 24 * j, acc.X);
     fe_st8(out_proj + 24 * j + 8, acc.Y);
@@ -90,16 +98,19 @@ k_fold_jump_combine(const uint32_t *__restrict__ partial, size_t m_out, int O, u
 // One inversion per output covers all its rows, row 0 included (Montgomery's trick, as in k_msm_table_build):
 // pass 1 parks (X, Y, Z, Z_0 ... Z_r) in the row's own 128-byte slot, pass 2 (lane 0 of the quad) walks back.
 __global__ void __launch_bounds__(FJ_BLOCK)
-k_fold_jump_table(const uint32_t *__restrict__ partial, size_t m_out, int O, size_t stride, int rows,
+k_fold_jump_table(const uint32_t *__restrict__ partial, size_t m_out, int O, int S, size_t stride, int rows,
                   uint32_t *__restrict__ table) {
     const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const int q = threadIdx.x & 3;
     if (j >= m_out) return;                                   // whole quads
-    const uint32_t *src = partial + EXT_WORDS * j * (size_t)O;
-    fe P = fe_ld(src + EXT_WORDS * (size_t)(O - 1) + FE_LIMBS * q);
+    const uint32_t *src = partial + EXT_WORDS * j * (size_t)O * S;
+    fe P = fe_ld(src + EXT_WORDS * ((size_t)(O - 1) * S) + FE_LIMBS * q);
+    for (int sh = 1; sh < S; sh++)
+        P = quadD_add_cached(P, quadD_to_cached(fe_ld(src + EXT_WORDS * ((size_t)(O - 1) * S + sh) + FE_LIMBS * q), q), q);
     for (int o = O - 2; o >= 0; o--) {
         for (int d = 0; d < 4; d++) P = quadD_dbl(P, q);
-        P = quadD_add_cached(P, quadD_to_cached(fe_ld(src + EXT_WORDS * (size_t)o + FE_LIMBS * q), q), q);
+        for (int sh = 0; sh < S; sh++)
+            P = quadD_add_cached(P, quadD_to_cached(fe_ld(src + EXT_WORDS * ((size_t)o * S + sh) + FE_LIMBS * q), q), q);
     }
     const int dbl_per_row = 256 / rows;
     fe run = quad_perm<0xaa>(P);                              // Z_0 on every lane
@@ -184,7 +195,10 @@ static int table_fold(vmpc_ctx *ctx, const void *table, size_t table_n, size_t t
         }
     }
     const size_t sched_bytes = (sched.size() * 4 + 255) & ~(size_t)255;
-    const size_t partial_bytes = m_out * (size_t)O * EXT_WORDS * 4;
+    // short vectors: S lanes share an (output, offset) schedule so that up to 2^17 lanes are at work
+    int S = 1;
+    while (S < 16 && m_out * (size_t)O * S * 2 <= ((size_t)1 << 17) && rows * B / (S * 2) >= 8) S *= 2;
+    const size_t partial_bytes = m_out * (size_t)O * S * EXT_WORDS * 4;
     const size_t proj_bytes = (m_out * 96 + 255) & ~(size_t)255;
     VMPC_CHECK(vmpc_ws_reserve(ctx, sched_bytes + partial_bytes + proj_bytes));
     char *ws = (char *)ctx->ws;
@@ -194,18 +208,18 @@ static int table_fold(vmpc_ctx *ctx, const void *table, size_t table_n, size_t t
     VMPC_CHECK(vmpc_stage_h2d(ctx, d_sched, sched.data(), sched.size() * 4));
     const unsigned n_blocks = (unsigned)(((m_out + 63) / 64) * (size_t)(O / FJ_WAVES));
     const unsigned grid = ((n_blocks + 7) / 8) * 8;
-    k_fold_jump<<<grid, FJ_BLOCK, 0, ctx->stream>>>((const uint32_t *)table, stride, m_out, O, e1, d_sched, n_blocks,
-                                                    d_partial);
+    k_fold_jump<<<dim3(grid, (unsigned)S), FJ_BLOCK, 0, ctx->stream>>>((const uint32_t *)table, stride, m_out, O, e1, d_sched,
+                                                                       n_blocks, d_partial);
     VMPC_KERNEL_CHECK();
     if (out_affine) {
         k_fold_jump_combine<<<(unsigned)((m_out + FJ_BLOCK - 1) / FJ_BLOCK), FJ_BLOCK, 0, ctx->stream>>>(d_partial, m_out,
-                                                                                                     O, d_proj);
+                                                                                                     O, S, d_proj);
         VMPC_KERNEL_CHECK();
         return vmpc_normalize_launch(ctx, d_proj, m_out, out_affine);
     }
     const size_t out_stride = (m_out + out_n_extra + 7) & ~(size_t)7;
     k_fold_jump_table<<<(unsigned)((4 * m_out + FJ_BLOCK - 1) / FJ_BLOCK), FJ_BLOCK, 0, ctx->stream>>>(
-        d_partial, m_out, O, out_stride, out_rows, (uint32_t *)out_table);
+        d_partial, m_out, O, S, out_stride, out_rows, (uint32_t *)out_table);
     VMPC_KERNEL_CHECK();
     if (extras_block) {     // the extras' columns as an (out_stride - m_out)-column table of their own: copy, row by row
         const size_t cols = out_stride - m_out;

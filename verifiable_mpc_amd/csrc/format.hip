@@ -12,6 +12,26 @@
 
 #define FMT_BLOCK 256
 
+// The [mpyc-recall] format choices of the PRODUCT, process-wide (vmpc_set_reference_format): how the reference's
+// str(input_list) prints a curve point.  Scalar signedness travels with every call (is_signed).
+static fmt_point_style g_point_style = {'[', ']', 0};
+
+extern "C" int vmpc_set_reference_format(char point_open, char point_close, int coord_signed) {
+    const bool ok = (point_open == '[' && point_close == ']') || (point_open == '(' && point_close == ')');
+    if (!ok || (coord_signed != 0 && coord_signed != 1)) return VMPC_E_INVAL;
+    g_point_style.open = point_open;
+    g_point_style.close = point_close;
+    g_point_style.coord_signed = coord_signed;
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_get_reference_format(char *point_open, char *point_close, int *coord_signed) {
+    if (point_open) *point_open = g_point_style.open;
+    if (point_close) *point_close = g_point_style.close;
+    if (coord_signed) *coord_signed = g_point_style.coord_signed;
+    return VMPC_OK;
+}
+
 __device__ __forceinline__ void fmt_ld8(uint32_t d[8], const uint32_t *src) {
     const uint4 *p = reinterpret_cast<const uint4 *>(src);
     uint4 a = p[0], b = p[1];
@@ -20,19 +40,19 @@ __device__ __forceinline__ void fmt_ld8(uint32_t d[8], const uint32_t *src) {
 }
 
 __global__ void __launch_bounds__(FMT_BLOCK)
-k_fmt_points_len(const uint32_t *__restrict__ proj, size_t n, uint32_t *__restrict__ lens) {
+k_fmt_points_len(const uint32_t *__restrict__ proj, size_t n, fmt_point_style style, uint32_t *__restrict__ lens) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t X[8], Y[8], Z[8];
     fmt_ld8(X, proj + 24 * i);
     fmt_ld8(Y, proj + 24 * i + 8);
     fmt_ld8(Z, proj + 24 * i + 16);
-    lens[i] = (uint32_t)proj_repr_len(X, Y, Z) + 2;
+    lens[i] = (uint32_t)proj_repr_len(X, Y, Z, style) + 2;
 }
 
 __global__ void __launch_bounds__(FMT_BLOCK)
-k_fmt_points_write(const uint32_t *__restrict__ proj, size_t n, const uint64_t *__restrict__ offs,
-                   char *__restrict__ out) {
+k_fmt_points_write(const uint32_t *__restrict__ proj, size_t n, fmt_point_style style,
+                   const uint64_t *__restrict__ offs, char *__restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t X[8], Y[8], Z[8];
@@ -40,7 +60,7 @@ k_fmt_points_write(const uint32_t *__restrict__ proj, size_t n, const uint64_t *
     fmt_ld8(Y, proj + 24 * i + 8);
     fmt_ld8(Z, proj + 24 * i + 16);
     char *dst = out + offs[i];
-    int o = proj_repr_write(X, Y, Z, dst);
+    int o = proj_repr_write(X, Y, Z, style, dst);
     dst[o] = ',';
     dst[o + 1] = ' ';
 }
@@ -85,7 +105,7 @@ static int fmt_common(vmpc_ctx *ctx, const void *src, size_t n, bool points, int
     {
         vmpc_stage_scope s(ctx, "format_len");
         if (points)
-            k_fmt_points_len<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, lens);
+            k_fmt_points_len<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, g_point_style, lens);
         else
             k_fmt_scalars_len<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, is_signed, lens);
         VMPC_KERNEL_CHECK();
@@ -99,7 +119,7 @@ static int fmt_common(vmpc_ctx *ctx, const void *src, size_t n, bool points, int
     {
         vmpc_stage_scope s(ctx, "format_write");
         if (points)
-            k_fmt_points_write<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, offs, (char *)out_text);
+            k_fmt_points_write<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, g_point_style, offs, (char *)out_text);
         else
             k_fmt_scalars_write<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, is_signed, offs,
                                                         (char *)out_text);
@@ -117,7 +137,7 @@ static int fmt_common(vmpc_ctx *ctx, const void *src, size_t n, bool points, int
 static int fmt_async(vmpc_ctx *ctx, const void *src, size_t n, bool points, int is_signed, void *dev_text,
                      size_t cap, void *host_text, uint64_t *host_len) {
     if (!ctx || !host_len || (n && (!src || !dev_text || !host_text))) return VMPC_E_INVAL;
-    size_t worst = n * (points ? (3 * 78 + 8) : (78 + 3));
+    size_t worst = n * (points ? (3 * 79 + 8) : (78 + 3));       // 78 digits + a sign per coordinate
     if (cap < worst) return VMPC_E_NOMEM;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -134,13 +154,13 @@ static int fmt_async(vmpc_ctx *ctx, const void *src, size_t n, bool points, int 
     unsigned g = (unsigned)((n + FMT_BLOCK - 1) / FMT_BLOCK);
     vmpc_stage_scope s(ctx, "format_async");
     if (points)
-        k_fmt_points_len<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, lens);
+        k_fmt_points_len<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, g_point_style, lens);
     else
         k_fmt_scalars_len<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, is_signed, lens);
     VMPC_KERNEL_CHECK();
     VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint64_t>(st, lens, offs, n, scan_ws, total)));
     if (points)
-        k_fmt_points_write<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, offs, (char *)dev_text);
+        k_fmt_points_write<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, g_point_style, offs, (char *)dev_text);
     else
         k_fmt_scalars_write<<<g, FMT_BLOCK, 0, st>>>((const uint32_t *)src, n, is_signed, offs,
                                                     (char *)dev_text);

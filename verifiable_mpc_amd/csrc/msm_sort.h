@@ -87,6 +87,24 @@ static inline int msm_ilog2(int v) {
     return r;
 }
 
+// A bucket of cnt entries is cut into ns = ceil(cnt / seg) segments of EQUAL length (+-1): the first cnt % ns of them
+// hold one entry more.  (Rounds 1-3 cut full segments of `seg` entries plus a remainder: with ~2 x seg entries per
+// bucket - the A_i / B_i pair of a prover round - the remainders formed a second, short wave of tasks that ran on a
+// quarter of the chip.)  Segment sidx of the bucket: its first entry and its length.
+__host__ __device__ __forceinline__ uint32_t msm_seg_count(uint32_t cnt, uint32_t seg_log) {
+    return (cnt + (1u << seg_log) - 1u) >> seg_log;
+}
+__device__ __forceinline__ void msm_seg_range(uint32_t cnt, uint32_t ns, uint32_t sidx, uint32_t &off, uint32_t &len) {
+    if (ns <= 1) {
+        off = 0;
+        len = cnt;
+        return;
+    }
+    const uint32_t q = cnt / ns, r = cnt - q * ns;
+    off = sidx * q + (sidx < r ? sidx : r);
+    len = q + (sidx < r ? 1u : 0u);
+}
+
 // ci = w * nb1 + b (b >= 1)  ->  w * nb + (b - 1)
 __device__ __forceinline__ size_t msm_bucket_slot(uint32_t ci, int nb1) {
     uint32_t w = ci / (uint32_t)nb1;

@@ -317,13 +317,11 @@ k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase,
             nseg[(size_t)w * nb1] = 0;
         }
         const uint32_t seg_log = (uint32_t)(MSM_SEG_LOG2 + seg_shift);
-        const uint32_t full = v >> seg_log, rem = v & ((1u << seg_log) - 1u);
-        const uint32_t ns = full + (rem ? 1u : 0u);
+        const uint32_t ns = msm_seg_count(v, seg_log);            // equal segments (msm_seg_range)
         uint32_t my_heavy = 0, my_seg = 0;
         if (threadIdx.x < (unsigned)NF) {
             nseg[ci] = ns;
-            if (full) atomicAdd(&lh[MSM_SEG], full);
-            if (rem) atomicAdd(&lh[msm_seg_class(rem, seg_shift)], 1u);
+            if (ns) atomicAdd(&lh[msm_seg_class((v + ns - 1u) / ns, seg_shift)], ns);
             if (ns > 1) {
                 my_heavy = atomicAdd(&heavy_n, 1u);
                 my_seg = atomicAdd(&heavy_segs, ns);
@@ -515,17 +513,12 @@ k_msm_plan2(const uint32_t *__restrict__ counts, int NC, int W, int NF, int top_
     if (w % period == top_row) NF = NF_top;
     if (threadIdx.x >= (unsigned)NF) return;
     const size_t ci = (size_t)w * nb1 + 1 + (size_t)cb * NF + threadIdx.x;
-    uint32_t cnt = counts[ci];
-    uint32_t full = cnt >> seg_log, rem = cnt & ((1u << seg_log) - 1u);
-    if (rem) {
-        uint32_t bin = msm_seg_class(rem, seg_shift);
-        uint32_t r = atomicAdd(&cur[bin], 1u);
-        tasks[first[bin] + r] = make_uint2((uint32_t)ci, full);
-    }
-    if (full) {
-        uint32_t r = atomicAdd(&cur[MSM_SEG], full);
-        uint32_t base = first[MSM_SEG] + r;
-        for (uint32_t sidx = 0; sidx < full; sidx++) tasks[base + sidx] = make_uint2((uint32_t)ci, sidx);
+    const uint32_t cnt = counts[ci];
+    const uint32_t ns = msm_seg_count(cnt, seg_log);
+    if (ns) {                                   // the bucket's ns equal segments are consecutive tasks of one class
+        const uint32_t bin = msm_seg_class((cnt + ns - 1u) / ns, seg_shift);
+        const uint32_t base = first[bin] + atomicAdd(&cur[bin], ns);
+        for (uint32_t sidx = 0; sidx < ns; sidx++) tasks[base + sidx] = make_uint2((uint32_t)ci, sidx);
     }
 }
 
@@ -646,6 +639,11 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
     // (with few windows - fixed-base tables - more chunk-lanes per window keep the same ~64 K lanes busy)
     int chunks = MSM_REDUCE_CHUNKS;
     while (chunks * 2 * p.W <= MSM_REDUCE_CHUNKS * 16 && chunks * 2 <= ctx->reduce_max_chunks) chunks *= 2;
+    // ... and FEWER for many windows (several commitments in one pass): the reduction kernel holds 256 VGPRs, so
+    // the chip keeps 2^17 of its lanes resident; beyond 2^16 chunk-lanes a pass runs in rounds, and every lane
+    // repeats the offset ladder - at three commitments per pass 1024 chunk-lanes per window do half the work of
+    // 4096 (0.93 -> 0.885 ms per commitment with three passes in flight, profiles/r04_probes/reduce_chunks.txt)
+    while (chunks * p.W > MSM_REDUCE_CHUNKS * 16 && chunks > 256) chunks /= 2;
     if (ctx->reduce_chunks_override >= 64) chunks = ctx->reduce_chunks_override;        // (experiment / throughput mode)
     if (chunks > p.nb) chunks = p.nb;
     p.chunks = chunks;

@@ -246,7 +246,6 @@ struct vmpc_p4 {
     char *mine, *gathered;            // 2 partial points of this rank; world x 2 gathered ones
     bool poisoned;                    // a call failed after the fold state advanced: only destroy is valid
     const void *table0;               // the caller's table (the unfolded CRS / block)
-    int small_window;                 // digit width on a folded vector's table (0: the context's default)
 };
 
 // All device buffers of a context are carved from one arena that stays with the vmpc_ctx between proofs
@@ -337,9 +336,6 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     p->block_lo = (size_t)rank * block_n;
     p->block_n = block_n;
     p->table = p->table0 = table;
-    p->small_window = 0;
-    if (const char *e = getenv("VMPC_P4_SMALL_WINDOW")) p->small_window = atoi(e);
-    if (p->small_window != 4 && p->small_window != 8 && p->small_window != 16) p->small_window = 0;
     p->table_n = table_n;
     p->table_extra = table_extra;
     p->rows = rows;
@@ -352,7 +348,7 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     {
         int l2 = p->log2_n;
         size_t bn = block_n, spread = (size_t)world;
-        const char *f2d = getenv("VMPC_P4_FOLD_TO_DIRECT");
+        const char *f2d = vmpc_getenv_experimental("VMPC_P4_FOLD_TO_DIRECT");
         while (int k = p4_next_jump(p->jump_k, p->jump_min, p->direct_log2, f2d && atoi(f2d) != 0, l2, bn, spread)) {
             vmpc_p4::jump_slot js;
             js.k = k;
@@ -600,15 +596,16 @@ static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
         VMPC_KERNEL_CHECK();
     } else {
         // v_a and v_b are each zero on half of their positions (z_l against g_r, z_r against g_l): tell the planner
-        ctx->plan_fill_shift = 1;
-        if (const char *e = getenv("VMPC_P4_FILL_SHIFT")) ctx->plan_fill_shift = atoi(e);       // (experiment)
-        // digit width of the commitments over a FOLDED vector's table (VMPC_P4_SMALL_WINDOW, tuning knob)
-        const int saved_window = ctx->window_override;
-        if (p->small_window && p->table != p->table0) ctx->window_override = p->small_window;
+        // (shift 2, not 1: the pair's 2 x 2^15 x period buckets hold ~128 entries each, and with 64-entry segments
+        // the chip's 2^18 lanes get one full segment each plus a short second wave - 32-entry segments measured
+        // 0.90 -> 0.75 ms for the bucket stage of a big round, scripts/prove_stages.py)
+        ctx->plan_fill_shift = 2;
+        if (const char *e = vmpc_getenv_experimental("VMPC_P4_FILL_SHIFT")) ctx->plan_fill_shift = atoi(e);
+        // (narrower digits on a folded vector's table were measured in rounds 2-3 and lose at every size - DESIGN.md
+        // section 10 - the knob is gone)
         const int rc = vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
                                                 pair_out, nullptr);
         ctx->plan_fill_shift = 0;
-        ctx->window_override = saved_window;
         VMPC_CHECK(rc);
     }
     // the round's one exchange: all-gather + rank-ordered add on the same stream, the result lands in the pinned block
@@ -618,7 +615,7 @@ static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
     // The first round's synchronisation also fetches the device status words (a non-canonical scalar in the caller's
     // z_hat / L~ shows up in this round's recoding); later rounds only consume scalars this context produced, so
     // they just wait for the stream - vmpc_p4_finish checks the status once more at the end.
-    if (p->committed == 0 || getenv("VMPC_P4_FULL_SYNC")) VMPC_CHECK(vmpc_ctx_sync(ctx));
+    if (p->committed == 0 || vmpc_getenv_experimental("VMPC_P4_FULL_SYNC")) VMPC_CHECK(vmpc_ctx_sync(ctx));
     else VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     p->committed++;
     p4_affine_pair(ext, out_A, out_B);

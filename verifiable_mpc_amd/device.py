@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from . import _native
+from . import _native, formats
 from .groups import ORDER, Ed25519Point
 
 _CTX = None
@@ -171,17 +171,21 @@ class ScalarVector:
         assert len(other) == len(self)
         return DeviceScalar(self.ctx.fr_dot_to_dev(self.ptr, other.ptr, len(self)), self.ctx)
 
-    def text_begin(self, is_signed=True):
+    def text_begin(self, is_signed=None):
         """start producing the transcript text on the side stream (no host wait): formatting and
         the device->host copy then overlap the kernels that follow on the main stream"""
+        if is_signed is None:
+            is_signed = formats.scalar_signed()
         if len(self):
             side = get_aux_context(2)
             side.wait_for(self.ctx)
             self._pending_text = (is_signed, side.format_begin("scalars", self.ptr, len(self), is_signed,
                                                                     keepalive=self.v.buf))
 
-    def text(self, is_signed=True):
+    def text(self, is_signed=None):
         """b'v0, v1, ..., ' as produced on the device (uint8 array)."""
+        if is_signed is None:
+            is_signed = formats.scalar_signed()
         pend = getattr(self, "_pending_text", None)
         if pend is not None and pend[0] == is_signed:
             return pend[1].result()
@@ -392,15 +396,17 @@ class PointVector:
         if self.p is not None and len(self):
             side = get_aux_context(2)
             side.wait_for(self.ctx)
-            self._pending_text = side.format_begin("points", self.p.ptr, len(self), keepalive=self.p.buf)
+            # (remembered WITH the point format it was produced in: formats.set_reference_format takes effect at once)
+            self._pending_text = (formats.point_style(), side.format_begin("points", self.p.ptr, len(self),
+                                                                           keepalive=self.p.buf))
 
     def text(self):
         """b'[X, Y, Z], [X, Y, Z], ..., ' (uint8 array) for the Fiat-Shamir pre-image."""
         if self.p is None:
             raise ValueError("projective representatives were not kept for this vector")
         pend = getattr(self, "_pending_text", None)
-        if pend is not None:
-            return pend.result()
+        if pend is not None and pend[0] == formats.point_style():
+            return pend[1].result()
         return self.ctx.format_points(self.p.ptr, len(self))
 
     def __repr__(self):

@@ -116,7 +116,11 @@ def _pfield(modulus, is_signed):
     return cls
 
 
-def GF(modulus, is_signed=True):
+def GF(modulus, is_signed=None):
     """Field of integers mod the prime `modulus` (no primality test: the two moduli of this
-    path, 2^255-19 and the Ed25519 group order, are fixed constants)."""
+    path, 2^255-19 and the Ed25519 group order, are fixed constants).  is_signed=None takes the
+    recalled MPyC default for scalar fields from formats.set_reference_format (signed today)."""
+    if is_signed is None:
+        from . import formats
+        is_signed = formats.scalar_signed()
     return _pfield(int(modulus), bool(is_signed))

@@ -73,7 +73,12 @@ class EllipticCurvePoint(FiniteGroupElement):
     __slots__ = ()
 
 
-_FIELD = GF(P, is_signed=False)
+_FIELD = GF(P, is_signed=False)      # [mpyc-recall] coordinates print unsigned; formats.set_reference_format changes it
+
+
+def _coord_field():
+    from . import formats
+    return GF(P, is_signed=formats.coord_signed())
 
 
 class Ed25519Point(EllipticCurvePoint):
@@ -105,7 +110,8 @@ class Ed25519Point(EllipticCurvePoint):
 
     @property
     def value(self):
-        return [_FIELD(c) for c in self.coords]
+        f = _coord_field()
+        return [f(c) for c in self.coords]
 
     def __getitem__(self, key):
         return self.value[key]
@@ -184,7 +190,11 @@ class Ed25519Point(EllipticCurvePoint):
         return hash(self.normalize().coords)
 
     def __repr__(self):
-        return repr(self.value)
+        # [mpyc-recall] the list of the three coordinates; bracket pair and coordinate signedness are the
+        # runtime choices of formats.set_reference_format (csrc/fmt.h prints device vectors the same way)
+        from . import formats
+        o, c = formats.point_brackets()
+        return o + ", ".join(repr(v) for v in self.value) + c
 
     # -- byte formats of include/vmpc.h -------------------------------------------------
     def to_affine_bytes(self):

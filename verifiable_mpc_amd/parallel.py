@@ -58,10 +58,12 @@ class HipBackend:
         # Phase pipelining (include/vmpc.h vmpc_ctx_set_bucket_stream): the slots share one bucket stream, so their
         # bucket kernels run back to back, one at a time, each a persistent launch that leaves register-file room
         # for the sort of the next pass and the reduction / recombination of the previous one.
-        # VMPC_BUCKET_STREAM=0 turns it off (each slot's whole pipeline on its own stream, as in rounds 1-3).
+        # OFF by default (VMPC_EXPERIMENTAL=1 VMPC_BUCKET_STREAM=1 turns it on): measured in round 4 it loses - a bucket kernel confined
+        # to 3 (2) workgroups per CU is 21 % (40 %) slower by itself, and the co-runners take their share of the
+        # vector ALU on top (profiles/r04_probes/bucket_stream.txt).
         self.bucket_stream = None
         wgs = int(os.environ.get("VMPC_PIPE_BUCKET_WGS_PER_CU", "3"))
-        if n_slots > 1 and os.environ.get("VMPC_BUCKET_STREAM", "1") != "0":
+        if n_slots > 1 and os.environ.get("VMPC_EXPERIMENTAL", "0") != "0" and os.environ.get("VMPC_BUCKET_STREAM", "0") != "0":
             from ._native import SharedStream
             self.bucket_stream = SharedStream(ctx.device, int(os.environ.get("VMPC_BUCKET_STREAM_PRIORITY", "-1")))
         self.bucket_wgs = wgs

@@ -15,6 +15,7 @@ reference's typing semantics, points are sent to the GPU per call) or the device
 vectors of verifiable_mpc_amd.device (everything stays in HBM).
 """
 import hashlib
+import time
 import logging
 from random import SystemRandom
 
@@ -161,6 +162,44 @@ def _int(value):
 
 # ---- Fiat-Shamir ---------------------------------------------------------------------------------
 
+# What the reference-transcript modes spend in SHA-256 itself: bytes hashed and seconds inside update() since the last
+# reset (bench.py prices prove / verify against this floor; pivot.py:131-136 hashes ~1 GB of text at N = 2^20).
+HASH_STATS = {"bytes": 0, "seconds": 0.0, "calls": 0}
+
+
+def hash_stats(reset=False):
+    out = dict(HASH_STATS)
+    if reset:
+        HASH_STATS.update(bytes=0, seconds=0.0, calls=0)
+    return out
+
+
+class _CountingSha256:
+    """hashlib.sha256 with a byte and time count on update() (large buffers only: the clock is read per call)"""
+    __slots__ = ("h",)
+
+    def __init__(self, h=None):
+        self.h = h if h is not None else hashlib.sha256()
+
+    def update(self, b):
+        n = len(b)
+        if n < 4096:
+            self.h.update(b)
+            HASH_STATS["bytes"] += n
+            return
+        t0 = time.perf_counter()
+        self.h.update(b)
+        HASH_STATS["seconds"] += time.perf_counter() - t0
+        HASH_STATS["bytes"] += n
+        HASH_STATS["calls"] += 1
+
+    def copy(self):
+        return _CountingSha256(self.h.copy())
+
+    def digest(self):
+        return self.h.digest()
+
+
 def _feed(h, obj):
     """Stream str(obj) into the hash without materialising it: byte-identical to
     str(input_list).encode('utf-8') for the object kinds on the AC20 path; device vectors
@@ -200,7 +239,7 @@ def _feed(h, obj):
 
 def fiat_shamir_hash(input_list, order):
     """pivot.py:131-136: int.from_bytes(sha256(str(input_list)), 'little') % order."""
-    h = hashlib.sha256()
+    h = _CountingSha256()
     _feed(h, input_list)
     return int.from_bytes(h.digest(), "little") % order
 
@@ -209,7 +248,7 @@ def fiat_shamir_hash_variants(common_items, tails, order):
     """[fiat_shamir_hash(common_items + tail, order) for tail in tails] with the shared
     prefix hashed once (SHA-256 state copied).  Protocol 5 hashes the same O(N) list twice,
     differing only in the trailing [0|1, tag] (compressed_pivot.py:125-130)."""
-    h = hashlib.sha256()
+    h = _CountingSha256()
     h.update(b"[")
     for i, item in enumerate(common_items):
         if i:
