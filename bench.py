@@ -343,7 +343,11 @@ def bn256_timing(vm, ctx, n_pow):
                              "kernel": "gk_bucket (stage bn_bucket)", "kernel_ms": bucket_s * 1e3,
                              "achieved": n * windows / bucket_s / 1e9 if bucket_s else None,
                              "frac": n * windows / bucket_s / peak if bucket_s else None,
-                             "whole_sum_frac": n * windows / (out[f"{tag}_prepared_key_ms"] * 1e-3) / peak}
+                             "whole_sum_frac": n * windows / (out[f"{tag}_prepared_key_ms"] * 1e-3) / peak,
+                             # what pynocchio.PreparedKey actually asks for: the sum left in Jacobian coordinates (one
+                             # host inversion instead of a ~380-multiplication single-lane chain on the device)
+                             "whole_sum_frac_jacobian_out":
+                                 n * windows / (out[f"{tag}_prepared_key_jacobian_out_ms"] * 1e-3) / peak}
         # algorithmic bytes per term: 32-byte scalar + affine point (64 B G1, 128 B twist)
         per_term = 32 + width
         out[f"{tag}_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_term": per_term,
@@ -375,6 +379,22 @@ def other_sizes_timing(vm, ctx, pows):
         ctx.sync()
         dt = (time.perf_counter() - t0) / reps
         out[f"n2^{lg}"] = {"ms": round(dt * 1e3, 3), "M_scalar_mults_per_s": round(n / dt / 1e6, 1)}
+        # the same commitment over the generators as circuit_sat.create_generators hands them to vector_commitment:
+        # a fixed-base table, rows by PointVector.precompute's budget (16 rows up to 2^19 generators, 8 at 2^20, the
+        # prepared form alone beyond) - the latency a prover's commitment actually pays
+        tab = vm.PointVector(pts.a, None, ctx).precompute([])
+        t_ = tab._table
+        for _ in range(2):
+            ctx.msm_table(t_.ptr, t_.n, 0, sc.ptr, n, None, res.ptr, None, rows=t_.rows)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.msm_table(t_.ptr, t_.n, 0, sc.ptr, n, None, res.ptr, None, rows=t_.rows)
+            ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        out[f"n2^{lg}"].update({"crs_table_rows": t_.rows, "ms_over_crs_table": round(dt * 1e3, 3),
+                                "M_scalar_mults_per_s_over_crs_table": round(n / dt / 1e6, 1)})
+        del tab, t_
         del pts, sc
     return out
 

@@ -37,5 +37,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_calib_$TAG" -- \
 (cd "$REPO" && sha256sum verifiable_mpc_amd/csrc/msm.hip verifiable_mpc_amd/csrc/msm_sort.hip verifiable_mpc_amd/csrc/ge25519.h verifiable_mpc_amd/csrc/fe25519.h) > "$OUT/sources_$TAG.txt"
 # (--batch 1 in the PMC passes: every k_msm_bucket launch is then ONE commitment, the unit the roofline figure uses)
 # keep what travels back small: stats + counter csv only
+# the timed region's dispatch timeline (which queues run what, when) and the prover's stage table
+(cd "$REPO" && bash scripts/pipeline_trace.sh timeline_$TAG 20 36 3 3 > /dev/null 2>&1)
+python3 "$REPO/scripts/prove_stages.py" 20 rounds > "$OUT/prove_stages_$TAG.txt" 2>&1
+python3 "$REPO/scripts/ref_prove_phases.py" 20 > "$OUT/ref_prove_phases_$TAG.txt" 2>&1
 find "$OUT" -name '*kernel_trace.csv' -delete
 ls "$OUT" | grep "$TAG" | head -40

@@ -83,6 +83,11 @@ def main():
                       (f"prof_{tag}_prove_reference.json", "prove_reference_under_rocprof.json")):
         if os.path.exists(os.path.join(out, sub)):
             shutil.copy(os.path.join(out, sub), os.path.join(prof, f"{tag}_{name}"))
+    for src, name in ((os.path.join(out, f"timeline_{tag}", "timeline.txt"), "timeline.txt"),
+                      (os.path.join(out, f"prove_stages_{tag}.txt"), "prove_stages.txt"),
+                      (os.path.join(out, f"ref_prove_phases_{tag}.txt"), "ref_prove_phases.txt")):
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(prof, f"{tag}_{name}"))
     fetch = counter_avgs(os.path.join(out, f"pmc_fetch_{tag}"), "FETCH_SIZE")
     write = counter_avgs(os.path.join(out, f"pmc_write_{tag}"), "WRITE_SIZE")
     kernels = {}

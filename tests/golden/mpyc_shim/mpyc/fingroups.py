@@ -2,7 +2,7 @@
 import functools
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "../../../..")))
-from .finfields import GF
+from .finfields import GF, _alt_format
 
 
 class FiniteGroupElement:
@@ -53,7 +53,6 @@ class FiniteGroupElement:
         return hash(repr(self))
 
     def __repr__(self):
-        from mpyc.finfields import _alt_format
         b = _alt_format()[0]
         if b == "[]":
             return repr(self.value)
@@ -76,7 +75,6 @@ def _make_ed25519():
     both with a textbook affine law and with OpenSSL-made vectors)."""
     p = 2**255 - 19
     field = GF(p)
-    from mpyc.finfields import _alt_format
     field.is_signed = _alt_format()[1]   # [mpyc-recall] fingroups sets is_signed = False on its fields
     a = field(-1)
     d = field(-121665) / field(121666)

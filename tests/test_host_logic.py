@@ -86,6 +86,33 @@ def test_install_patches_reference_modules(monkeypatch):
     assert len(patched) == 8
 
 
+def test_circuit_sat_harness_names_delegate_to_the_reference(monkeypatch):
+    """circuit_sat_prover / circuit_sat_verifier (circuit_sat_cb.py:255,285) exist under this package's names, install the
+    hot path into the reference's modules and call the reference's own function with the reference's enum member"""
+    import enum
+    import sys
+    import types
+    pkg = "fake_ref_pkg2"
+    mods = {}
+    for name in ("", ".pivot", ".compressed_pivot", ".circuit_sat_r1cs", ".circuit_sat_cb"):
+        m = types.ModuleType(pkg + name)
+        mods[pkg + name] = m
+        monkeypatch.setitem(sys.modules, pkg + name, m)
+    cb = mods[pkg + ".circuit_sat_cb"]
+    cb.PivotChoice = enum.Enum("PivotChoice", "pivot compressed koe")
+    calls = []
+    cb.circuit_sat_prover = lambda gens, circuit, x, gf, choice: calls.append(("p", choice)) or {"proof": 1}
+    cb.circuit_sat_verifier = lambda proof, gens, circuit, gf, choice: calls.append(("v", choice)) or {"ok": True}
+    monkeypatch.setattr(vm.circuit_sat, "REFERENCE_PACKAGE", pkg)
+    assert vm.circuit_sat_prover({"g": []}, None, [1], None) == {"proof": 1}
+    assert vm.circuit_sat_verifier({"proof": 1}, {"g": []}, None, None, vm.PivotChoice.pivot) == {"ok": True}
+    assert calls == [("p", cb.PivotChoice.compressed), ("v", cb.PivotChoice.pivot)]
+    assert mods[pkg + ".pivot"].vector_commitment is pivot.vector_commitment          # install() ran
+    monkeypatch.setattr(vm.circuit_sat, "REFERENCE_PACKAGE", "no_such_reference_pkg")
+    with pytest.raises(ImportError, match="circuit front end"):
+        vm.circuit_sat_prover({}, None, [], None)
+
+
 def test_product_never_imports_the_oracle():
     import os
     root = os.path.dirname(os.path.abspath(vm.__file__))

@@ -6,7 +6,7 @@ Importing the package does not touch the GPU; the first kernel call loads
 libvmpc_hip.so and raises if it (or a GPU) is missing - there is no CPU fallback.
 """
 from . import circuit_sat, compressed_pivot, pivot  # noqa: F401
-from .circuit_sat import PivotChoice, create_generators  # noqa: F401
+from .circuit_sat import PivotChoice, circuit_sat_prover, circuit_sat_verifier, create_generators  # noqa: F401
 from .device import PointVector, ScalarVector, get_context  # noqa: F401
 from .fields import GF  # noqa: F401
 from .formats import get_reference_format, reset_reference_format, set_reference_format  # noqa: F401

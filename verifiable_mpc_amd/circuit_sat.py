@@ -75,3 +75,47 @@ def check_input_length_power_of_2(x, circuit, padding_value=0):
         padding = 0
     check = padding == 0
     return check, padding, z_len + padding
+
+
+# ---- the harness names (circuit_sat_cb.py:255-318) ----------------------------------------------------------------
+# The circuit front end - circuit_builder, the Protocol-8 form construction, the dispatch on PivotChoice - is
+# quadratic-time Python that stays with the reference (out of scope).  These two names exist so
+# that a caller who switches to this package finds them: they install() the hot path into the reference's modules
+# and hand the call to the reference's own function, unchanged.
+REFERENCE_PACKAGE = "verifiable_mpc.ac20"
+
+
+def _reference_circuit_sat():
+    import importlib
+    from . import install
+    try:
+        ref = importlib.import_module(REFERENCE_PACKAGE + ".circuit_sat_cb")
+    except ImportError as e:
+        raise ImportError(
+            f"circuit_sat_prover / circuit_sat_verifier delegate to the reference's {REFERENCE_PACKAGE}.circuit_sat_cb "
+            f"(circuit front end, out of scope of this package); it is not importable here: {e}") from e
+    install(REFERENCE_PACKAGE)
+    return ref
+
+
+def circuit_sat_prover(generators, circuit, x, gf, pivot_choice=PivotChoice.compressed):
+    """circuit_sat_cb.py:255-282, same arguments and return value: the reference's function over this package's
+    vector_commitment / protocol_5_prover / create_generators (install())."""
+    ref = _reference_circuit_sat()
+    return ref.circuit_sat_prover(generators, circuit, x, gf, _ref_choice(ref, pivot_choice))
+
+
+def circuit_sat_verifier(proof, generators, circuit, gf, pivot_choice=PivotChoice.compressed):
+    """circuit_sat_cb.py:285-318, same arguments and return value (the verification dict)."""
+    ref = _reference_circuit_sat()
+    return ref.circuit_sat_verifier(proof, generators, circuit, gf, _ref_choice(ref, pivot_choice))
+
+
+def _ref_choice(ref, choice):
+    """this package's PivotChoice member -> the reference's member of the same name (the reference compares
+    members of ITS enum)"""
+    ref_enum = getattr(ref, "PivotChoice", None)
+    name = getattr(choice, "name", None)
+    if ref_enum is not None and name is not None and not isinstance(choice, ref_enum):
+        return ref_enum[name]
+    return choice

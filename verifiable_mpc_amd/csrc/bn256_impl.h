@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(MSM_BLOCK)
 gk_bucket(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ sorted,
           const uint32_t *__restrict__ starts, const uint32_t *__restrict__ counts,
           const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
-          const uint2 *__restrict__ tasks, const uint32_t *__restrict__ n_tasks, int nb1, int seg,
+          const uint2 *__restrict__ tasks, const uint32_t *__restrict__ n_tasks, int nb1, int seg, int balanced,
           uint32_t *__restrict__ buckets, uint32_t *__restrict__ partial) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= *n_tasks) return;
@@ -45,7 +45,7 @@ gk_bucket(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ sor
     uint32_t ci = tk.x, sidx = tk.y;
     const uint32_t ns = nseg[ci];
     uint32_t lo, len;
-    msm_seg_range(counts[ci], ns, sidx, lo, len);      // equal segments (msm_sort.h)
+    msm_seg_range(counts[ci], ns, sidx, (uint32_t)seg, balanced, lo, len);      // msm_sort.h
     lo += starts[ci];
     typename C::acc_t acc = C::identity();
     for (uint32_t j = 0; j < len; j++) {
@@ -286,7 +286,7 @@ int bn_kernels<C, F>::bucket(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const 
     hipStream_t st = ctx->stream;
     gk_bucket<C><<<(unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, st>>>(
         entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
-        (int)msm_seg_len(p), w.buckets, w.seg_partial);
+        (int)msm_seg_len(p), p.balanced, w.buckets, w.seg_partial);
     VMPC_KERNEL_CHECK();
     gk_finish_light<C, F><<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg, w.seg_starts,
                                                                   w.seg_partial, p.nb1, w.buckets);

@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_BUCKET_WAVES)
 k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ sorted,
              const uint32_t *__restrict__ starts, const uint32_t *__restrict__ counts,
              const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
-             const uint2 *__restrict__ tasks, const uint32_t *__restrict__ n_tasks, int nb1, int seg,
+             const uint2 *__restrict__ tasks, const uint32_t *__restrict__ n_tasks, int nb1, int seg, int balanced,
              uint32_t *__restrict__ buckets, uint32_t *__restrict__ partial) {
     // grid-stride over the task table: a launch with fewer workgroups than tasks / 256 (persistent form,
     // msm_accumulate) leaves register-file room on every SIMD for other streams' kernels
@@ -77,7 +77,7 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
     uint32_t ci = tk.x, sidx = tk.y;
     const uint32_t ns = nseg[ci];
     uint32_t lo, len;
-    msm_seg_range(counts[ci], ns, sidx, lo, len);
+    msm_seg_range(counts[ci], ns, sidx, (uint32_t)seg, balanced, lo, len);
     lo += starts[ci];
     ge_ext acc = ge_ext_identity();
     // Sorted indices in groups of MSM_IDX_BATCH.  A lane walks its own segment, so the lanes' 4-byte index loads
@@ -420,7 +420,7 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
             grid = (unsigned)(ctx->bucket_wgs_per_cu * ctx->cu_count);
         k_msm_bucket<<<grid, MSM_BLOCK, 0, bst>>>(
             entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
-            (int)msm_seg_len(p), w.buckets, w.seg_partial);
+            (int)msm_seg_len(p), p.balanced, w.buckets, w.seg_partial);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             ctx->stage_stream = nullptr;

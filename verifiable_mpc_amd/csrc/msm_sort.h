@@ -21,6 +21,7 @@ struct msm_plan {
     int scalar_bits;    // scalars are < 2^scalar_bits
     int c, W, nb, nb1;  // nb = 2^(c-1) buckets per window, nb1 = nb + 1 (bucket 0 unused)
     int seg_shift;      // segments of MSM_SEG << seg_shift entries (negative: MSM_SEG >> -seg_shift), msm_seg_len()
+    int balanced;       // 1: a bucket's segments have EQUAL length (+-1); 0: full segments plus a remainder
     int LB;             // fine bits: bucket b = coarse << LB | fine, 2^LB <= 512 fine buckets per coarse bin
     int NC;             // coarse bins per window = nb >> LB
     int J;              // chunks of 8192 terms per digit row
@@ -87,17 +88,26 @@ static inline int msm_ilog2(int v) {
     return r;
 }
 
-// A bucket of cnt entries is cut into ns = ceil(cnt / seg) segments of EQUAL length (+-1): the first cnt % ns of them
-// hold one entry more.  (Rounds 1-3 cut full segments of `seg` entries plus a remainder: with ~2 x seg entries per
-// bucket - the A_i / B_i pair of a prover round - the remainders formed a second, short wave of tasks that ran on a
-// quarter of the chip.)  Segment sidx of the bucket: its first entry and its length.
+// A bucket of cnt entries is cut into ns = ceil(cnt / seg) segments.  balanced: of EQUAL length (+-1), the first
+// cnt % ns of them one entry longer; otherwise full segments of `seg` entries plus a remainder.  Which is better
+// depends on how the tasks fill the chip: with ~2 x seg entries per bucket and four waves per SIMD (the A_i / B_i pair
+// of an Ed25519 prover round) the remainders formed a second, short wave of tasks on a quarter of the chip - equal
+// segments took that bucket stage from 0.75 to 0.71 ms; with one wave per SIMD (the 384-VGPR BN-256 kernels run their
+// workgroups in rounds) the short remainders ARE the cheap last round - equal segments cost 14 %.  The plan says.
+// Segment sidx of the bucket: its first entry and its length.
 __host__ __device__ __forceinline__ uint32_t msm_seg_count(uint32_t cnt, uint32_t seg_log) {
     return (cnt + (1u << seg_log) - 1u) >> seg_log;
 }
-__device__ __forceinline__ void msm_seg_range(uint32_t cnt, uint32_t ns, uint32_t sidx, uint32_t &off, uint32_t &len) {
+__device__ __forceinline__ void msm_seg_range(uint32_t cnt, uint32_t ns, uint32_t sidx, uint32_t seg, int balanced,
+                                              uint32_t &off, uint32_t &len) {
     if (ns <= 1) {
         off = 0;
         len = cnt;
+        return;
+    }
+    if (!balanced) {
+        off = sidx * seg;
+        len = cnt - off < seg ? cnt - off : seg;
         return;
     }
     const uint32_t q = cnt / ns, r = cnt - q * ns;

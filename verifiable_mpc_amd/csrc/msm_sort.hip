@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(SORT_BLOCK, 8)      // 8 waves per SIMD = two 
 k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase, int NC, int W, int LB, int top_row,
             int period, int LB_top, int J, int idx_bits, int nb1, const int16_t *__restrict__ digits, size_t n_pad,
             uint32_t *__restrict__ counts, uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
-            int seg_shift, uint32_t *__restrict__ nseg, uint32_t *__restrict__ block_hist,
+            int seg_shift, int balanced, uint32_t *__restrict__ nseg, uint32_t *__restrict__ block_hist,
             uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ seg_starts,
             uint32_t *__restrict__ ctrl /*[0] = #split buckets, [2] = #partial sums, [3] = #big bins*/) {
     __shared__ uint32_t cnt[512], cur[512], scratch[16];
@@ -321,7 +321,13 @@ k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase,
         uint32_t my_heavy = 0, my_seg = 0;
         if (threadIdx.x < (unsigned)NF) {
             nseg[ci] = ns;
-            if (ns) atomicAdd(&lh[msm_seg_class((v + ns - 1u) / ns, seg_shift)], ns);
+            if (balanced) {
+                if (ns) atomicAdd(&lh[msm_seg_class((v + ns - 1u) / ns, seg_shift)], ns);
+            } else {
+                const uint32_t full = v >> seg_log, rem = v & ((1u << seg_log) - 1u);
+                if (full) atomicAdd(&lh[MSM_SEG], full);
+                if (rem) atomicAdd(&lh[msm_seg_class(rem, seg_shift)], 1u);
+            }
             if (ns > 1) {
                 my_heavy = atomicAdd(&heavy_n, 1u);
                 my_seg = atomicAdd(&heavy_segs, ns);
@@ -367,6 +373,8 @@ k_sort_fine_big(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gb
                 int top_row, int period, int LB_top, int J, int idx_bits, int nb1, const int16_t *__restrict__ digits,
                 size_t n_pad, const uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
                 const uint32_t *__restrict__ ctrl) {
+    // (a small grid walking the slots instead of one workgroup per slot was tried in round 4 to make the empty case
+    // cheaper: 15 against 13 us - the cost of this launch is not its workgroup count)
     if (ctrl[3] == 0) return;
     const int cb = blockIdx.x % NC, w = W - 1 - blockIdx.x / NC;
     const size_t slot = (size_t)w * NC + cb;
@@ -497,7 +505,7 @@ k_msm_classes(uint32_t *__restrict__ ctrl, int W, uint32_t *__restrict__ class_b
 // bucket: task id = first id of the (length, window) cell + this block's first rank in it + a local rank
 __global__ void __launch_bounds__(512)
 k_msm_plan2(const uint32_t *__restrict__ counts, int NC, int W, int NF, int top_row, int period, int NF_top, int nb1,
-            int seg_shift,
+            int seg_shift, int balanced,
             const uint32_t *__restrict__ class_base, const uint32_t *__restrict__ block_rank,
             uint2 *__restrict__ tasks) {
     const uint32_t seg_log = (uint32_t)(MSM_SEG_LOG2 + seg_shift);
@@ -515,10 +523,22 @@ k_msm_plan2(const uint32_t *__restrict__ counts, int NC, int W, int NF, int top_
     const size_t ci = (size_t)w * nb1 + 1 + (size_t)cb * NF + threadIdx.x;
     const uint32_t cnt = counts[ci];
     const uint32_t ns = msm_seg_count(cnt, seg_log);
-    if (ns) {                                   // the bucket's ns equal segments are consecutive tasks of one class
-        const uint32_t bin = msm_seg_class((cnt + ns - 1u) / ns, seg_shift);
-        const uint32_t base = first[bin] + atomicAdd(&cur[bin], ns);
-        for (uint32_t sidx = 0; sidx < ns; sidx++) tasks[base + sidx] = make_uint2((uint32_t)ci, sidx);
+    if (balanced) {
+        if (ns) {                               // the bucket's ns equal segments are consecutive tasks of one class
+            const uint32_t bin = msm_seg_class((cnt + ns - 1u) / ns, seg_shift);
+            const uint32_t base = first[bin] + atomicAdd(&cur[bin], ns);
+            for (uint32_t sidx = 0; sidx < ns; sidx++) tasks[base + sidx] = make_uint2((uint32_t)ci, sidx);
+        }
+        return;
+    }
+    const uint32_t full = cnt >> seg_log, rem = cnt & ((1u << seg_log) - 1u);
+    if (rem) {
+        const uint32_t bin = msm_seg_class(rem, seg_shift);
+        tasks[first[bin] + atomicAdd(&cur[bin], 1u)] = make_uint2((uint32_t)ci, full);
+    }
+    if (full) {
+        const uint32_t base = first[MSM_SEG] + atomicAdd(&cur[MSM_SEG], full);
+        for (uint32_t sidx = 0; sidx < full; sidx++) tasks[base + sidx] = make_uint2((uint32_t)ci, sidx);
     }
 }
 
@@ -625,6 +645,7 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
     // (work = the entries to expect: every position of every digit row, unless the caller knows the rows to be
     // sparsely populated - with the positions of a half-empty pair the prover's rounds got 128-entry segments,
     // 2^17 tasks for 2^18 lanes, and a bucket stage at half occupancy: 0.97 instead of 0.68 ms)
+    p.balanced = p.scalar_bits == 253 ? 1 : 0;       // Ed25519 (4 waves per SIMD) / BN-256 (1 wave per SIMD): msm_sort.h
     const size_t work = ((size_t)p.W * p.n_total) >> ctx->plan_fill_shift;
     p.seg_shift = 0;
     while (p.seg_shift < 4 && (((size_t)MSM_SEG << p.seg_shift) << 18) < work) p.seg_shift++;
@@ -763,7 +784,7 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
         if (p.fine_in_entry) {
             k_sort_fine<true><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period, p.LB_top,
                                                           p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.counts, w.starts,
-                                                          w.sorted, p.seg_shift, w.nseg, w.block_hist, w.heavy_list,
+                                                          w.sorted, p.seg_shift, p.balanced, w.nseg, w.block_hist, w.heavy_list,
                                                           w.seg_starts, w.ctrl);
             k_sort_fine_big<true><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period,
                                                               p.LB_top, p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.starts,
@@ -771,7 +792,7 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
         } else {
             k_sort_fine<false><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period, p.LB_top,
                                                            p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.counts, w.starts,
-                                                           w.sorted, p.seg_shift, w.nseg, w.block_hist, w.heavy_list,
+                                                           w.sorted, p.seg_shift, p.balanced, w.nseg, w.block_hist, w.heavy_list,
                                                            w.seg_starts, w.ctrl);
             k_sort_fine_big<false><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period,
                                                                p.LB_top, p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.starts,
@@ -786,7 +807,7 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
         k_msm_classes<<<1, 1024, 0, st>>>(w.ctrl, p.W, w.block_base);
         VMPC_KERNEL_CHECK();
         k_msm_plan2<<<w.plan_blocks, 512, 0, st>>>(w.counts, p.NC, p.W, 1 << p.LB, p.top_row, p.period, 1 << p.LB_top,
-                                                  p.nb1, p.seg_shift, w.block_base, w.block_hist, w.tasks);
+                                                  p.nb1, p.seg_shift, p.balanced, w.block_base, w.block_hist, w.tasks);
         VMPC_KERNEL_CHECK();
     }
     return VMPC_OK;
