@@ -15,6 +15,7 @@
 #include "../../verifiable_mpc_amd/csrc/fr.h"
 #include "../../verifiable_mpc_amd/csrc/fmt.h"
 #include "../../verifiable_mpc_amd/csrc/sw256.h"
+#include "../../verifiable_mpc_amd/csrc/fp29.h"
 
 static void parse_hex(const std::string &h, uint32_t *out, int limbs) {
     for (int i = 0; i < limbs; i++) out[i] = 0;
@@ -87,6 +88,28 @@ template <> fp rd_el<Fp1Ops>(std::istringstream &is) { return rd_fp(is); }
 template <> fp2 rd_el<Fp2Ops>(std::istringstream &is) { return rd_fp2(is); }
 static std::string elhex(const fp &a) { return fphex(a); }
 static std::string elhex(const fp2 &a) { return fp2hex(a); }
+// the latency field (fp29.h): canonical integers in and out through its own load / store
+static fp29 rd_fp29(std::istringstream &is) {
+    std::string h;
+    is >> h;
+    uint32_t w[8];
+    parse_hex(h, w, 8);
+    return Fp29Ops::load(w);
+}
+static std::string fp29hex(const fp29 &a) {
+    uint32_t w[8];
+    Fp29Ops::store(w, a);
+    return to_hex(w, 8);
+}
+template <> fp29 rd_el<Fp29Ops>(std::istringstream &is) { return rd_fp29(is); }
+template <> fp29x2 rd_el<Fp29x2Ops>(std::istringstream &is) {
+    fp29x2 r;
+    r.a = rd_fp29(is);
+    r.b = rd_fp29(is);
+    return r;
+}
+static std::string elhex(const fp29 &a) { return fp29hex(a); }
+static std::string elhex(const fp29x2 &a) { return fp29hex(a.a) + " " + fp29hex(a.b); }
 
 template <class F> static aff<F> rd_aff(std::istringstream &is) {
     aff<F> r;
@@ -274,6 +297,35 @@ int main() {
         } else if (cmd == "bn2sqr" || cmd == "bn2inv") {
             fp2 a = rd_fp2(is);
             std::cout << fp2hex(cmd == "bn2sqr" ? fp2_sqr(a) : fp2_inv(a)) << "\n";
+        } else if (cmd == "l29mul" || cmd == "l29add" || cmd == "l29sub") {
+            fp29 a = rd_fp29(is), b = rd_fp29(is);
+            std::cout << fp29hex(cmd == "l29mul" ? fp29_mul(a, b) : cmd == "l29add" ? fp29_add(a, b) : fp29_sub(a, b)) << "\n";
+        } else if (cmd == "l29chain") {
+            // sums and differences fed back into products (every value stays in [0, 2p)): ((a+b)(a-b) - a a + b b) (a + a)
+            fp29 a = rd_fp29(is), b = rd_fp29(is);
+            fp29 t = fp29_sub(fp29_mul(fp29_add(a, b), fp29_sub(a, b)), fp29_sqr(a));
+            t = fp29_mul(fp29_add(t, fp29_sqr(b)), fp29_dbl(a));
+            std::cout << fp29hex(t) << " " << (fp29_is_zero(t) ? 1 : 0) << " " << (fp29_is_zero(fp29_sub(a, b)) ? 1 : 0) << "\n";
+        } else if (cmd == "l29sqr") {
+            fp29 a = rd_fp29(is);
+            std::cout << fp29hex(fp29_sqr(a)) << " " << fp29hex(fp29_sqr(fp29_add(a, a))) << "\n";
+        } else if (cmd == "l29inv") {
+            fp29 a = rd_fp29(is);
+            std::cout << fp29hex(fp29_inv(a)) << "\n";
+        } else if (cmd == "l29raw") {
+            // the workspace / table format: canonical residue of x 2^261 in eight words, and back
+            fp29 a = rd_fp29(is);
+            uint32_t w[8];
+            Fp29Ops::store_raw(w, fp29_add(a, fp29_zero()));
+            const fp29 l = Fp29Ops::load_raw(w);
+            std::cout << fp29hex(l) << " " << (Fp29Ops::raw_canonical(w) ? 1 : 0) << "\n";
+        } else if (cmd == "l29x2mul") {
+            fp29x2 a = rd_el<Fp29x2Ops>(is), b = rd_el<Fp29x2Ops>(is);
+            std::cout << elhex(fp29x2_mul(a, b)) << " " << elhex(fp29x2_sqr(a)) << " " << elhex(Fp29x2Ops::inv(a)) << "\n";
+        } else if (cmd.rfind("h1", 0) == 0) {
+            curve_cmd<Fp29Ops>(cmd.substr(2), is);
+        } else if (cmd.rfind("h2", 0) == 0) {
+            curve_cmd<Fp29x2Ops>(cmd.substr(2), is);
         } else if (cmd.rfind("g1", 0) == 0) {
             curve_cmd<Fp1Ops>(cmd.substr(2), is);
         } else if (cmd.rfind("g2", 0) == 0) {

@@ -230,9 +230,38 @@ def _flat(pt):
     return " ".join(hx(v) for v in out)
 
 
-@pytest.mark.parametrize("which", ["g1", "g2"])
+def test_bn256_latency_field(harness):
+    """fp29.h (9 x 29-bit limbs, Montgomery radix 2^261: the field of the reduction / recombination kernels) against
+    big ints: products, sums, differences with every value kept in [0, 2p), the zero test on unreduced values (p itself
+    is a representation of zero), inversion, and the conversion from / to sw256.h's memory format"""
+    rng = random.Random(29)
+    vals = [0, 1, 2, bn.P - 1, bn.P - 2, 2**255, 2**128 - 1, (bn.P + 1) // 2] + [rng.randrange(bn.P) for _ in range(80)]
+    lines, want = [], []
+    for i, a in enumerate(vals):
+        b = vals[(i * 7 + 3) % len(vals)]
+        lines += [f"l29mul {hx(a)} {hx(b)}", f"l29add {hx(a)} {hx(b)}", f"l29sub {hx(a)} {hx(b)}", f"l29sub {hx(a)} {hx(a)}"]
+        want += [hx(a * b % bn.P), hx((a + b) % bn.P), hx((a - b) % bn.P), hx(0)]
+        t = (((a + b) * (a - b) - a * a + b * b) * 2 * a) % bn.P          # == 0 identically
+        lines.append(f"l29chain {hx(a)} {hx(b)}")
+        want.append(f"{hx(t)} 1 {1 if a == b else 0}")
+        lines.append(f"l29raw {hx(a)}")
+        want.append(f"{hx(a)} 1")
+        lines.append(f"l29sqr {hx(a)}")
+        want.append(f"{hx(a * a % bn.P)} {hx(4 * a * a % bn.P)}")
+    for a in vals[1:24]:
+        lines.append(f"l29inv {hx(a)}")
+        want.append(hx(pow(a, bn.P - 2, bn.P)))
+    for _ in range(12):
+        a = (rng.randrange(bn.P), rng.randrange(bn.P))
+        b = (rng.randrange(bn.P), rng.randrange(bn.P))
+        lines.append(f"l29x2mul {hx(a[0])} {hx(a[1])} {hx(b[0])} {hx(b[1])}")
+        want.append(" ".join(hx(v) for v in bn.Fp2.mul(a, b) + bn.Fp2.mul(a, a) + bn.Fp2.inv(a)))
+    assert harness(lines) == want
+
+
+@pytest.mark.parametrize("which", ["g1", "g2", "h1", "h2"])
 def test_bn256_curve_ops(harness, which):
-    E, G = (bn.E1, bn.G1) if which == "g1" else (bn.E2, bn.G2)
+    E, G = (bn.E1, bn.G1) if which in ("g1", "h1") else (bn.E2, bn.G2)       # h1 / h2: the same curves over fp29.h
     rng = random.Random(7)
     pts = [E.mul(rng.randrange(1, bn.N), G) for _ in range(5)]
     lines, want = [], []

@@ -63,12 +63,12 @@ static int bn_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, si
 
 extern "C" int vmpc_bn256_g1_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, size_t n,
                                      void *out_affine) {
-    return bn_msm_dev<G1, Fp1Ops>(ctx, scalars, points, n, out_affine, "g1");
+    return bn_msm_dev<G1, BnF1>(ctx, scalars, points, n, out_affine, "g1");
 }
 
 extern "C" int vmpc_bn256_g2_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *points, size_t n,
                                      void *out_affine) {
-    return bn_msm_dev<G2, Fp2Ops>(ctx, scalars, points, n, out_affine, "g2");
+    return bn_msm_dev<G2, BnF2>(ctx, scalars, points, n, out_affine, "g2");
 }
 
 // ---- fixed-base tables (the evaluation key of a circuit is fixed: pynocchio.py:228-246 reads the
@@ -121,15 +121,15 @@ extern "C" int vmpc_bn256_table_bytes(int group, size_t n, size_t *bytes) {
 }
 
 extern "C" int vmpc_bn256_table_build_dev(vmpc_ctx *ctx, int group, const void *points, size_t n, void *table) {
-    if (group == 1) return bn_table_build_dev<G1, Fp1Ops>(ctx, points, n, table);
-    if (group == 2) return bn_table_build_dev<G2, Fp2Ops>(ctx, points, n, table);
+    if (group == 1) return bn_table_build_dev<G1, BnF1>(ctx, points, n, table);
+    if (group == 2) return bn_table_build_dev<G2, BnF2>(ctx, points, n, table);
     return VMPC_E_INVAL;
 }
 
 extern "C" int vmpc_bn256_table_msm_dev(vmpc_ctx *ctx, int group, const void *table, size_t table_n,
                                         const void *scalars, size_t m, void *out_affine, void *out_jacobian) {
-    if (group == 1) return bn_table_msm_dev<G1, Fp1Ops>(ctx, table, table_n, scalars, m, out_affine, out_jacobian);
-    if (group == 2) return bn_table_msm_dev<G2, Fp2Ops>(ctx, table, table_n, scalars, m, out_affine, out_jacobian);
+    if (group == 1) return bn_table_msm_dev<G1, BnF1>(ctx, table, table_n, scalars, m, out_affine, out_jacobian);
+    if (group == 2) return bn_table_msm_dev<G2, BnF2>(ctx, table, table_n, scalars, m, out_affine, out_jacobian);
     return VMPC_E_INVAL;
 }
 
@@ -141,8 +141,8 @@ extern "C" int vmpc_bn256_validate_dev(vmpc_ctx *ctx, int group, const void *poi
     unsigned long long *d_bad = (unsigned long long *)vmpc_ws_take(ctx, 8);
     VMPC_HIP_CHECK(hipMemsetAsync(d_bad, 0, 8, ctx->stream));
     if (n)
-        VMPC_CHECK(group == 1 ? (bn_kernels<G1, Fp1Ops>::validate(ctx, points, n, d_bad))
-                              : (bn_kernels<G2, Fp2Ops>::validate(ctx, points, n, d_bad)));
+        VMPC_CHECK(group == 1 ? (bn_kernels<G1, BnF1>::validate(ctx, points, n, d_bad))
+                              : (bn_kernels<G2, BnF2>::validate(ctx, points, n, d_bad)));
     unsigned long long h = 0;
     VMPC_HIP_CHECK(hipMemcpyAsync(&h, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -161,8 +161,8 @@ extern "C" int vmpc_bn256_fixed_base_dev(vmpc_ctx *ctx, int group, const void *b
     if (n == 0) return VMPC_OK;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     vmpc_stage_scope s(ctx, "bn_fixed_base");
-    return group == 1 ? bn_kernels<G1, Fp1Ops>::fixed_base(ctx, base_affine, scalars, n, out_affine)
-                      : bn_kernels<G2, Fp2Ops>::fixed_base(ctx, base_affine, scalars, n, out_affine);
+    return group == 1 ? bn_kernels<G1, BnF1>::fixed_base(ctx, base_affine, scalars, n, out_affine)
+                      : bn_kernels<G2, BnF2>::fixed_base(ctx, base_affine, scalars, n, out_affine);
 }
 
 // ---- host-buffer one-shots -------------------------------------------------------------------------

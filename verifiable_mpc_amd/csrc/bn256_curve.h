@@ -1,7 +1,8 @@
 // The curve half of the BN-256 MSM kernels as a policy type (csrc/bn256.hip, csrc/bn256_probe.hip): entries are
-// affine points in Montgomery form, accumulators Jacobian; F = Fp1Ops (G1) or Fp2Ops (the sextic twist), sw256.h.
+// affine points in Montgomery form, accumulators Jacobian; F = BnF1 (G1) or BnF2 (the sextic twist): fp29.h.
 #pragma once
 #include "sw256.h"
+#include "fp29.h"
 
 template <class F>
 struct SwCurve {
@@ -40,5 +41,8 @@ struct SwCurve {
         return jac_madd<F>(a, e);
     }
 };
-typedef SwCurve<Fp1Ops> G1;
-typedef SwCurve<Fp2Ops> G2;
+// the fields the device kernels compute in (fp29.h)
+typedef Fp29Ops BnF1;
+typedef Fp29x2Ops BnF2;
+typedef SwCurve<BnF1> G1;
+typedef SwCurve<BnF2> G2;

@@ -1,4 +1,4 @@
 // BN-256 twist (F_p^2): bucket reduction
 #include "bn256_impl.h"
 
-template int bn_kernels<G2, Fp2Ops>::reduce(vmpc_ctx *, const msm_plan &, msm_ws &);
+template int bn_kernels<G2, BnF2>::reduce(vmpc_ctx *, const msm_plan &, msm_ws &);

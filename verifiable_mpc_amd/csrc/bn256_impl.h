@@ -9,15 +9,14 @@
 #include "sw256.h"
 #include "bn256_curve.h"
 
-#define BN_B3_MONT                                                                             \
-    { 0x29d50ffdu, 0x8630a1e2u, 0x5c7373e9u, 0x583653eau, 0x1867b356u, 0xabd06066u, 0x8ace581fu,  \
-      0x3176f68fu }
-#define BN_B2A_MONT                                                                            \
-    { 0xb4c5ee14u, 0xb94f760fu, 0x4c3b6eb4u, 0xdae9f8f2u, 0xe52f4fe4u, 0x77a675d2u, 0x9116c66bu,  \
-      0x736f31b0u }
-#define BN_B2B_MONT                                                                            \
-    { 0x386b8d71u, 0x75046774u, 0x46d36cf8u, 0x5bd0854au, 0xd41c8414u, 0x664327a1u, 0x932eeb2fu,  \
-      0x096c9abbu }
+// twist constant b' = 3 / xi, xi = i + 3 (oracle/bn256_ref.py; verifiable_mpc/ac20/pairing.py:44-51): canonical
+// residues of its two coordinates, little-endian words
+#define BN_B2A_CANON                                                                           \
+    { 0xdb6c6949u, 0x7774124bu, 0x96e598bbu, 0x5a0cdfc5u, 0x111033b1u, 0x90e7f281u, 0x1aa5abfbu,  \
+      0x64984e1fu }
+#define BN_B2B_CANON                                                                           \
+    { 0xd6340f0au, 0x35a2de0au, 0x83455ef6u, 0x316f8daeu, 0x7026e2d0u, 0x5dd7fe12u, 0xbaa9f3ffu,  \
+      0x0e5ee696u }
 static const msm_modulus BN_ORDER = {{0x57ac7261u, 0x1a2ef45bu, 0xf82b3924u, 0x2e8d8e12u, 0x6184dc21u,
                                       0xaa6fecb8u, 0x4aa387f9u, 0x8fb501e3u}};
 
@@ -330,16 +329,17 @@ int bn_kernels<C, F>::fixed_base(vmpc_ctx *ctx, const void *base_affine, const v
     return VMPC_OK;
 }
 
-// the curve constant b (3 for G1, 3 / (9 + i) for the twist) in Montgomery form
-inline fp bn_curve_b(const Fp1Ops *) {
-    fp b = {BN_B3_MONT};
-    return b;
+// the curve constant b (3 for G1, 3 / (i + 3) for the twist) in the field's Montgomery form, from its canonical value
+inline fp29 bn_curve_b(const BnF1 *) {
+    const uint32_t three[8] = {3, 0, 0, 0, 0, 0, 0, 0};
+    return BnF1::load(three);
 }
-inline fp2 bn_curve_b(const Fp2Ops *) {
-    fp2 b;
-    fp ba = {BN_B2A_MONT}, bb = {BN_B2B_MONT};
-    b.a = ba;
-    b.b = bb;
+inline fp29x2 bn_curve_b(const BnF2 *) {
+    // b' = 3 / (i + 3)
+    const uint32_t ba[8] = BN_B2A_CANON, bb[8] = BN_B2B_CANON;
+    fp29x2 b;
+    b.a = BnF1::load(ba);
+    b.b = BnF1::load(bb);
     return b;
 }
 
@@ -352,5 +352,5 @@ int bn_kernels<C, F>::validate(vmpc_ctx *ctx, const void *points, size_t n, unsi
 }
 
 // instantiated in bn256_g1.hip / bn256_g2_*.hip
-extern template struct bn_kernels<G1, Fp1Ops>;
-extern template struct bn_kernels<G2, Fp2Ops>;
+extern template struct bn_kernels<G1, BnF1>;
+extern template struct bn_kernels<G2, BnF2>;

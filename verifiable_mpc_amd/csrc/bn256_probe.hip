@@ -59,7 +59,7 @@ static int bn_madd_rate(vmpc_ctx *ctx, int iters, double *rate) {
 
 extern "C" int vmpc_bn256_madd_rate(vmpc_ctx *ctx, int group, int iters, double *madds_per_second) {
     if (!ctx || !madds_per_second || iters < 1 || (group != 1 && group != 2)) return VMPC_E_INVAL;
-    return group == 1 ? bn_madd_rate<G1, Fp1Ops>(ctx, iters, madds_per_second)
-                      : bn_madd_rate<G2, Fp2Ops>(ctx, iters, madds_per_second);
+    return group == 1 ? bn_madd_rate<G1, BnF1>(ctx, iters, madds_per_second)
+                      : bn_madd_rate<G2, BnF2>(ctx, iters, madds_per_second);
 }
 

@@ -18,6 +18,8 @@
 // HBM traffic is dominated by the 96-B niels gathers (W per term) and the 4-B sorted
 // indices; the algorithmic bytes of SURVEY.md 8d are 96 B per term (32 B scalar + 64 B
 // point).  Arithmetic is 32x32->64 integer multiply-add; no MFMA.
+#include <stdlib.h>
+
 #include "common.h"
 #include "fe25519.h"
 #include "fr.h"
@@ -95,6 +97,12 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
     // fixed-base table: not worth carrying loads the compiler cannot see.  Staging the gather through LDS with
     // LDS-DMA (global_load_lds_dwordx4 into a [piece][lane] stage, no VGPR cost) measured 1.07 ms.
     // Initialising the accumulator from the first term (1M instead of 7M) lost to register pressure.
+    // Round 4 settled what the kernel is bound by (profiles/r04_probes/bucket_prefetch_and_occupancy.txt): a variant with
+    // the next entry REALLY prefetched (the eight loads as inline assembly between sched_barriers right after the third
+    // multiplication, awaited after the seventh: 157 VGPRs, three waves) and a variant that touches the next line
+    // early both take the same 660 us as this kernel; confined to 3 / 2 / 1 workgroups per CU all of them take 735 /
+    // 760-770 / 880 us, with or without prefetch.  It is bound by vector-ALU issue, not by the gather's latency:
+    // one wave per SIMD already issues 75 % of what four do.
     uint32_t ev[MSM_IDX_BATCH];
 #pragma unroll
     for (int k = 0; k < MSM_IDX_BATCH; k++) ev[k] = sorted[lo + ((uint32_t)k < len ? (uint32_t)k : len - 1)];
