@@ -596,6 +596,23 @@ def self_launch(args, argv):
             sk.bind(("127.0.0.1", 0))
             return sk.getsockname()[1]
 
+    live = []
+
+    def forward(signum, _frame):
+        # the launcher is being stopped: take the ranks (own process groups) along, then go
+        for pr in list(live):
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except Exception:
+                    pr.kill()
+        os._exit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            signal.signal(sg, forward)
+        except Exception:
+            pass
+
     def attempt(extra):
         env0 = dict(os.environ)
         env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
@@ -606,6 +623,7 @@ def self_launch(args, argv):
             env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + extra, env=env,
                                           stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True))
+            live.append(procs[-1])
 
         def pump(r, pr):
             for ln in pr.stdout:
