@@ -753,6 +753,8 @@ def main():
 
     def enter(stage):
         state["stage"], state["since"] = stage, time.time()
+        if world > 1:            # a multi-rank run that stalls should say where, in the launcher's log
+            print(f"[bench rank {rank}] +{time.time() - t_start:6.1f} s  {stage}", file=sys.stderr, flush=True)
     state["since"] = t_start
 
     def give_up(why):
