@@ -74,6 +74,8 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
     if (rc && atoi(rc) >= 256 && atoi(rc) <= 32768) c->reduce_max_chunks = atoi(rc);
     const char *ro = vmpc_getenv_experimental("VMPC_REDUCE_CHUNKS");
     if (ro && atoi(ro) >= 64 && atoi(ro) <= 32768 && (atoi(ro) & (atoi(ro) - 1)) == 0) c->reduce_chunks_override = atoi(ro);
+    const char *rt = vmpc_getenv_experimental("VMPC_REDUCE_TREE");
+    if (rt) c->reduce_tree = atoi(rt) != 0;
     const char *ss = vmpc_getenv_experimental("VMPC_SEG_SHIFT_MIN");
     if (ss && atoi(ss) <= 0 && atoi(ss) >= -5) c->seg_shift_min = atoi(ss);
     *out = c;

@@ -53,6 +53,8 @@ struct vmpc_ctx {
     int bucket_wgs_per_cu = 0;     // > 0: persistent bucket kernel with this many 256-thread workgroups per CU
     int reduce_max_chunks = 32768; // most chunk-lanes per bucket set in the bucket reduction (msm_sort.hip)
     int reduce_chunks_override = 0; // > 0: chunk-lanes per bucket set, fixed (power of two)
+    int reduce_tree = 1;           // short chunks: weights from the quad tree (msm_reduce_tree.hip), not per-lane ladders
+    bool reduce_tree_ready = false; // its kernels' dynamic-LDS limits are set on this context's device
     int seg_shift_min = -3;        // shortest bucket segments the plan may choose: 64 >> 3 entries (msm_sort.hip)
     int sort_fine_bits = -1;       // fine bits of the two-level bucket sort; -1 = automatic (msm_sort.hip)
     int plan_fill_shift = 0;       // the next plan's digit rows are only 1 / 2^shift populated (the A_i, B_i pair of a

@@ -450,15 +450,21 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
                                                                     w.buckets);
         VMPC_KERNEL_CHECK();
     }
+    // short chunks (latency path: one commitment alone, the prover's rounds): weights from the quad tree
+    const bool tree = ctx->reduce_tree && msm_reduce_tree_fits(p);
     {
         vmpc_stage_scope s(ctx, "msm_reduce");
-        k_msm_reduce<<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, st>>>(
-            w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, msm_ilog2(p.chunk_len), p.red_blocks, w.partials);
-        VMPC_KERNEL_CHECK();
+        if (tree) {
+            VMPC_CHECK(msm_reduce_tree(ctx, p, w, st));
+        } else {
+            k_msm_reduce<<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, st>>>(
+                w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, msm_ilog2(p.chunk_len), p.red_blocks, w.partials);
+            VMPC_KERNEL_CHECK();
+        }
     }
     {
         vmpc_stage_scope s(ctx, "msm_final");
-        k_msm_final<<<batch, 64, 0, st>>>(w.partials, p.period, p.red_blocks, p.c, (uint32_t *)out_ext,
+        k_msm_final<<<batch, 64, 0, st>>>(w.partials, p.period, tree ? 1 : p.red_blocks, p.c, (uint32_t *)out_ext,
                                           (uint32_t *)out_affine);
         VMPC_KERNEL_CHECK();
     }

@@ -46,7 +46,7 @@ struct msm_ws {
     uint32_t *stage1;       // entries partitioned by (window, coarse bin)
     uint32_t *counts, *starts, *sorted;
     uint32_t *buckets;      // W * nb accumulators, acc_bytes each
-    uint32_t *partials;     // W * red_blocks accumulators
+    uint32_t *partials;     // W * red_blocks accumulators (msm_reduce_tree: W window sums, then 3 W red_blocks)
     uint32_t *nseg, *seg_starts, *block_hist, *block_base, *heavy_list, *ctrl;
     uint32_t *seg_partial;  // per-segment partial sums, acc_bytes each
     uint2 *tasks;
@@ -66,6 +66,9 @@ void msm_make_plan(vmpc_ctx *ctx, size_t n_main, size_t n_extra, int scalar_bits
                    const msm_modulus *modulus = nullptr);
 void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p);   // from (n_total, c, W) already set
 void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, size_t acc_bytes);
+// Ed25519 bucket reduction through the quad tree (msm_reduce_tree.hip): W window sums at w.partials
+bool msm_reduce_tree_fits(const msm_plan &p);
+int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st);
 // recode -> hist1 -> scan -> part1 -> fine -> plan: fills digits, sorted, starts, counts, nseg,
 // seg_starts, heavy_list, tasks, ctrl[0] = #split buckets, ctrl[1] = #tasks
 int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scalars, size_t n,

@@ -689,7 +689,7 @@ void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, si
     w.stage1 = (uint32_t *)take((size_t)p.W * p.n_total * 4);
     w.sorted = (uint32_t *)take((size_t)p.W * p.n_total * 4);
     w.buckets = (uint32_t *)take((size_t)p.W * p.nb * acc_bytes);
-    w.partials = (uint32_t *)take((size_t)p.W * p.red_blocks * acc_bytes);
+    w.partials = (uint32_t *)take((size_t)p.W * (3 * p.red_blocks + 1) * acc_bytes);     // msm_sort.h
     // segment planning: at most M/SEG full segments plus one remainder per non-empty bucket
     size_t m_max = (size_t)p.W * p.n_total;
     size_t nonempty_max = m_max < (size_t)p.W * p.nb ? m_max : (size_t)p.W * p.nb;
