@@ -112,8 +112,11 @@ __device__ __forceinline__ void rt_tree(uint32_t *TA, uint32_t *US, uint32_t *EX
 }
 
 // workgroup (g, w): chunks 256 g .. 256 g + 255 of window w; out3[(w G + g) 3 + {0, 1, 2}] = U_g, Rw_g, D_g
-template <bool HAS_U>
-__global__ void __launch_bounds__(RT_THREADS)
+// Chunk sums: L <= 2 - a quad per chunk (1024 threads); longer chunks - a LANE per chunk (LANE_P1: the running sums
+// are throughput, four waves of lanes do 2 L additions of 9 multiplications where sixteen waves of quads would do
+// them at 12), in a workgroup of 512 threads so that the lane form has its 256 registers.
+template <bool HAS_U, bool LANE_P1>
+__global__ void __launch_bounds__(LANE_P1 ? RT_THREADS / 2 : RT_THREADS)
 k_msm_reduce_tree(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ counts, int nb, int G, int L,
                   uint32_t *__restrict__ out3) {
     extern __shared__ __align__(16) uint32_t rt_lds[];
@@ -122,15 +125,43 @@ k_msm_reduce_tree(const uint32_t *__restrict__ buckets, const uint32_t *__restri
     uint32_t *DD = RR + (RT_LEAVES / 2) * EXT_WORDS;
     uint32_t *US = DD + (RT_LEAVES / 2) * EXT_WORDS;             // only with HAS_U
     const int w = blockIdx.y, g = blockIdx.x;
-    const int t = threadIdx.x >> 2, q = threadIdx.x & 3;
-    {
+    if (LANE_P1) {
+        if (threadIdx.x < RT_LEAVES) {
+            const int t = threadIdx.x;
+            const int lo = (RT_LEAVES * g + t) * L;
+            const uint32_t *bw = buckets + EXT_WORDS * ((size_t)w * nb + lo);
+            const uint32_t *cw = counts + (size_t)w * (nb + 1) + lo + 1;
+            ge_ext acc = ge_ext_identity(), sum = ge_ext_identity();
+            bool have = false;
+            for (int j = L - 1; j >= 0; j--) {
+                if (cw[j]) {
+                    const ge_ext B = ext_ld(bw + EXT_WORDS * j);
+                    acc = have ? ge_add(acc, B) : B;
+                    have = true;
+                }
+                if (j == L - 1) sum = acc;
+                else if (have) sum = ge_add(sum, acc);
+            }
+            ext_st(TA + EXT_WORDS * t, acc);
+            if (HAS_U) ext_st(US + EXT_WORDS * t, sum);
+        }
+    } else {
+        const int t = threadIdx.x >> 2, q = threadIdx.x & 3;
         const int lo = (RT_LEAVES * g + t) * L;                  // 0-based bucket index; bucket value = index + 1
         const uint32_t *bw = buckets + EXT_WORDS * ((size_t)w * nb + lo);
         const uint32_t *cw = counts + (size_t)w * (nb + 1) + lo + 1;   // empty buckets are never written
-        fe acc = rt_identity(q), sum = rt_identity(q);
+        fe acc = rt_identity(q), sum = acc;
+        bool have = false;                                       // quad-uniform, like every condition below
         for (int j = L - 1; j >= 0; j--) {
-            if (cw[j]) acc = rt_add(acc, fe_ld(bw + EXT_WORDS * j + FE_LIMBS * q), q);      // quad-uniform
-            if (HAS_U) sum = rt_add(sum, acc, q);
+            if (cw[j]) {
+                const fe B = fe_ld(bw + EXT_WORDS * j + FE_LIMBS * q);
+                acc = have ? rt_add(acc, B, q) : B;
+                have = true;
+            }
+            if (HAS_U) {
+                if (j == L - 1) sum = acc;
+                else if (have) sum = rt_add(sum, acc, q);
+            }
         }
         rt_st(TA, t, q, acc);
         if (HAS_U) rt_st(US, t, q, sum);
@@ -184,19 +215,23 @@ int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st)
     const size_t lds_a1 = (size_t)(RT_LEAVES * 2) * EXT_WORDS * 4, lds_aU = (size_t)(RT_LEAVES * 3) * EXT_WORDS * 4;
     const size_t lds_b = (size_t)(4 * G + 1) * EXT_WORDS * 4;
     if (!ctx->reduce_tree_ready) {
-        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_reduce_tree<false>,
+        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_reduce_tree<false, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a1));
-        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_reduce_tree<true>,
+        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_reduce_tree<true, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_aU));
+        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_reduce_tree<true, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_aU));
         VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_reduce_combine,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 * 128 + 1) * EXT_WORDS * 4)));
         ctx->reduce_tree_ready = true;
     }
     uint32_t *triples = w.partials + (size_t)EXT_WORDS * p.W;
-    if (L > 1)
-        k_msm_reduce_tree<true><<<dim3(G, p.W), RT_THREADS, lds_aU, st>>>(w.buckets, w.counts, p.nb, G, L, triples);
+    if (L > 2)
+        k_msm_reduce_tree<true, true><<<dim3(G, p.W), RT_THREADS / 2, lds_aU, st>>>(w.buckets, w.counts, p.nb, G, L, triples);
+    else if (L > 1)
+        k_msm_reduce_tree<true, false><<<dim3(G, p.W), RT_THREADS, lds_aU, st>>>(w.buckets, w.counts, p.nb, G, L, triples);
     else
-        k_msm_reduce_tree<false><<<dim3(G, p.W), RT_THREADS, lds_a1, st>>>(w.buckets, w.counts, p.nb, G, L, triples);
+        k_msm_reduce_tree<false, false><<<dim3(G, p.W), RT_THREADS, lds_a1, st>>>(w.buckets, w.counts, p.nb, G, L, triples);
     VMPC_KERNEL_CHECK();
     k_msm_reduce_combine<<<p.W, RT_THREADS, lds_b, st>>>(triples, G, msm_ilog2(L), w.partials);
     VMPC_KERNEL_CHECK();
