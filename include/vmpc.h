@@ -229,6 +229,11 @@ int vmpc_affine_to_proj_dev(vmpc_ctx *ctx, const void *affine, size_t n, void *o
 int vmpc_fr_axpy_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *x, const void *y, size_t n,
                      void *out);
 int vmpc_fr_scale_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *x, size_t n, void *out);
+/* out[0..n) = c * x + y (y == NULL: c * x), out[n] = tail: z_hat = (c0 * x + r) || phi and L~ = c1 * (L || 0)
+ * (compressed_pivot.py:134-141) in one pass each, without a copy to append the scalar.  c, tail: canonical
+ * residues (VMPC_E_NONCANON otherwise); out: n + 1 elements. */
+int vmpc_fr_axpy_tail_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *x, const void *y, size_t n,
+                          const uint8_t tail[32], void *out);
 /* out[j] = z[j mod 2^low_bits] * prod_{i < rounds} (c_i if bit (low_bits+rounds-1-i) of j is 0
  * else 1), n = 2^(rounds+low_bits) <= 2^40, rounds <= 20; challenges = rounds x 32 bytes (host).
  * These are the coefficients of `rounds` applications of the fold of compressed_pivot.py:64

@@ -16,6 +16,7 @@
 #include "../../verifiable_mpc_amd/csrc/fmt.h"
 #include "../../verifiable_mpc_amd/csrc/sw256.h"
 #include "../../verifiable_mpc_amd/csrc/fp29.h"
+#include "../../verifiable_mpc_amd/csrc/fe51_host.h"
 
 static void parse_hex(const std::string &h, uint32_t *out, int limbs) {
     for (int i = 0; i < limbs; i++) out[i] = 0;
@@ -162,7 +163,18 @@ int main() {
         std::istringstream is(line);
         std::string cmd;
         is >> cmd;
-        if (cmd == "femul") {
+        if (cmd == "h51mul" || cmd == "h51inv") {
+            // the host-only 51-bit-limb field (fe51_host.h): bytes in, canonical bytes out
+            uint32_t wa[8], wb[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+            rd_raw8(is, wa);
+            if (cmd == "h51mul") rd_raw8(is, wb);
+            const fe51::el a = fe51::from_bytes((const uint8_t *)wa), b = fe51::from_bytes((const uint8_t *)wb);
+            uint8_t out[32];
+            fe51::to_bytes(out, cmd == "h51mul" ? fe51::mul(a, b) : fe51::inv(a));
+            uint32_t wo[8];
+            memcpy(wo, out, 32);
+            std::cout << to_hex(wo, 8) << "\n";
+        } else if (cmd == "femul") {
             fe a = rd_fe(is), b = rd_fe(is);
             std::cout << fehex(fe_mul(a, b)) << "\n";
         } else if (cmd == "fesqr") {

@@ -75,6 +75,21 @@ def test_field_ops(harness):
     assert harness(lines) == want
 
 
+def test_host_51_bit_field(harness):
+    """fe51_host.h - the prover's per-round inversion on the host (prover.hip p4_affine_pair)"""
+    rng = random.Random(51)
+    vals = EDGE + [rng.getrandbits(256) for _ in range(100)]
+    lines, want = [], []
+    for a in vals:
+        b = rng.choice(vals)
+        lines.append(f"h51mul {hx(a)} {hx(b)}")
+        want.append(hx(a * b % P))
+        if a % P:
+            lines.append(f"h51inv {hx(a)}")
+            want.append(hx(pow(a, P - 2, P)))
+    assert harness(lines) == want
+
+
 def _limbs_value(limbs):
     return sum(v << ((51 * i + 1) // 2) for i, v in enumerate(limbs))
 

@@ -31,7 +31,7 @@ SYMBOLS = [
     "vmpc_ed25519_fixed_base_batch", "vmpc_fr_axpy", "vmpc_fr_dot", "vmpc_points_validate_dev",
     "vmpc_msm_dev", "vmpc_msm_table_bytes", "vmpc_msm_table_build_dev", "vmpc_msm_table_dev", "vmpc_msm_table_batch_dev", "vmpc_points_sum_dev", "vmpc_points_sum_many_dev", "vmpc_fixed_base_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
-    "vmpc_fr_scale_dev", "vmpc_fr_dot_dev", "vmpc_fr_dot_to_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
+    "vmpc_fr_scale_dev", "vmpc_fr_axpy_tail_dev", "vmpc_fr_dot_dev", "vmpc_fr_dot_to_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
     "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev", "vmpc_fr_tail_scalars_block_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
@@ -112,6 +112,7 @@ def load_library():
         "vmpc_affine_to_proj_dev": (i32, [vp, vp, sz, vp]),
         "vmpc_fr_axpy_dev": (i32, [vp, vp, vp, vp, sz, vp]),
         "vmpc_fr_scale_dev": (i32, [vp, vp, vp, sz, vp]),
+        "vmpc_fr_axpy_tail_dev": (i32, [vp, vp, vp, vp, sz, vp, vp]),
         "vmpc_fr_dot_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_fr_dot_to_dev": (i32, [vp, vp, vp, sz, vp]),
         "vmpc_format_points_dev": (i32, [vp, vp, sz, vp, sz, u64p]),
@@ -596,6 +597,13 @@ class Context:
         _check(self.lib.vmpc_fr_axpy_dev(self.handle, cb, ctypes.c_void_p(x_ptr),
                                          ctypes.c_void_p(y_ptr), n, ctypes.c_void_p(out_ptr)),
                "vmpc_fr_axpy_dev")
+
+    def fr_axpy_tail(self, c, x_ptr, y_ptr, n, tail, out_ptr):
+        """out[0..n) = c * x + y (y_ptr None: c * x), out[n] = tail"""
+        cb = ctypes.create_string_buffer(scalar_to_bytes(c), 32)
+        tb = ctypes.create_string_buffer(scalar_to_bytes(tail), 32)
+        _check(self.lib.vmpc_fr_axpy_tail_dev(self.handle, cb, ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), n, tb,
+                                              ctypes.c_void_p(out_ptr)), "vmpc_fr_axpy_tail_dev")
 
     def fr_scale(self, c, x_ptr, n, out_ptr):
         cb = ctypes.create_string_buffer(scalar_to_bytes(c), 32)

@@ -562,7 +562,7 @@ class _LazyQ:
 def _extend_form(L, c1):
     """L~ = (L.coeffs || 0) * c1 (compressed_pivot.py:141)."""
     if isinstance(L.coeffs, ScalarVector):
-        return pivot.LinearForm(L.coeffs.concat([0]).scale(c1))
+        return pivot.LinearForm(L.coeffs.axpy_concat(c1, None, 0))
     return pivot.LinearForm(L.coeffs + [0]) * c1
 
 
@@ -624,12 +624,13 @@ def protocol_5_prover(generators, P, L, y, x, gamma, gf, transcript=None, r=None
     c0, c1, seed = _p5_challenges(mode, order, gens_for_hash, t, A, P, L, y)
     logger_cp_hout.debug(f"After hash, hash=\n{c0}, {c1}")
 
+    phi = gf(c0 * gamma + rho)
     if device_mode:
-        z = x.axpy(c0, r)
+        z_hat = x.axpy_concat(c0, r, phi)          # z and its extension in one pass
+        z = z_hat[:n]
     else:
         z = [c0 * x_i + r[i] for i, x_i in enumerate(x)]
-    phi = gf(c0 * gamma + rho)
-    z_hat = z + [phi]
+        z_hat = z + [phi]
     g_hat = gv + [h]
     logger_cp.debug("Calculate Q.")
     Q = _LazyQ(A, P, k, c0, int(c1 * (c0 * y + t)), order)

@@ -53,7 +53,9 @@ k_fold_jump(const uint32_t *__restrict__ table, size_t stride, size_t m_out, int
     const uint32_t *sc = sched + (size_t)o * e1;
     const uint32_t cnt = sc[0];
     const uint32_t *col = table + NIELS_WORDS * j;
-    uint32_t *slot = partial + EXT_WORDS * ((j * (size_t)O + o) * S + share);
+    const size_t slot_i = (j * (size_t)O + o) * S + share;
+    uint32_t *slot = partial + EXT_WORDS * slot_i;
+    uint32_t *park = partial + EXT_WORDS * (m_out * (size_t)O * S + slot_i);   // where `run` waits during a step down
     ge_ext run = ge_ext_identity();
     ext_st(slot, run);
     bool have = false;
@@ -62,8 +64,15 @@ k_fold_jump(const uint32_t *__restrict__ table, size_t stride, size_t m_out, int
         const uint32_t ent = sc[1 + e];
         const uint32_t v = ent >> 16;
         if (cur > v) {                  // entries of |digit| >= cur are all in `run`: it counts once per level
-            if (have)
-                for (; cur > v; cur--) ext_st(slot, ge_add(ext_ld(slot), run));
+            if (have) {
+                // the addition of two extended points does not fit beside a live `run` and a table entry in 128
+                // registers (193 spilled, the loop below included): `run` goes to memory by hand, here only
+                ext_st(park, run);
+                asm volatile("" ::: "memory");
+                for (; cur > v; cur--) ext_st(slot, ge_add(ext_ld(slot), ext_ld(park)));
+                asm volatile("" ::: "memory");
+                run = ext_ld(park);
+            }
             cur = v;
         }
         if (e == cnt) break;
@@ -197,8 +206,10 @@ static int table_fold(vmpc_ctx *ctx, const void *table, size_t table_n, size_t t
     const size_t sched_bytes = (sched.size() * 4 + 255) & ~(size_t)255;
     // short vectors: S lanes share an (output, offset) schedule so that up to 2^17 lanes are at work
     int S = 1;
+    // (2^16 / 2^17 / 2^18 lanes: 4.03 / 4.04 / 4.02 ms for the fold of a 2^20-generator proof, 2^19: 4.40 - the pass
+    // is bound by its 8 GB of table reads, 64 x 128 bytes per generator, not by the lanes at work)
     while (S < 16 && m_out * (size_t)O * S * 2 <= ((size_t)1 << 17) && rows * B / (S * 2) >= 8) S *= 2;
-    const size_t partial_bytes = m_out * (size_t)O * S * EXT_WORDS * 4;
+    const size_t partial_bytes = 2 * m_out * (size_t)O * S * EXT_WORDS * 4;      // slots, then k_fold_jump's parking
     const size_t proj_bytes = (m_out * 96 + 255) & ~(size_t)255;
     VMPC_CHECK(vmpc_ws_reserve(ctx, sched_bytes + partial_bytes + proj_bytes));
     char *ws = (char *)ctx->ws;

@@ -43,6 +43,28 @@ k_fr_axpy(fr_arg c, const uint32_t *__restrict__ x, const uint32_t *__restrict__
     }
 }
 
+// the same with one more element behind the n results (z_hat = (c0 x + r) || phi, L~ = c1 (L || 0):
+// compressed_pivot.py:134-141) - no copy of the vector to append a scalar
+__global__ void __launch_bounds__(FR_BLOCK)
+k_fr_axpy_tail(fr_arg c, const uint32_t *__restrict__ x, const uint32_t *__restrict__ y, size_t n, fr_arg tail,
+               uint32_t *__restrict__ out) {
+    fr cc;
+#pragma unroll
+    for (int i = 0; i < 8; i++) cc.v[i] = c.v[i];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        fr r = fr_mul(cc, frv_ld(x + 8 * i));
+        if (y) r = fr_add(r, frv_ld(y + 8 * i));
+        frv_st(out + 8 * i, r);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        fr t;
+#pragma unroll
+        for (int i = 0; i < 8; i++) t.v[i] = tail.v[i];
+        frv_st(out + 8 * n, t);
+    }
+}
+
 __global__ void __launch_bounds__(FR_BLOCK)
 k_fr_dot(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t n,
          uint32_t *__restrict__ partials) {
@@ -196,6 +218,20 @@ extern "C" int vmpc_fr_axpy_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *
     vmpc_stage_scope s(ctx, "fr_axpy");
     k_fr_axpy<<<fr_grid(n), FR_BLOCK, 0, ctx->stream>>>(ca, (const uint32_t *)x, (const uint32_t *)y, n,
                                                         (uint32_t *)out);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_fr_axpy_tail_dev(vmpc_ctx *ctx, const uint8_t c[32], const void *x, const void *y, size_t n,
+                                     const uint8_t tail[32], void *out) {
+    if (!ctx || !c || !tail || !out || (n && !x)) return VMPC_E_INVAL;
+    fr_arg ca, ta;
+    VMPC_CHECK(fr_arg_from(c, ca));
+    VMPC_CHECK(fr_arg_from(tail, ta));
+    VMPC_HIP_CHECK(hipSetDevice(ctx->device));
+    vmpc_stage_scope s(ctx, "fr_axpy");
+    k_fr_axpy_tail<<<n ? fr_grid(n) : 1, FR_BLOCK, 0, ctx->stream>>>(ca, (const uint32_t *)x, (const uint32_t *)y, n, ta,
+                                                                      (uint32_t *)out);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }

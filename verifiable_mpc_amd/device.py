@@ -157,6 +157,15 @@ class ScalarVector:
         self.ctx.fr_axpy(reduce_scalar(c), self.ptr, y.ptr, len(self), out.ptr)
         return out
 
+    def axpy_concat(self, c, y, tail):
+        """(c * self + y) + [tail]  (y None: c * self) in one pass: z_hat = (c0 x + r) || phi,
+        L~ = (L || 0) * c1 (compressed_pivot.py:134-141)"""
+        assert y is None or len(y) == len(self)
+        out = ScalarVector.empty(len(self) + 1, self.ctx)
+        self.ctx.fr_axpy_tail(reduce_scalar(c), self.ptr, y.ptr if y is not None else None, len(self),
+                              reduce_scalar(tail), out.ptr)
+        return out
+
     def scale(self, c):
         out = ScalarVector.empty(len(self), self.ctx)
         self.ctx.fr_scale(reduce_scalar(c), self.ptr, len(self), out.ptr)
@@ -225,6 +234,8 @@ class PointVector:
 
     def __init__(self, affine_view, proj_view=None, ctx=None):
         self.ctx = ctx or get_context()
+        self._n = 0
+        self._a_make = None      # deferred affine array (concat of a tabulated vector: built if anybody reads it)
         self.a = affine_view
         self.p = proj_view
         self._digest = None
@@ -283,7 +294,19 @@ class PointVector:
 
     # ---- list protocol ----------------------------------------------------------------------
     def __len__(self):
-        return self.a.n
+        return self._n
+
+    @property
+    def a(self):
+        if self._a is None and self._a_make is not None:
+            self._a, self._a_make = self._a_make(), None
+        return self._a
+
+    @a.setter
+    def a(self, view):
+        self._a = view
+        if view is not None:
+            self._n = view.n
 
     @property
     def affine_ptr(self):
@@ -330,10 +353,18 @@ class PointVector:
     def concat(self, points):
         """self + [pt, ...] as a new vector (g_hat = g + [h], compressed_pivot.py:138)."""
         n, m = len(self), len(points)
-        abuf = self.ctx.alloc(64 * (n + m))
-        self.ctx.copy(abuf.ptr, self.a.ptr, 64 * n)
-        self.ctx.upload_into(abuf.ptr + 64 * n,
-                             np.frombuffer(b"".join(p.to_affine_bytes() for p in points), np.uint8))
+        t = self._table
+        tabulated = t is not None and self._table_tail == 0 and n == t.n and \
+            [p.to_affine_bytes() for p in points] == t.extra_bytes[:m]
+        src, ctx = self, self.ctx
+
+        def affine():
+            abuf = ctx.alloc(64 * (n + m))
+            ctx.copy(abuf.ptr, src.a.ptr, 64 * n)
+            ctx.upload_into(abuf.ptr + 64 * n,
+                            np.frombuffer(b"".join(p.to_affine_bytes() for p in points), np.uint8))
+            return _View(abuf, 0, n + m, 64)
+
         pv = None
         if self.p is not None:
             pbuf = self.ctx.alloc(96 * (n + m))
@@ -341,10 +372,14 @@ class PointVector:
             self.ctx.upload_into(pbuf.ptr + 96 * n,
                                  np.frombuffer(b"".join(p.to_proj_bytes() for p in points), np.uint8))
             pv = _View(pbuf, 0, n + m, 96)
-        out = PointVector(_View(abuf, 0, n + m, 64), pv, self.ctx)
-        t = self._table
-        if t is not None and self._table_tail == 0 and n == t.n and \
-                [p.to_affine_bytes() for p in points] == t.extra_bytes[:m]:
+        if tabulated and pv is None:
+            # g + [h] with h an extra of g's table: commitments over the result run on the table, so the 64-byte
+            # affine copy of 2^20 generators (64 MB moved per proof) waits until somebody reads the array
+            out = PointVector(None, None, self.ctx)
+            out._n, out._a_make = n + m, affine
+        else:
+            out = PointVector(affine(), pv, self.ctx)
+        if tabulated:
             out._table, out._table_tail = t, m      # g + [h]: h is extra 0 of g's table
         return out
 
