@@ -139,12 +139,17 @@ k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ so
 // e.g. the under-full top window) are summed by one lane each; heavily split ones (skewed
 // scalars) by a workgroup-wide LDS tree.
 
+// One launch for both: workgroups [0, gridDim.x / 2) sum the lightly split buckets, the other half the heavily split
+// ones (two launches cost a dispatch each, 5 us of the ~250 us of a late prover round).
 __global__ void __launch_bounds__(MSM_BLOCK)
-k_msm_bucket_finish_light(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ ctrl,
-                          const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
-                          const uint32_t *__restrict__ partial, int nb1, uint32_t *__restrict__ buckets) {
+k_msm_bucket_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ ctrl,
+                    const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
+                    const uint32_t *__restrict__ partial, int nb1, uint32_t *__restrict__ buckets) {
+    __shared__ uint32_t lds[MSM_BLOCK * EXT_WORDS];
+    const uint32_t half = gridDim.x / 2;
     const uint32_t n_heavy = ctrl[0];
-    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n_heavy; h += gridDim.x * blockDim.x) {
+    if (blockIdx.x < half) {
+    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n_heavy; h += half * blockDim.x) {
         uint32_t ci = heavy_list[h];
         uint32_t ns = nseg[ci];
         if (ns > MSM_FINISH_SERIAL) continue;
@@ -153,16 +158,10 @@ k_msm_bucket_finish_light(const uint32_t *__restrict__ heavy_list, const uint32_
         for (uint32_t j = 1; j < ns; j++) acc = ge_add(acc, ext_ld(src + EXT_WORDS * (size_t)j));
         ext_st(buckets + EXT_WORDS * msm_bucket_slot(ci, nb1), acc);
     }
-}
-
-__global__ void __launch_bounds__(MSM_BLOCK)
-k_msm_bucket_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ ctrl,
-                    const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
-                    const uint32_t *__restrict__ partial, int nb1, uint32_t *__restrict__ buckets) {
-    __shared__ uint32_t lds[MSM_BLOCK * EXT_WORDS];
+    return;
+    }
     if (ctrl[4] == 0) return;                      // no heavily split bucket: nothing for the workgroup trees
-    const uint32_t n_heavy = ctrl[0];
-    for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+    for (uint32_t h = blockIdx.x - half; h < n_heavy; h += half) {
         uint32_t ci = heavy_list[h];
         uint32_t ns = nseg[ci];
         if (ns <= MSM_FINISH_SERIAL) continue;          // wave-uniform: whole workgroup skips
@@ -442,10 +441,7 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
     }
     {
         vmpc_stage_scope s(ctx, "msm_bucket_finish");
-        k_msm_bucket_finish_light<<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(
-            w.heavy_list, w.ctrl, w.nseg, w.seg_starts, w.seg_partial, p.nb1, w.buckets);
-        VMPC_KERNEL_CHECK();
-        k_msm_bucket_finish<<<2 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg,
+        k_msm_bucket_finish<<<4 * ctx->cu_count, MSM_BLOCK, 0, st>>>(w.heavy_list, w.ctrl, w.nseg,
                                                                     w.seg_starts, w.seg_partial, p.nb1,
                                                                     w.buckets);
         VMPC_KERNEL_CHECK();

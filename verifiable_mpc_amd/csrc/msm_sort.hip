@@ -458,10 +458,9 @@ k_sort_fine_big(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gb
 // block_hist[block][class] (segments of that length in the block) -> the block's first rank among its
 // window's segments of that class, in place; the window's class totals go to ctrl[16 + class * W + w].
 // One workgroup per window: thread (class, group) walks NC / 16 consecutive blocks.
-__global__ void __launch_bounds__(1024)
-k_msm_ranks(uint32_t *__restrict__ block_hist, int NC, int W, uint32_t *__restrict__ ctrl) {
-    __shared__ uint32_t part[16][MSM_SEG];
-    const int w = blockIdx.x, cls = threadIdx.x % MSM_SEG, g = threadIdx.x / MSM_SEG;      // 16 groups
+__device__ __forceinline__ void msm_ranks_window(uint32_t *__restrict__ block_hist, int NC, int W, int w,
+                                                 uint32_t *__restrict__ ctrl, uint32_t (*part)[MSM_SEG]) {
+    const int cls = threadIdx.x % MSM_SEG, g = threadIdx.x / MSM_SEG;      // 16 groups
     const int per = (NC + 15) / 16, b0 = g * per, b1 = b0 + per < NC ? b0 + per : NC;
     uint32_t run = 0;
     for (int b = b0; b < b1; b++) run += block_hist[((size_t)w * NC + b) * MSM_SEG + cls];
@@ -484,11 +483,16 @@ k_msm_ranks(uint32_t *__restrict__ block_hist, int NC, int W, uint32_t *__restri
     if (g == 0) ctrl[16 + (MSM_SEG - 1 - cls) * W + w] = total;
 }
 
+__global__ void __launch_bounds__(1024)
+k_msm_ranks(uint32_t *__restrict__ block_hist, int NC, int W, uint32_t *__restrict__ ctrl) {
+    __shared__ uint32_t part[16][MSM_SEG];
+    msm_ranks_window(block_hist, NC, W, (int)blockIdx.x, ctrl, part);
+}
+
 // first task id of every (length class, window) cell: exclusive scan of the 64 x W totals in the order
 // longest class first, windows ascending - longest segments get the smallest task ids
-__global__ void __launch_bounds__(1024)
-k_msm_classes(uint32_t *__restrict__ ctrl, int W, uint32_t *__restrict__ class_base) {
-    __shared__ uint32_t scratch[16];
+__device__ __forceinline__ void msm_classes_body(uint32_t *__restrict__ ctrl, int W, uint32_t *__restrict__ class_base,
+                                                 uint32_t *scratch) {
     const int ncell = MSM_SEG * W;                  // <= 4096
     uint32_t running = 0;
     for (int k0 = 0; k0 < ncell; k0 += 1024) {
@@ -499,6 +503,26 @@ k_msm_classes(uint32_t *__restrict__ ctrl, int W, uint32_t *__restrict__ class_b
         running += tot;
     }
     if (threadIdx.x == 0) ctrl[1] = running;        // #tasks
+}
+
+__global__ void __launch_bounds__(1024)
+k_msm_classes(uint32_t *__restrict__ ctrl, int W, uint32_t *__restrict__ class_base) {
+    __shared__ uint32_t scratch[16];
+    msm_classes_body(ctrl, W, class_base, scratch);
+}
+
+// few windows (one commitment over a tabulated vector, a prover round's pair): both steps in one workgroup, the
+// windows one after the other - a launch less
+__global__ void __launch_bounds__(1024)
+k_msm_ranks_classes(uint32_t *__restrict__ block_hist, int NC, int W, uint32_t *__restrict__ ctrl,
+                    uint32_t *__restrict__ class_base) {
+    __shared__ uint32_t part[16][MSM_SEG];
+    __shared__ uint32_t scratch[16];
+    for (int w = 0; w < W; w++) {
+        msm_ranks_window(block_hist, NC, W, w, ctrl, part);
+        __syncthreads();
+    }
+    msm_classes_body(ctrl, W, class_base, scratch);
 }
 
 // plan, pass 2 (pass 1 is the tail of k_sort_fine): one block per (window, coarse bin), one thread per
@@ -802,10 +826,15 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
     }
     {
         vmpc_stage_scope s(ctx, "msm_plan");
-        k_msm_ranks<<<p.W, 1024, 0, st>>>(w.block_hist, p.NC, p.W, w.ctrl);
-        VMPC_KERNEL_CHECK();
-        k_msm_classes<<<1, 1024, 0, st>>>(w.ctrl, p.W, w.block_base);
-        VMPC_KERNEL_CHECK();
+        if (p.W <= 8) {
+            k_msm_ranks_classes<<<1, 1024, 0, st>>>(w.block_hist, p.NC, p.W, w.ctrl, w.block_base);
+            VMPC_KERNEL_CHECK();
+        } else {
+            k_msm_ranks<<<p.W, 1024, 0, st>>>(w.block_hist, p.NC, p.W, w.ctrl);
+            VMPC_KERNEL_CHECK();
+            k_msm_classes<<<1, 1024, 0, st>>>(w.ctrl, p.W, w.block_base);
+            VMPC_KERNEL_CHECK();
+        }
         k_msm_plan2<<<w.plan_blocks, 512, 0, st>>>(w.counts, p.NC, p.W, 1 << p.LB, p.top_row, p.period, 1 << p.LB_top,
                                                   p.nb1, p.seg_shift, p.balanced, w.block_base, w.block_hist, w.tasks);
         VMPC_KERNEL_CHECK();

@@ -70,6 +70,32 @@ k_scan_add(OutT *__restrict__ out, const OutT *__restrict__ tile_offsets, size_t
         if (base + i < n) out[base + i] += off;
 }
 
+// up to 16384 items in ONE workgroup of 1024 threads (the histogram of a short MSM: three launches for 8192
+// counters cost three dispatches)
+#define VMPC_SCAN_SMALL_MAX 16384
+template <typename InT, typename OutT>
+__global__ void __launch_bounds__(1024)
+k_scan_small(const InT *__restrict__ in, OutT *__restrict__ out, OutT *__restrict__ total_out, size_t n) {
+    __shared__ OutT lds[16];
+    const int per = (int)((n + 1023) / 1024);                  // <= 16 consecutive items per thread
+    const size_t base = (size_t)threadIdx.x * per;
+    OutT v[16];
+    OutT s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        v[i] = (i < per && base + i < n) ? (OutT)in[base + i] : (OutT)0;
+        s += v[i];
+    }
+    OutT tot;
+    OutT ex = vmpc_block_excl_scan<OutT>(s, &tot, lds);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i < per && base + i < n) out[base + i] = ex;
+        ex += v[i];
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = tot;
+}
+
 inline size_t vmpc_scan_ws_bytes(size_t n, size_t elem) {
     size_t total = 0;
     while (n > 1) {
@@ -93,6 +119,11 @@ int vmpc_exclusive_scan(hipStream_t stream, const InT *in, OutT *out, size_t n, 
     size_t tiles = (n + VMPC_SCAN_TILE - 1) / VMPC_SCAN_TILE;
     OutT *sums = (OutT *)ws;
     char *next_ws = (char *)ws + vmpc_align(tiles * sizeof(OutT));
+    if (tiles > 1 && n <= VMPC_SCAN_SMALL_MAX) {
+        k_scan_small<InT, OutT><<<1, 1024, 0, stream>>>(in, out, total_out, n);
+        VMPC_KERNEL_CHECK();
+        return VMPC_OK;
+    }
     if (tiles == 1) {
         k_scan_tiles<InT, OutT><<<1, VMPC_SCAN_THREADS, 0, stream>>>(in, out, total_out, n);
         VMPC_KERNEL_CHECK();

@@ -236,6 +236,7 @@ class PointVector:
         self.ctx = ctx or get_context()
         self._n = 0
         self._a_make = None      # deferred affine array (concat of a tabulated vector: built if anybody reads it)
+        self._p_make = None      # ... and the projective representatives, likewise
         self.a = affine_view
         self.p = proj_view
         self._digest = None
@@ -314,16 +315,26 @@ class PointVector:
 
     @property
     def proj_ptr(self):
-        return self.p.ptr if self.p is not None else None
+        return self.p.ptr if self.has_proj else None
 
     @property
     def has_proj(self):
-        return self.p is not None
+        return self._p is not None or self._p_make is not None
+
+    @property
+    def p(self):
+        if self._p is None and self._p_make is not None:
+            self._p, self._p_make = self._p_make(), None
+        return self._p
+
+    @p.setter
+    def p(self, view):
+        self._p = view
 
     def __getitem__(self, key):
         if isinstance(key, slice):
             a, b = _slice_bounds(key, self.a.n)
-            sub = PointVector(self.a.sub(a, b), self.p.sub(a, b) if self.p is not None else None,
+            sub = PointVector(self.a.sub(a, b), self.p.sub(a, b) if self.has_proj else None,
                               self.ctx)
             if a == 0 and self._table is not None:
                 sub._table = self._table       # a prefix addresses the same table rows
@@ -331,7 +342,7 @@ class PointVector:
             return sub
         if key < 0:
             key += self.a.n
-        if self.p is not None:
+        if self.has_proj:
             return Ed25519Point.from_proj_bytes(self.ctx.download(self.p.ptr + 96 * key, 96).tobytes())
         return Ed25519Point.from_affine_bytes(self.ctx.download(self.a.ptr + 64 * key, 64).tobytes())
 
@@ -341,7 +352,7 @@ class PointVector:
 
     def to_points(self):
         n = len(self)
-        if self.p is not None:
+        if self.has_proj:
             raw = self.ctx.download(self.p.ptr, 96 * n).tobytes()
             return [Ed25519Point.from_proj_bytes(raw[96 * i:96 * i + 96]) for i in range(n)]
         raw = self.ctx.download(self.a.ptr, 64 * n).tobytes()
@@ -365,20 +376,22 @@ class PointVector:
                             np.frombuffer(b"".join(p.to_affine_bytes() for p in points), np.uint8))
             return _View(abuf, 0, n + m, 64)
 
-        pv = None
-        if self.p is not None:
-            pbuf = self.ctx.alloc(96 * (n + m))
-            self.ctx.copy(pbuf.ptr, self.p.ptr, 96 * n)
-            self.ctx.upload_into(pbuf.ptr + 96 * n,
-                                 np.frombuffer(b"".join(p.to_proj_bytes() for p in points), np.uint8))
-            pv = _View(pbuf, 0, n + m, 96)
-        if tabulated and pv is None:
-            # g + [h] with h an extra of g's table: commitments over the result run on the table, so the 64-byte
-            # affine copy of 2^20 generators (64 MB moved per proof) waits until somebody reads the array
+        def proj():
+            pbuf = ctx.alloc(96 * (n + m))
+            ctx.copy(pbuf.ptr, src.p.ptr, 96 * n)
+            ctx.upload_into(pbuf.ptr + 96 * n,
+                            np.frombuffer(b"".join(p.to_proj_bytes() for p in points), np.uint8))
+            return _View(pbuf, 0, n + m, 96)
+
+        if tabulated:
+            # g + [h] with h an extra of g's table: commitments over the result run on the table, so the copies of
+            # 2^20 generators (64 MB affine, 96 MB projective, per proof) wait until somebody reads the arrays
             out = PointVector(None, None, self.ctx)
             out._n, out._a_make = n + m, affine
+            if self.has_proj:
+                out._p_make = proj
         else:
-            out = PointVector(affine(), pv, self.ctx)
+            out = PointVector(affine(), proj() if self.has_proj else None, self.ctx)
         if tabulated:
             out._table, out._table_tail = t, m      # g + [h]: h is extra 0 of g's table
         return out
@@ -417,10 +430,10 @@ class PointVector:
         assert len(self) == len(other)
         half = len(self)
         if keep_proj is None:
-            keep_proj = self.p is not None
+            keep_proj = self.has_proj
         abuf = self.ctx.alloc(max(1, 64 * half))
         pbuf = self.ctx.alloc(max(1, 96 * half)) if keep_proj else None
-        use_proj = self.p is not None and other.p is not None
+        use_proj = self.has_proj and other.has_proj
         self.ctx.fold(self.p.ptr if use_proj else self.a.ptr, other.p.ptr if use_proj else other.a.ptr,
                       not use_proj, reduce_scalar(c), half, pbuf.ptr if pbuf else None, abuf.ptr)
         return PointVector(_View(abuf, 0, half, 64), _View(pbuf, 0, half, 96) if pbuf else None,
@@ -428,7 +441,7 @@ class PointVector:
 
     def text_begin(self):
         """start producing the transcript text on the side stream (no host wait)"""
-        if self.p is not None and len(self):
+        if self.has_proj and len(self):
             side = get_aux_context(2)
             side.wait_for(self.ctx)
             # (remembered WITH the point format it was produced in: formats.set_reference_format takes effect at once)
@@ -437,7 +450,7 @@ class PointVector:
 
     def text(self):
         """b'[X, Y, Z], [X, Y, Z], ..., ' (uint8 array) for the Fiat-Shamir pre-image."""
-        if self.p is None:
+        if not self.has_proj:
             raise ValueError("projective representatives were not kept for this vector")
         pend = getattr(self, "_pending_text", None)
         if pend is not None and pend[0] == formats.point_style():
