@@ -55,8 +55,9 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
         return VMPC_E_HIP;
     }
     c->own_stream = true;
-    e = hipMalloc((void **)&c->d_status, VMPC_ST_WORDS * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(c->d_status, 0, VMPC_ST_WORDS * sizeof(uint32_t));
+    // (+16 words: the arrival counter of vmpc_publish_done sits behind the status words)
+    e = hipMalloc((void **)&c->d_status, (VMPC_ST_WORDS + 16) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_status, 0, (VMPC_ST_WORDS + 16) * sizeof(uint32_t));
     if (e != hipSuccess) {
         VMPC_IGNORE(hipStreamDestroy(c->stream));
         delete c;
@@ -214,6 +215,10 @@ extern "C" int vmpc_ctx_set_window(vmpc_ctx *ctx, int c_bits) {
 
 int vmpc_pinned_reserve(vmpc_ctx *ctx, size_t bytes) {
     if (ctx->pin && bytes <= ctx->pin_bytes) return VMPC_OK;
+    if (ctx->stream_waits) {
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "pinned block would grow while the stream waits on the host");
+        return VMPC_E_INVAL;
+    }
     // growing: nothing may still be using the old block (its last H2D is awaited by the caller through pin_event;
     // pin_out is only written by kernels whose results the host has already consumed)
     VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -224,6 +229,7 @@ int vmpc_pinned_reserve(vmpc_ctx *ctx, size_t bytes) {
     VMPC_HIP_CHECK(hipHostMalloc(&ctx->pin, want + 4096, hipHostMallocDefault));
     ctx->pin_bytes = want;
     ctx->pin_out = (char *)ctx->pin + want;
+    memset(ctx->pin_out, 0, 4096);          // the prover's mailbox words (prover.hip) start below every sequence number
     VMPC_HIP_CHECK(hipHostGetDevicePointer(&ctx->pin_out_dev, ctx->pin_out, 0));
     return VMPC_OK;
 }
@@ -242,6 +248,10 @@ int vmpc_stage_h2d(vmpc_ctx *ctx, void *dst, const void *src, size_t bytes) {
 int vmpc_ws_reserve(vmpc_ctx *ctx, size_t total_bytes) {
     ctx->ws_used = 0;
     if (total_bytes <= ctx->ws_bytes) return VMPC_OK;
+    if (ctx->stream_waits) {
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "workspace would grow while the stream waits on the host");
+        return VMPC_E_INVAL;
+    }
     VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->ws) {
         VMPC_HIP_CHECK(hipFree(ctx->ws));

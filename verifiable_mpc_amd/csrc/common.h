@@ -73,6 +73,13 @@ struct vmpc_ctx {
     void *pin = nullptr;
     size_t pin_bytes = 0;
     hipEvent_t pin_event = nullptr;
+    bool stream_waits = false;     // work is queued behind a hipStreamWaitValue32 only this thread can release: nothing
+                                   // may synchronise the stream now (vmpc_ws_reserve / vmpc_pinned_reserve refuse to grow)
+    // the last kernel of a queued-ahead prover round publishes its completion itself (vmpc_publish_done): set by
+    // prover.hip before it queues the round's commitment, consumed (and cleared) by the launch of that kernel
+    uint32_t *done_flag_dev = nullptr;
+    uint32_t done_seq = 0;
+    uint32_t p4_seq = 0;           // sequence numbers of the prover's pinned mailbox words (prover.hip), never reused
     void *pin_out = nullptr;       // 4 KiB of pinned, device-mapped host memory behind `pin` (same allocation): small
     void *pin_out_dev = nullptr;   // results a kernel writes for the host every round (prover.hip); its device address
     // arena of the prover's round context, kept between proofs (prover.hip)
@@ -121,3 +128,16 @@ const char *vmpc_getenv_experimental(const char *name);
 
 #define VMPC_IGNORE(expr) ((void)(expr))
 #define VMPC_KERNEL_CHECK() VMPC_HIP_CHECK(hipGetLastError())
+
+// Completion word for the host: every workgroup of a grid calls this (one thread, after its own result stores);
+// the last one to arrive stores `seq` to `flag` (pinned host memory the host polls) and re-arms the counter.
+#ifdef __HIPCC__
+__device__ __forceinline__ void vmpc_publish_done(uint32_t *counter, uint32_t *flag, uint32_t seq) {
+    __threadfence_system();
+    if (atomicAdd(counter, 1u) == gridDim.x - 1) {
+        *counter = 0;
+        __threadfence_system();
+        *(volatile uint32_t *)flag = seq;
+    }
+}
+#endif

@@ -169,15 +169,18 @@ k_fr_tail_scalars(fr_chal_arg ch, int t, int log2_m0, const uint32_t *__restrict
 // incremental form: `prod` holds s[j] for the first t-1 challenges (all ones for t = 0) and is updated
 // in place with the newest one, so a round costs two products per element instead of up to t + 1
 __global__ void __launch_bounds__(FR_BLOCK)
-k_fr_tail_scalars_inc(fr_arg c_new, int t, int log2_m0, const uint32_t *__restrict__ z, size_t j0, size_t count,
+k_fr_tail_scalars_inc(fr_arg c_new, const uint32_t *__restrict__ c_mem, int t, int log2_m0,
+                      const uint32_t *__restrict__ z, size_t j0, size_t count,
                       uint32_t *__restrict__ prod, uint32_t *__restrict__ out_a, uint32_t *__restrict__ out_b) {
     // positions j0 .. j0 + count - 1 of the length-2^log2_m0 vectors; prod / out_a / out_b hold that block only
     // (a rank of the sharded prover owns one block of g_hat: verifiable_mpc_amd/sharded.py)
     const size_t m0 = (size_t)1 << log2_m0;
     const size_t m = m0 >> t, h = m >> 1;
+    // c_mem: the challenge was not known when the launch was queued (prover.hip: rounds queued behind a stream
+    // wait) - it is read from device-visible memory instead of the argument
     fr c;
 #pragma unroll
-    for (int k = 0; k < 8; k++) c.v[k] = c_new.v[k];
+    for (int k = 0; k < 8; k++) c.v[k] = c_mem ? c_mem[k] : c_new.v[k];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
          i += (size_t)gridDim.x * blockDim.x) {
         const size_t j = j0 + i;
@@ -332,22 +335,33 @@ extern "C" int vmpc_fr_tail_scalars_inc_dev(vmpc_ctx *ctx, const uint8_t newest_
                                           products, out_a, out_b);
 }
 
-extern "C" int vmpc_fr_tail_scalars_block_dev(vmpc_ctx *ctx, const uint8_t newest_challenge[32], int t, int log2_m0,
-                                              const void *z, size_t j0, size_t count, void *products, void *out_a,
-                                              void *out_b) {
-    if (!ctx || t < 0 || t > 40 || log2_m0 < 1 || log2_m0 > 40 || t >= log2_m0 || (t && !newest_challenge) ||
-        !z || !products || !out_a || !out_b || j0 + count > ((size_t)1 << log2_m0))
+// challenge_mem != NULL: the newest challenge is read by the kernel from that device-visible address (8 words, a
+// canonical residue) - for launches queued before the challenge exists (prover.hip)
+int vmpc_fr_tail_scalars_block_mem(vmpc_ctx *ctx, const uint8_t newest_challenge[32], const uint32_t *challenge_mem,
+                                   int t, int log2_m0, const void *z, size_t j0, size_t count, void *products,
+                                   void *out_a, void *out_b) {
+    if (!ctx || t < 0 || t > 40 || log2_m0 < 1 || log2_m0 > 40 || t >= log2_m0 ||
+        (t && !newest_challenge && !challenge_mem) || !z || !products || !out_a || !out_b ||
+        j0 + count > ((size_t)1 << log2_m0))
         return VMPC_E_INVAL;
     if (count == 0) return VMPC_OK;
     fr_arg a;
     memset(&a, 0, sizeof a);
-    if (t) VMPC_CHECK(fr_arg_from(newest_challenge, a));
+    if (t && !challenge_mem) VMPC_CHECK(fr_arg_from(newest_challenge, a));
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     vmpc_stage_scope s(ctx, "fr_tail_scalars");
     k_fr_tail_scalars_inc<<<fr_grid(count), FR_BLOCK, 0, ctx->stream>>>(
-        a, t, log2_m0, (const uint32_t *)z, j0, count, (uint32_t *)products, (uint32_t *)out_a, (uint32_t *)out_b);
+        a, t ? challenge_mem : nullptr, t, log2_m0, (const uint32_t *)z, j0, count, (uint32_t *)products,
+        (uint32_t *)out_a, (uint32_t *)out_b);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
+}
+
+extern "C" int vmpc_fr_tail_scalars_block_dev(vmpc_ctx *ctx, const uint8_t newest_challenge[32], int t, int log2_m0,
+                                              const void *z, size_t j0, size_t count, void *products, void *out_a,
+                                              void *out_b) {
+    return vmpc_fr_tail_scalars_block_mem(ctx, newest_challenge, nullptr, t, log2_m0, z, j0, count, products, out_a,
+                                          out_b);
 }
 
 // canonical-residue check of a scalar vector (C-ABI boundary hygiene, SURVEY.md hard part 5)

@@ -255,7 +255,8 @@ k_msm_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ 
 // of 733 for the replicated form with four-way picks and carried sums.
 __global__ void __launch_bounds__(64)
 k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
-            uint32_t *__restrict__ out_ext, uint32_t *__restrict__ out_aff) {
+            uint32_t *__restrict__ out_ext, uint32_t *__restrict__ out_aff,
+            uint32_t *done_counter, uint32_t *done_flag, uint32_t done_seq) {
     __builtin_amdgcn_s_setprio(3);   // latency chain: win issue arbitration against co-resident bucket waves
     __shared__ uint32_t lds[64 * EXT_WORDS];
     // block k = commitment k of a batch: its W windows, its own 128-byte / 64-byte output slot
@@ -310,6 +311,7 @@ k_msm_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
             fe_st8(out_aff, a.x);
             fe_st8(out_aff + 8, a.y);
         }
+        if (done_flag) vmpc_publish_done(done_counter, done_flag, done_seq);   // a prover round queued ahead (prover.hip)
     }
 }
 
@@ -461,7 +463,9 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
     {
         vmpc_stage_scope s(ctx, "msm_final");
         k_msm_final<<<batch, 64, 0, st>>>(w.partials, p.period, tree ? 1 : p.red_blocks, p.c, (uint32_t *)out_ext,
-                                          (uint32_t *)out_affine);
+                                          (uint32_t *)out_affine, ctx->d_status + VMPC_ST_WORDS, ctx->done_flag_dev,
+                                          ctx->done_seq);
+        ctx->done_flag_dev = nullptr;
         VMPC_KERNEL_CHECK();
     }
     return VMPC_OK;

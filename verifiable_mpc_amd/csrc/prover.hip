@@ -40,6 +40,7 @@
 #include <stdlib.h>
 
 #include <array>
+#include <chrono>
 #include <vector>
 
 #include "common.h"
@@ -77,13 +78,14 @@ __device__ __forceinline__ void p4_st(uint32_t *dst, const fr &a) {
 //   gamma_a = <L'[h:], z'[:h]>,   gamma_b = <L'[:h], z'[h:]>,   h = len(z') / 2.
 // Lane i < h produces elements i and h + i of both new vectors.  fold = 0: first round, nothing to fold.
 __global__ void __launch_bounds__(P4_BLOCK)
-k_p4_fold_dots(p4_scalar c, int fold, const uint32_t *__restrict__ z_in, const uint32_t *__restrict__ L_in,
+k_p4_fold_dots(p4_scalar c, const uint32_t *__restrict__ c_mem, int fold, const uint32_t *__restrict__ z_in,
+               const uint32_t *__restrict__ L_in,
                size_t m_out, uint32_t *__restrict__ z_out, uint32_t *__restrict__ L_out,
                uint32_t *__restrict__ partials /* [2][gridDim.x] */) {
     __shared__ uint32_t lds[2 * P4_BLOCK * 8];
-    fr cc;
+    fr cc;                                  // c_mem: a round queued before its challenge existed (vmpc_p4_run_compact)
 #pragma unroll
-    for (int i = 0; i < 8; i++) cc.v[i] = c.v[i];
+    for (int i = 0; i < 8; i++) cc.v[i] = c_mem ? c_mem[i] : c.v[i];
     const size_t h = m_out / 2;
     fr pa = fr_zero(), pb = fr_zero();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < h; i += (size_t)gridDim.x * blockDim.x) {
@@ -199,15 +201,20 @@ k_p4_direct(const uint32_t *__restrict__ table, size_t stride, int rows, size_t 
 
 // the blocks_per partial sums of each commitment -> its sum, 128 bytes X || Y || Z || T at out + 128 * blockIdx.x
 __global__ void __launch_bounds__(P4D_BLOCK)
-k_p4_direct_sum(const uint32_t *__restrict__ partial, unsigned blocks_per, uint32_t *__restrict__ out_ext) {
+k_p4_direct_sum(const uint32_t *__restrict__ partial, unsigned blocks_per, uint32_t *__restrict__ out_ext,
+                uint32_t *done_counter, uint32_t *done_flag, uint32_t done_seq) {
     __shared__ uint32_t lds[P4D_BLOCK * EXT_WORDS];
     const uint32_t *src = partial + EXT_WORDS * (size_t)blockIdx.x * blocks_per;
     ge_ext acc = ge_ext_identity();
     for (unsigned j = threadIdx.x; j < blocks_per; j += P4D_BLOCK) acc = ge_add(acc, ext_ld(src + EXT_WORDS * (size_t)j));
     p4d_tree(lds, acc, out_ext + 32 * blockIdx.x, true);
+    if (done_flag && threadIdx.x == 0) vmpc_publish_done(done_counter, done_flag, done_seq);
 }
 
 int vmpc_fr_check_dev(vmpc_ctx *ctx, const void *v, size_t n);      // frvec.hip: bumps the status word, no sync
+int vmpc_fr_tail_scalars_block_mem(vmpc_ctx *ctx, const uint8_t newest_challenge[32], const uint32_t *challenge_mem,
+                                   int t, int log2_m0, const void *z, size_t j0, size_t count, void *products,
+                                   void *out_a, void *out_b);       // frvec.hip
 
 int vmpc_table_fold_table_with_block(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
                                      size_t n_cols, int k, const uint8_t *scalars, size_t n_extra, int out_rows,
@@ -446,12 +453,17 @@ extern "C" int vmpc_p4_destroy(vmpc_p4 *p) {
 
 // z' = z_l + c z_r, L' = c L_l + L_r with the challenge of the round just hashed (c = NULL: first round, no fold),
 // and the two inner products of the resulting vectors as partial sums (k_p4_fold_dots)
-static int p4_fold_dots(vmpc_p4 *p, const uint8_t *c) {
+// c_mem: the challenge is not known yet - the kernel reads it from there, and the entry of `pending` is a
+// placeholder the caller fills in before the next fold of the generators
+static int p4_fold_dots(vmpc_p4 *p, const uint8_t *c, const uint32_t *c_mem = nullptr) {
+    static const uint8_t placeholder[32] = {0};
     p4_scalar cs;
     memset(&cs, 0, sizeof cs);
     if (c) {
         memcpy(cs.v, c, 32);
         if (fr_geq_l(cs.v)) return VMPC_E_NONCANON;
+    } else if (c_mem) {
+        c = placeholder;
     }
     const size_t m_out = c ? p->m / 2 : p->m, h = m_out / 2;
     const int nx = c ? p->cur ^ 1 : p->cur;
@@ -460,7 +472,7 @@ static int p4_fold_dots(vmpc_p4 *p, const uint8_t *c) {
     if (g == 0) g = 1;
     vmpc_stage_scope s(p->ctx, "p4_fold_dots");
     k_p4_fold_dots<<<(unsigned)g, P4_BLOCK, 0, p->ctx->stream>>>(
-        cs, c ? 1 : 0, (const uint32_t *)p->z[p->cur], (const uint32_t *)p->L[p->cur], m_out, (uint32_t *)p->z[nx],
+        cs, c_mem, c ? 1 : 0, (const uint32_t *)p->z[p->cur], (const uint32_t *)p->L[p->cur], m_out, (uint32_t *)p->z[nx],
         (uint32_t *)p->L[nx], (uint32_t *)p->partials);
     VMPC_KERNEL_CHECK();
     p->dots_grid = (unsigned)g;
@@ -552,16 +564,20 @@ static void p4_affine_pair(const uint8_t ext[256], uint8_t out_a[64], uint8_t ou
     }
 }
 
-static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
+// everything of a round that runs on the stream; c_mem as in p4_fold_dots (the fold before it was queued with it)
+static int p4_round_enqueue(vmpc_p4 *p, const uint32_t *c_mem) {
     vmpc_ctx *ctx = p->ctx;
-    if (p4_jump_due(p)) VMPC_CHECK(p4_jump(p));
+    if (p4_jump_due(p)) {
+        if (c_mem) return VMPC_E_INVAL;                     // a fold of the generators needs the challenges' values
+        VMPC_CHECK(p4_jump(p));
+    }
     const int t = (int)p->pending.size();                   // challenges the table's generators have not seen
     const char *z = p->z[p->cur];
     hipStream_t st = ctx->stream;
     // commitment scalars over the unfolded g_hat (this rank's block of it): challenge products x the (shifted)
     // witness halves
     static const uint8_t zero[32] = {0};
-    VMPC_CHECK(vmpc_fr_tail_scalars_block_dev(ctx, t ? p->pending.back().data() : zero, t, p->log2_n, z, p->block_lo,
+    VMPC_CHECK(vmpc_fr_tail_scalars_block_mem(ctx, t ? p->pending.back().data() : zero, c_mem, t, p->log2_n, z, p->block_lo,
                                               p->block_n, p->products, p->va, p->vb));
     // extras: the tail of g_hat (h) lives among them, and k with the inner products as exponents (rank 0 only:
     // the k term must enter the sum over the ranks once)
@@ -590,7 +606,9 @@ static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
                                                           (const uint32_t *)p->ex_a, (const uint32_t *)p->ex_b, blocks_per,
                                                           part);
         VMPC_KERNEL_CHECK();
-        k_p4_direct_sum<<<2, P4D_BLOCK, 0, st>>>(part, blocks_per, (uint32_t *)pair_out);
+        k_p4_direct_sum<<<2, P4D_BLOCK, 0, st>>>(part, blocks_per, (uint32_t *)pair_out, ctx->d_status + VMPC_ST_WORDS,
+                                                 ctx->done_flag_dev, ctx->done_seq);
+        ctx->done_flag_dev = nullptr;
         VMPC_KERNEL_CHECK();
     } else {
         // v_a and v_b are each zero on half of their positions (z_l against g_r, z_r against g_l): tell the planner
@@ -609,6 +627,12 @@ static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
     // the round's one exchange: all-gather + rank-ordered add on the same stream, the result lands in the pinned block
     if (p->comm)
         VMPC_CHECK(vmpc_comm_points_allsum_dev(p->comm, ctx, p->mine, 2, p->gathered, ctx->pin_out_dev, nullptr));
+    return VMPC_OK;
+}
+
+static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
+    vmpc_ctx *ctx = p->ctx;
+    VMPC_CHECK(p4_round_enqueue(p, nullptr));
     const uint8_t *ext = (const uint8_t *)ctx->pin_out;
     // The first round's synchronisation also fetches the device status words (a non-canonical scalar in the caller's
     // z_hat / L~ shows up in this round's recoding); later rounds only consume scalars this context produced, so
@@ -708,6 +732,65 @@ struct host_sha256 {
 };
 }  // namespace
 
+// The chain step: state' = SHA-256(state || round index || A || B), challenge = state' mod l.
+static void p4_chain_step(uint8_t state[32], uint32_t round_index, const uint8_t ab[128], uint8_t challenge[32]) {
+    uint8_t msg[32 + 4 + 128];
+    memcpy(msg, state, 32);
+    for (int b = 0; b < 4; b++) msg[32 + b] = (uint8_t)(round_index >> (8 * b));
+    memcpy(msg + 36, ab, 128);
+    host_sha256::digest(msg, sizeof msg, state);
+    uint32_t w[8];
+    memcpy(w, state, 32);
+    fr_store((uint32_t *)challenge, fr_from_u256(w));
+}
+
+// Rounds queued AHEAD of their challenge.  Between two rounds the device used to sit idle for the host's turn:
+// hipStreamSynchronize returning (~6 us), the pair's inversion and the hash (~5 us), and the first launch of the
+// next round reaching the device (~7 us, the other twenty launches hide behind it) - ~27 us, 19 times per proof.
+// Now round i + 1 is queued while round i runs, behind a stream wait (hipStreamWaitValue32) on a word of pinned
+// host memory; its two kernels that consume the challenge read it from the pinned block instead of their
+// arguments.  The host polls a second pinned word that round i's last kernel sets (vmpc_publish_done), turns A_i, B_i into the challenge, stores it and releases the wait: ~5 us from the store to the
+// first kernel (scripts/waitvalue_probe.hip), and the launches of round i + 1 cost the device nothing.
+// A round that folds the generators (p4_jump) builds its schedule on the host from the challenges' values and is
+// queued the old way, after its challenge; so is everything when the device cannot wait on memory, with a
+// communicator (the exchange is a collective on the same stream: kept in the plain order), or on request.
+namespace {
+struct p4_mailbox {
+    volatile uint32_t *done_h, *go_h;
+    uint32_t *challenge_h;
+    uint32_t *done_d, *go_d;
+    const uint32_t *challenge_d;
+};
+p4_mailbox p4_mail(vmpc_ctx *ctx) {            // behind the results (256 B) and before the status words (2048)
+    char *h = (char *)ctx->pin_out, *d = (char *)ctx->pin_out_dev;
+    p4_mailbox m;
+    m.done_h = (volatile uint32_t *)(h + 1024);
+    m.go_h = (volatile uint32_t *)(h + 1088);
+    m.challenge_h = (uint32_t *)(h + 1152);
+    m.done_d = (uint32_t *)(d + 1024);
+    m.go_d = (uint32_t *)(d + 1088);
+    m.challenge_d = (const uint32_t *)(d + 1152);
+    return m;
+}
+bool p4_poll(volatile uint32_t *word, uint32_t want, double seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        if (*word == want) return true;
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0xfff &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds)
+            return false;
+    }
+}
+}  // namespace
+
+static bool p4_can_queue_ahead(vmpc_p4 *p) {
+    if (p->comm || vmpc_getenv_experimental("VMPC_P4_NO_QUEUE_AHEAD")) return false;
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, p->ctx->device) != hipSuccess) return false;
+    return can != 0;
+}
+
 // state: the chain value before the first round (in), after the last (out).  out_AB: log2(N) - 1 rounds x
 // (A_i || B_i) = 128 bytes each; out_z_prime: the two final residues.  The context must be fresh.
 extern "C" int vmpc_p4_run_compact(vmpc_p4 *p, uint8_t state[32], int first_round_index, uint8_t *out_AB,
@@ -715,18 +798,80 @@ extern "C" int vmpc_p4_run_compact(vmpc_p4 *p, uint8_t state[32], int first_roun
     if (!p || !state || !out_AB || !out_z_prime || p->committed != 0 || first_round_index < 0) return VMPC_E_INVAL;
     uint8_t challenge[32];
     const int rounds = p->total_rounds;
-    for (int i = 0; i < rounds; i++) {
+    if (!p4_can_queue_ahead(p)) {
+        for (int i = 0; i < rounds; i++) {
+            uint8_t *ab = out_AB + 128 * (size_t)i;
+            VMPC_CHECK(vmpc_p4_round(p, i ? challenge : nullptr, ab, ab + 64));
+            p4_chain_step(state, (uint32_t)(first_round_index + i), ab, challenge);
+        }
+        return vmpc_p4_finish(p, challenge, out_z_prime);
+    }
+    vmpc_ctx *ctx = p->ctx;
+    hipStream_t st = ctx->stream;
+    // round 0 the plain way: its synchronisation also fetches the status words (canonical z_hat / L~)
+    VMPC_CHECK(vmpc_p4_round(p, nullptr, out_AB, out_AB + 64));
+    p4_chain_step(state, (uint32_t)first_round_index, out_AB, challenge);
+    VMPC_CHECK(vmpc_pinned_reserve(ctx, (size_t)1 << 18));   // nothing in the rounds below stages more than this
+    const p4_mailbox mb = p4_mail(ctx);
+    bool queued = false;                 // round i sits behind a wait (its fold was queued with a placeholder)
+    uint32_t go_seq = 0;
+    size_t placeholder_at = 0;
+    // a failure with a wait in the queue: let the queue drain (the round runs on a stale challenge; the context is
+    // poisoned) before anybody synchronises
+    auto bail = [&](int rc) {
+        p->poisoned = true;
+        if (queued) *mb.go_h = go_seq;
+        ctx->stream_waits = false;
+        ctx->done_flag_dev = nullptr;
+        (void)hipStreamSynchronize(st);
+        return rc;
+    };
+    for (int i = 1; i < rounds; i++) {
         uint8_t *ab = out_AB + 128 * (size_t)i;
-        VMPC_CHECK(vmpc_p4_round(p, i ? challenge : nullptr, ab, ab + 64));
-        uint8_t msg[32 + 4 + 128];
-        memcpy(msg, state, 32);
-        const uint32_t ri = (uint32_t)(first_round_index + i);
-        for (int b = 0; b < 4; b++) msg[32 + b] = (uint8_t)(ri >> (8 * b));
-        memcpy(msg + 36, ab, 128);
-        host_sha256::digest(msg, sizeof msg, state);
-        uint32_t w[8];
-        memcpy(w, state, 32);
-        fr_store((uint32_t *)challenge, fr_from_u256(w));
+        uint32_t done_seq;
+        if (queued) {
+            // the round is in the queue: hand it its challenge
+            memcpy(mb.challenge_h, challenge, 32);
+            memcpy(p->pending[placeholder_at].data(), challenge, 32);
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            *mb.go_h = go_seq;
+            done_seq = go_seq + 1;
+            queued = false;
+            ctx->stream_waits = false;
+        } else {
+            int rc = p->m / 2 < 4 ? VMPC_E_INVAL : p4_fold_dots(p, challenge);
+            done_seq = ++ctx->p4_seq;
+            ctx->done_flag_dev = mb.done_d;                  // the commitment's last kernel publishes the completion
+            ctx->done_seq = done_seq;
+            if (rc == VMPC_OK) rc = p4_round_enqueue(p, nullptr);
+            if (rc != VMPC_OK) return bail(rc);
+        }
+        // queue round i + 1 behind the wait, unless its fold of the witness is followed by a fold of the generators
+        const bool jump_next = p->jumps_done < p->jumps.size() &&
+                               (int)p->pending.size() + 1 == p->jumps[p->jumps_done].k;
+        if (i + 1 < rounds && !jump_next && p->m / 2 >= 4) {
+            go_seq = ++ctx->p4_seq;
+            ++ctx->p4_seq;                                   // = go_seq + 1: the round's completion word
+            int rc = hipStreamWaitValue32(st, mb.go_d, go_seq, hipStreamWaitValueEq, 0xffffffffu) == hipSuccess
+                         ? VMPC_OK : VMPC_E_HIP;
+            if (rc != VMPC_OK) return bail(rc);
+            queued = true;
+            ctx->stream_waits = true;
+            placeholder_at = p->pending.size();
+            rc = p4_fold_dots(p, nullptr, mb.challenge_d);
+            ctx->done_flag_dev = mb.done_d;
+            ctx->done_seq = go_seq + 1;
+            if (rc == VMPC_OK) rc = p4_round_enqueue(p, mb.challenge_d);
+            if (rc != VMPC_OK) return bail(rc);
+        }
+        // round i's pair
+        if (!p4_poll(mb.done_h, done_seq, 20.0)) {
+            snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "vmpc_p4_run_compact: round %d did not complete", i);
+            return bail(VMPC_E_HIP);
+        }
+        p->committed++;
+        p4_affine_pair((const uint8_t *)ctx->pin_out, ab, ab + 64);
+        p4_chain_step(state, (uint32_t)(first_round_index + i), ab, challenge);
     }
     return vmpc_p4_finish(p, challenge, out_z_prime);
 }
