@@ -399,6 +399,44 @@ def test_native_round_context_with_fold_jumps(vm, monkeypatch, log_n, jump_k, mi
     assert proofs[0] == proofs[1]
 
 
+@pytest.mark.parametrize("log_n,jump_k,min_log2", [(3, 0, 30), (9, 3, 5), (13, 5, 8)])
+def test_rounds_queued_ahead_of_their_challenge(vm, monkeypatch, log_n, jump_k, min_log2):
+    """vmpc_p4_run_compact queues round i + 1 behind a stream wait while round i runs and hands it the challenge
+    through pinned memory (csrc/prover.hip); with VMPC_P4_NO_QUEUE_AHEAD every round is launched after its
+    challenge.  Same proofs, proof after proof on one context (the mailbox's sequence numbers keep counting),
+    through fold jumps and the bucket-free short rounds."""
+    rng = random.Random(7700 + log_n)
+    n = (1 << log_n) - 1
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    h, k = group.generator, vm.Ed25519Point.repeat(group.generator, rng.randrange(1, ELL))
+    g = vm.PointVector.fixed_base(h, [rng.randrange(1, ELL) for _ in range(n)], keep_proj=False)
+    g.precompute([h, k])
+    gens = {"g": g, "h": h, "k": k}
+    Lf = vm.pivot.LinearForm(vm.ScalarVector.from_ints([rng.randrange(ELL) for _ in range(n)]))
+    monkeypatch.setenv("VMPC_P4_JUMP", str(jump_k))
+    monkeypatch.setenv("VMPC_P4_JUMP_MIN_LOG2", str(min_log2))
+    monkeypatch.setenv("VMPC_EXPERIMENTAL", "1")
+    for rep in range(3):
+        xs = vm.ScalarVector.from_ints([rng.randrange(ELL) for _ in range(n)])
+        gamma, rho = rng.randrange(1, ELL), rng.randrange(ELL)
+        r = [rng.randrange(ELL) for _ in range(n)]
+        P = vm.pivot.vector_commitment(xs, gamma, g, h)
+        y = gf(Lf(xs))
+        proofs = []
+        for plain in (False, True, False):
+            if plain:
+                monkeypatch.setenv("VMPC_P4_NO_QUEUE_AHEAD", "1")
+            else:
+                monkeypatch.delenv("VMPC_P4_NO_QUEUE_AHEAD", raising=False)
+            proof = vm.compressed_pivot.protocol_5_prover(gens, P, Lf, y, xs, gamma, gf, transcript="compact",
+                                                          r=list(r), rho=rho)
+            proofs.append({key: (tuple(v.normalize().coords) if hasattr(v, "normalize") else
+                                 [int(e) for e in v] if isinstance(v, list) else int(v)) for key, v in proof.items()})
+        assert proofs[0] == proofs[1] == proofs[2]
+        assert vm.compressed_pivot.protocol_5_verifier(gens, P, Lf, y, proof, gf, transcript="compact") is True
+
+
 @pytest.mark.parametrize("n_table,with_h", [(128, False), (127, True)])
 def test_protocol4_over_a_prefix_of_a_tabulated_crs(vm, n_table, with_h):
     """protocol_4_prover(g[:m], ...) with g[:m] a STRICT prefix of a tabulated vector (PointVector slices keep
