@@ -450,17 +450,19 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
     }
     // short chunks (latency path: one commitment alone, the prover's rounds): weights from the quad tree
     const bool tree = ctx->reduce_tree && msm_reduce_tree_fits(p);
+    // ... and with one bucket set per commitment (a 16-row table) its second kernel writes the results itself
+    const bool tree_is_final = tree && p.period == 1 && out_ext && !out_affine;
     {
         vmpc_stage_scope s(ctx, "msm_reduce");
         if (tree) {
-            VMPC_CHECK(msm_reduce_tree(ctx, p, w, st));
+            VMPC_CHECK(msm_reduce_tree(ctx, p, w, st, tree_is_final ? out_ext : nullptr));
         } else {
             k_msm_reduce<<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, st>>>(
                 w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, msm_ilog2(p.chunk_len), p.red_blocks, w.partials);
             VMPC_KERNEL_CHECK();
         }
     }
-    {
+    if (!tree_is_final) {
         vmpc_stage_scope s(ctx, "msm_final");
         k_msm_final<<<batch, 64, 0, st>>>(w.partials, p.period, tree ? 1 : p.red_blocks, p.c, (uint32_t *)out_ext,
                                           (uint32_t *)out_affine, ctx->d_status + VMPC_ST_WORDS, ctx->done_flag_dev,

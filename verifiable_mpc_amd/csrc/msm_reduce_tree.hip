@@ -178,7 +178,8 @@ k_msm_reduce_tree(const uint32_t *__restrict__ buckets, const uint32_t *__restri
 
 // workgroup w: R_w = X + L (Y + Z) from the G triples of the window:  X = sum U_g, Y = sum Rw_g, Z = sum g D_g
 __global__ void __launch_bounds__(RT_THREADS)
-k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_t *__restrict__ out) {
+k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_t *__restrict__ out,
+                     uint32_t *__restrict__ out_packed, uint32_t *done_counter, uint32_t *done_flag, uint32_t done_seq) {
     extern __shared__ __align__(16) uint32_t rt_lds[];
     uint32_t *TA = rt_lds;
     uint32_t *US = TA + (size_t)G * EXT_WORDS;
@@ -200,7 +201,11 @@ k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_
     if (G > 1) R = rt_add(R, rt_ld(RR, 0, q), q);
     for (int k = 0; k < log2L; k++) R = quadD_dbl(R, q);
     R = rt_add(R, rt_ld(US, 0, q), q);
-    if (threadIdx.x < 4) fe_st(out + EXT_WORDS * (size_t)w + FE_LIMBS * q, R);
+    if (threadIdx.x < 4) {
+        if (out_packed) fe_st8(out_packed + 32 * (size_t)w + 8 * q, R);      // one bucket set per commitment: its result
+        else fe_st(out + EXT_WORDS * (size_t)w + FE_LIMBS * q, R);
+    }
+    if (out_packed && done_flag && threadIdx.x == 0) vmpc_publish_done(done_counter, done_flag, done_seq);
 }
 
 bool msm_reduce_tree_fits(const msm_plan &p) {
@@ -209,8 +214,10 @@ bool msm_reduce_tree_fits(const msm_plan &p) {
     return G >= 1 && G <= 128 && (G & (G - 1)) == 0 && p.chunk_len <= 8 && (p.chunk_len & (p.chunk_len - 1)) == 0;
 }
 
-// buckets -> W window sums at w.partials (one per window: k_msm_final's red_blocks = 1); the triples sit behind them
-int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st) {
+// buckets -> W window sums at w.partials (one per window: k_msm_final's red_blocks = 1); the triples sit behind them.
+// out_packed != NULL (one bucket set per commitment, extended output wanted): the window sums ARE the results and go
+// there in the public 128-byte form - no recombination launch.
+int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st, void *out_packed) {
     const int G = p.chunks / RT_LEAVES, L = p.chunk_len;
     const size_t lds_a1 = (size_t)(RT_LEAVES * 2) * EXT_WORDS * 4, lds_aU = (size_t)(RT_LEAVES * 3) * EXT_WORDS * 4;
     const size_t lds_b = (size_t)(4 * G + 1) * EXT_WORDS * 4;
@@ -233,7 +240,10 @@ int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st)
     else
         k_msm_reduce_tree<false, false><<<dim3(G, p.W), RT_THREADS, lds_a1, st>>>(w.buckets, w.counts, p.nb, G, L, triples);
     VMPC_KERNEL_CHECK();
-    k_msm_reduce_combine<<<p.W, RT_THREADS, lds_b, st>>>(triples, G, msm_ilog2(L), w.partials);
+    k_msm_reduce_combine<<<p.W, RT_THREADS, lds_b, st>>>(triples, G, msm_ilog2(L), w.partials, (uint32_t *)out_packed,
+                                                         ctx->d_status + VMPC_ST_WORDS, out_packed ? ctx->done_flag_dev : nullptr,
+                                                         ctx->done_seq);
+    if (out_packed) ctx->done_flag_dev = nullptr;
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }
