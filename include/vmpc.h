@@ -281,6 +281,14 @@ int vmpc_format_points_async_dev(vmpc_ctx *ctx, const void *proj, size_t n, void
                                  void *host_text, uint64_t *host_len);
 int vmpc_format_scalars_async_dev(vmpc_ctx *ctx, const void *scalars, size_t n, int is_signed,
                                   void *dev_text, size_t cap, void *host_text, uint64_t *host_len);
+/* The same with the text delivered in pieces of chunk_bytes (>= 4096): host_len is a pinned block of >= 16 bytes -
+ * [0, 8) the text's length, [8, 12) the number of pieces that have landed (0 when the call is made, advanced on the
+ * stream) - so that the caller can hash piece k while piece k + 1 is in flight (pivot.py:131-136 hashes ~1 GB of such
+ * text per proof at N = 2^20). */
+int vmpc_format_points_chunked_dev(vmpc_ctx *ctx, const void *proj, size_t n, void *dev_text, size_t cap,
+                                   void *host_text, uint64_t *host_len, size_t chunk_bytes);
+int vmpc_format_scalars_chunked_dev(vmpc_ctx *ctx, const void *scalars, size_t n, int is_signed, void *dev_text,
+                                    size_t cap, void *host_text, uint64_t *host_len, size_t chunk_bytes);
 /* page-locked host memory for the asynchronous copies above */
 int vmpc_host_alloc(size_t bytes, void **out);
 int vmpc_host_free(void *p);

@@ -6,6 +6,7 @@ compressed_pivot.py, ...) mirror the reference's call signatures and send all O(
 group / vector work through here.
 """
 import ctypes
+import time
 import os
 
 import numpy as np
@@ -32,6 +33,7 @@ SYMBOLS = [
     "vmpc_msm_dev", "vmpc_msm_table_bytes", "vmpc_msm_table_build_dev", "vmpc_msm_table_dev", "vmpc_msm_table_batch_dev", "vmpc_points_sum_dev", "vmpc_points_sum_many_dev", "vmpc_fixed_base_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
     "vmpc_fr_scale_dev", "vmpc_fr_axpy_tail_dev", "vmpc_fr_dot_dev", "vmpc_fr_dot_to_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
+    "vmpc_format_points_chunked_dev", "vmpc_format_scalars_chunked_dev",
     "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev", "vmpc_fr_tail_scalars_block_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
@@ -119,6 +121,8 @@ def load_library():
         "vmpc_format_scalars_dev": (i32, [vp, vp, sz, i32, vp, sz, u64p]),
         "vmpc_format_points_async_dev": (i32, [vp, vp, sz, vp, sz, vp, vp]),
         "vmpc_format_scalars_async_dev": (i32, [vp, vp, sz, i32, vp, sz, vp, vp]),
+        "vmpc_format_points_chunked_dev": (i32, [vp, vp, sz, vp, sz, vp, vp, sz]),
+        "vmpc_format_scalars_chunked_dev": (i32, [vp, vp, sz, i32, vp, sz, vp, vp, sz]),
         "vmpc_host_alloc": (i32, [sz, ctypes.POINTER(vp)]),
         "vmpc_host_free": (i32, [vp]),
         "vmpc_sha256_chunks_dev": (i32, [vp, vp, sz, sz, vp]),
@@ -269,8 +273,9 @@ class PendingText:
     """Transcript text being formatted and copied on a context's stream (PointVector /
     ScalarVector .text_begin()); result() synchronises that stream."""
 
-    def __init__(self, ctx, pinned, dev, cap, keepalive=None):
+    def __init__(self, ctx, pinned, dev, cap, keepalive=None, chunk_bytes=0):
         self.ctx, self.pinned, self.dev, self.cap = ctx, pinned, dev, cap
+        self.chunk_bytes = chunk_bytes
         # the SOURCE vector's device block belongs to another context's block cache: hold it until this
         # stream has been synchronised, so that it cannot be recycled under the formatter's reads
         self.keepalive = keepalive
@@ -284,6 +289,33 @@ class PendingText:
             self.keepalive = None
         return self._view
 
+    def chunks(self, trim=0):
+        """the text minus its last `trim` bytes as consecutive memory views, each handed out as soon as its piece
+        has landed on the host (vmpc_format_*_chunked_dev): the caller hashes one while the next is on the link"""
+        if self.dev is None or not self.chunk_bytes:
+            view = self.result()
+            yield view[:len(view) - trim] if trim else view
+            return
+        words = np.frombuffer(self.pinned.array[:16], dtype=np.uint32)      # length (2 words), pieces landed
+        total, k, step = None, 0, self.chunk_bytes
+        deadline = time.monotonic() + 120.0
+        while True:
+            spins = 0
+            while int(words[2]) <= k:
+                spins += 1
+                if spins & 0xfff == 0 and time.monotonic() > deadline:
+                    self.ctx.sync()                  # reports the stream's error, if that is why nothing lands
+                    raise VmpcError(E_HIP, "transcript text did not arrive")
+            if total is None:
+                total = int(np.frombuffer(self.pinned.array[:8], dtype=np.uint64)[0]) - trim
+            lo, hi = k * step, min((k + 1) * step, total)
+            if lo >= total:
+                return
+            yield self.pinned.array[16 + lo:16 + hi]
+            if hi >= total:
+                return
+            k += 1
+
     def __del__(self):
         # the pinned block goes back to the pool only when nobody can still read the text
         try:
@@ -295,6 +327,21 @@ class PendingText:
                 self.pinned = None
         except Exception:
             pass
+
+
+class TextSequence:
+    """Several PendingTexts that are one text (a vector formatted slice by slice, PointVector.fold)."""
+
+    def __init__(self, parts):
+        self.parts = parts
+
+    def result(self):
+        views = [p.result() for p in self.parts]
+        return views[0] if len(views) == 1 else np.concatenate(views)
+
+    def chunks(self, trim=0):
+        for i, p in enumerate(self.parts):
+            yield from p.chunks(trim if i == len(self.parts) - 1 else 0)
 
 
 class Context:
@@ -321,6 +368,8 @@ class Context:
         # until the NEXT text_begin of the same size class on this context
         self._pinned.setdefault(_size_class(nbytes), []).append(buf)
 
+    TEXT_CHUNK_BYTES = 8 << 20      # pieces of the transcript text on their way to the host (PendingText.chunks)
+
     def format_begin(self, kind, src_ptr, n, is_signed=True, keepalive=None):
         """enqueue formatting + D2H of a vector's transcript text; returns a PendingText.
         `keepalive`: the owner of `src_ptr` when it lives in another context's block cache"""
@@ -330,7 +379,17 @@ class Context:
         dev = DeviceBuffer(self, cap)
         host_len = ctypes.c_void_p(pinned.ptr)
         host_text = ctypes.c_void_p(pinned.ptr + 16)
-        if kind == "points":
+        chunk = self.TEXT_CHUNK_BYTES if cap > 2 * self.TEXT_CHUNK_BYTES else 0
+        if chunk:
+            pinned.array[:16] = 0                                   # length, pieces landed
+            if kind == "points":
+                rc = self.lib.vmpc_format_points_chunked_dev(self.handle, ctypes.c_void_p(src_ptr), n,
+                                                             ctypes.c_void_p(dev.ptr), cap, host_text, host_len, chunk)
+            else:
+                rc = self.lib.vmpc_format_scalars_chunked_dev(self.handle, ctypes.c_void_p(src_ptr), n,
+                                                              1 if is_signed else 0, ctypes.c_void_p(dev.ptr),
+                                                              cap, host_text, host_len, chunk)
+        elif kind == "points":
             rc = self.lib.vmpc_format_points_async_dev(self.handle, ctypes.c_void_p(src_ptr), n,
                                                        ctypes.c_void_p(dev.ptr), cap, host_text, host_len)
         else:
@@ -338,7 +397,7 @@ class Context:
                                                         1 if is_signed else 0, ctypes.c_void_p(dev.ptr),
                                                         cap, host_text, host_len)
         _check(rc, "vmpc_format_async")
-        return PendingText(self, pinned, dev, cap, keepalive)
+        return PendingText(self, pinned, dev, cap, keepalive, chunk)
 
     def _take_block(self, cap):
         lst = self._cache.get(cap)

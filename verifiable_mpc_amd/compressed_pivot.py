@@ -421,9 +421,9 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
         if tail_cs is not None:
             tail_cs.append(c)
         else:
-            g_hat = g_l.fold(g_r, c)
-            if transcript.mode == "reference":
-                g_hat.text_begin()       # next round's pre-image: format + copy behind the MSMs
+            # reference transcript: the folded vector's text is the bulk of the next pre-image - folded, formatted
+            # and copied slice by slice (PointVector.fold), hashed while the rest is still on its way
+            g_hat = g_l.fold(g_r, c, stream_text=transcript.mode == "reference")
         if transcript.mode == "reference":
             # only the reference pre-image contains Q (compressed_pivot.py:52); the compact
             # chain binds Q once at the start, so the prover need not track it
@@ -502,7 +502,7 @@ def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=N
         A = _pt(proof["A" + str(round_i)])
         B = _pt(proof["B" + str(round_i)])
         c = transcript.round_challenge(round_i, A, B, g_hat, k, Q, L_tilde)
-        g_prime = g_l.fold(g_r, c)
+        g_prime = g_l.fold(g_r, c, stream_text=transcript.mode == "reference" and half > 2)
         if transcript.mode == "reference":
             Q = _fold_commitment(A, Q, B, c)
         else:

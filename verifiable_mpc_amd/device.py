@@ -200,6 +200,15 @@ class ScalarVector:
             return pend[1].result()
         return self.ctx.format_scalars(self.ptr, len(self), is_signed)
 
+    def text_chunks(self, is_signed=None):
+        """text()[:-2] in pieces, each as soon as it is on the host (a text_begin() in flight), else at once"""
+        if is_signed is None:
+            is_signed = formats.scalar_signed()
+        pend = getattr(self, "_pending_text", None)
+        if pend is not None and pend[0] == is_signed:
+            return pend[1].chunks(trim=2)
+        return iter([memoryview(self.text(is_signed))[:-2]])
+
     def __repr__(self):
         body = self.text().tobytes().decode()
         return "[" + body[:-2] + "]"
@@ -394,6 +403,7 @@ class PointVector:
             out = PointVector(affine(), proj() if self.has_proj else None, self.ctx)
         if tabulated:
             out._table, out._table_tail = t, m      # g + [h]: h is extra 0 of g's table
+        out._text_parent = (src, list(points))      # its transcript text = the source's text + these points' (text_chunks)
         return out
 
     def __add__(self, other):
@@ -425,8 +435,14 @@ class PointVector:
         self._table = FixedBaseTable(buf, len(self), [raw[64 * i:64 * i + 64] for i in range(len(extras))], rows)
         return self
 
-    def fold(self, other, c, keep_proj=None):
-        """[(self[i] ** c) * other[i]] (compressed_pivot.py:64/:178), csrc/exact.hip k_fold."""
+    TEXT_SLICE = 1 << 16     # fold(stream_text=True): elements folded, formatted and sent to the host at a time
+
+    def fold(self, other, c, keep_proj=None, stream_text=False):
+        """[(self[i] ** c) * other[i]] (compressed_pivot.py:64/:178), csrc/exact.hip k_fold.
+        stream_text: the result's transcript text is wanted next (the reference transcript hashes the folded
+        generators every round, compressed_pivot.py:52): a long vector is folded slice by slice, each slice formatted
+        and copied on the side stream as soon as it exists, so the host hashes the first slices while the rest is
+        still being folded (an exact 2^19-element fold is 8.6 ms; hashing its 123 MB of text takes 50)."""
         assert len(self) == len(other)
         half = len(self)
         if keep_proj is None:
@@ -434,10 +450,23 @@ class PointVector:
         abuf = self.ctx.alloc(max(1, 64 * half))
         pbuf = self.ctx.alloc(max(1, 96 * half)) if keep_proj else None
         use_proj = self.has_proj and other.has_proj
-        self.ctx.fold(self.p.ptr if use_proj else self.a.ptr, other.p.ptr if use_proj else other.a.ptr,
-                      not use_proj, reduce_scalar(c), half, pbuf.ptr if pbuf else None, abuf.ptr)
-        return PointVector(_View(abuf, 0, half, 64), _View(pbuf, 0, half, 96) if pbuf else None,
-                           self.ctx)
+        lp, rp = (self.p.ptr, other.p.ptr) if use_proj else (self.a.ptr, other.a.ptr)
+        stride = 96 if use_proj else 64
+        out = PointVector(_View(abuf, 0, half, 64), _View(pbuf, 0, half, 96) if pbuf else None, self.ctx)
+        if not (stream_text and pbuf is not None and half >= 2 * self.TEXT_SLICE):
+            self.ctx.fold(lp, rp, not use_proj, reduce_scalar(c), half, pbuf.ptr if pbuf else None, abuf.ptr)
+            if stream_text:
+                out.text_begin()
+            return out
+        side, pieces = get_aux_context(2), []
+        for a in range(0, half, self.TEXT_SLICE):
+            cnt = min(self.TEXT_SLICE, half - a)
+            self.ctx.fold(lp + stride * a, rp + stride * a, not use_proj, reduce_scalar(c), cnt, pbuf.ptr + 96 * a,
+                          abuf.ptr + 64 * a)
+            side.wait_for(self.ctx)
+            pieces.append(side.format_begin("points", pbuf.ptr + 96 * a, cnt, keepalive=pbuf))
+        out._pending_text = (formats.point_style(), _native.TextSequence(pieces))
+        return out
 
     def text_begin(self):
         """start producing the transcript text on the side stream (no host wait)"""
@@ -456,6 +485,27 @@ class PointVector:
         if pend is not None and pend[0] == formats.point_style():
             return pend[1].result()
         return self.ctx.format_points(self.p.ptr, len(self))
+
+    def text_chunks(self):
+        """text()[:-2] in pieces, each as soon as it is on the host (a text_begin() in flight), else at once"""
+        if not self.has_proj:
+            raise ValueError("projective representatives were not kept for this vector")
+        pend = getattr(self, "_pending_text", None)
+        if pend is not None and pend[0] == formats.point_style():
+            return pend[1].chunks(trim=2)
+        parent = getattr(self, "_text_parent", None)
+        if parent is not None:
+            # g_hat = g + [h] right after g itself went into a hash (compressed_pivot.py:125-138): g's text is on
+            # the host already (or on its way) - 246 MB at 2^20 points that need not be formatted and copied again
+            src, pts = parent
+            ppend = getattr(src, "_pending_text", None)
+            if ppend is not None and ppend[0] == formats.point_style():
+                def pieces():
+                    yield from ppend[1].chunks(trim=0)
+                    tail = PointVector.from_points(pts, self.ctx).text()
+                    yield memoryview(tail)[:-2]
+                return pieces()
+        return iter([memoryview(self.text())[:-2]])
 
     def __repr__(self):
         body = self.text().tobytes().decode()

@@ -204,15 +204,11 @@ def _feed(h, obj):
     """Stream str(obj) into the hash without materialising it: byte-identical to
     str(input_list).encode('utf-8') for the object kinds on the AC20 path; device vectors
     contribute text formatted by csrc/format.hip."""
-    if isinstance(obj, PointVector):
+    if isinstance(obj, (PointVector, ScalarVector)):
         h.update(b"[")
         if len(obj):
-            h.update(memoryview(obj.text())[:-2])
-        h.update(b"]")
-    elif isinstance(obj, ScalarVector):
-        h.update(b"[")
-        if len(obj):
-            h.update(memoryview(obj.text())[:-2])
+            for piece in obj.text_chunks():      # hashed piece by piece while the rest is still on the link
+                h.update(memoryview(piece))
         h.update(b"]")
     elif isinstance(obj, AffineForm):
         _feed(h, obj.coeffs)
