@@ -293,6 +293,12 @@ int vmpc_format_scalars_chunked_dev(vmpc_ctx *ctx, const void *scalars, size_t n
 int vmpc_host_alloc(size_t bytes, void **out);
 int vmpc_host_free(void *p);
 
+/* out = A + c * Q + c^2 * B on the HOST, affine x || y (64 bytes) in and out, c a canonical residue: the commitment
+ * fold Q' = A * Q**c * B**(c**2) of compressed_pivot.py:66 / :180, whose normalised value the reference transcript
+ * hashes every round (no device, no context). */
+int vmpc_ed25519_fold_commitment_host(const uint8_t A[64], const uint8_t Q[64], const uint8_t B[64],
+                                      const uint8_t c[32], uint8_t out[64]);
+
 /* ---- BN-256 G1 / G2 (Pinocchio prover MSMs) ----------------------------------
  * The eight sums of verifiable_mpc/trinocchio/pynocchio.py:229-246
  *     apply_to_list(point_add, [int(c[i]) * evalkey[...] for i in qap.indices_mid])

@@ -163,7 +163,29 @@ int main() {
         std::istringstream is(line);
         std::string cmd;
         is >> cmd;
-        if (cmd == "h51mul" || cmd == "h51inv") {
+        if (cmd == "h51lin3") {
+            // A + c Q + c^2 B on the host curve code of fe51_host.h: six coordinates and c in, affine x y out
+            uint32_t w[7][8];
+            for (int i = 0; i < 7; i++) rd_raw8(is, w[i]);
+            uint8_t pts[3][64];
+            for (int i = 0; i < 3; i++) {
+                memcpy(pts[i], w[2 * i], 32);
+                memcpy(pts[i] + 32, w[2 * i + 1], 32);
+            }
+            const fr cf = fr_load(w[6]);
+            uint8_t c2[32];
+            fr_store((uint32_t *)c2, fr_mul(cf, cf));
+            const fe51::el dd = fe51::d2();
+            const fe51::pt a = fe51::pt_from_affine(pts[0]), q = fe51::pt_from_affine(pts[1]), b = fe51::pt_from_affine(pts[2]);
+            const fe51::pt r = fe51::pt_add(fe51::pt_add(a, fe51::pt_mul(q, (const uint8_t *)w[6], dd), dd),
+                                            fe51::pt_mul(b, c2, dd), dd);
+            uint8_t out[64];
+            fe51::pt_to_affine(out, r);
+            uint32_t ox[8], oy[8];
+            memcpy(ox, out, 32);
+            memcpy(oy, out + 32, 32);
+            std::cout << to_hex(ox, 8) << " " << to_hex(oy, 8) << "\n";
+        } else if (cmd == "h51mul" || cmd == "h51inv") {
             // the host-only 51-bit-limb field (fe51_host.h): bytes in, canonical bytes out
             uint32_t wa[8], wb[8] = {1, 0, 0, 0, 0, 0, 0, 0};
             rd_raw8(is, wa);

@@ -90,6 +90,29 @@ def test_host_51_bit_field(harness):
     assert harness(lines) == want
 
 
+def test_host_commitment_fold(harness):
+    """fe51_host.h curve code behind vmpc_ed25519_fold_commitment_host: A + c Q + c^2 B (compressed_pivot.py:66)
+    against the oracle's point arithmetic, identity operands and the doubling case of the unified addition included"""
+    rng = random.Random(66)
+
+    def rnd_pt():
+        return ed.pt_affine(ed.pt_repeat(ed.BASE, rng.randrange(1, ELL)))
+    ident = (0, 1)
+    cases = [(rnd_pt(), rnd_pt(), rnd_pt(), rng.randrange(ELL)) for _ in range(12)]
+    cases += [(ident, rnd_pt(), rnd_pt(), rng.randrange(ELL)), (rnd_pt(), ident, ident, 5), (rnd_pt(), rnd_pt(), rnd_pt(), 0),
+              (rnd_pt(), rnd_pt(), rnd_pt(), 1), (rnd_pt(), rnd_pt(), rnd_pt(), ELL - 1)]
+    p0 = rnd_pt()
+    cases.append((p0, p0, p0, 2))
+    lines, want = [], []
+    for A, Q, Bp, c in cases:
+        lines.append("h51lin3 " + " ".join(hx(v) for v in (A[0], A[1], Q[0], Q[1], Bp[0], Bp[1], c)))
+        ext = lambda a: (a[0], a[1], 1)
+        R = ed.pt_add(ed.pt_add(ext(A), ed.pt_repeat(ext(Q), c)), ed.pt_repeat(ext(Bp), c * c))
+        x, y = ed.pt_affine(R)
+        want.append(f"{hx(x)} {hx(y)}")
+    assert harness(lines) == want
+
+
 def _limbs_value(limbs):
     return sum(v << ((51 * i + 1) // 2) for i, v in enumerate(limbs))
 

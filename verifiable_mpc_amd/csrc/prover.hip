@@ -565,6 +565,26 @@ static void p4_affine_pair(const uint8_t ext[256], uint8_t out_a[64], uint8_t ou
 }
 
 // everything of a round that runs on the stream; c_mem as in p4_fold_dots (the fold before it was queued with it)
+// Q' = A + c Q + c^2 B on the HOST (compressed_pivot.py:66: Q' = A * Q**c * B**(c**2)), affine x || y in and out.
+// The reference transcript hashes Q' normalised, so any representative will do, and the host does the two 253-bit
+// ladders in ~0.1 ms (fe51_host.h) - as a 3-term MSM on a side stream it was ~20 launches and three blocking
+// uploads per round, all of them queued behind the round's generator fold.
+extern "C" int vmpc_ed25519_fold_commitment_host(const uint8_t A[64], const uint8_t Q[64], const uint8_t B[64],
+                                                 const uint8_t c[32], uint8_t out[64]) {
+    if (!A || !Q || !B || !c || !out) return VMPC_E_INVAL;
+    uint32_t cw[8];
+    memcpy(cw, c, 32);
+    if (fr_geq_l(cw)) return VMPC_E_NONCANON;
+    const fr cf = fr_load(cw);
+    uint8_t c2[32];
+    fr_store((uint32_t *)c2, fr_mul(cf, cf));
+    const fe51::el dd = fe51::d2();
+    const fe51::pt a = fe51::pt_from_affine(A), q = fe51::pt_from_affine(Q), b = fe51::pt_from_affine(B);
+    const fe51::pt r = fe51::pt_add(fe51::pt_add(a, fe51::pt_mul(q, c, dd), dd), fe51::pt_mul(b, c2, dd), dd);
+    fe51::pt_to_affine(out, r);
+    return VMPC_OK;
+}
+
 static int p4_round_enqueue(vmpc_p4 *p, const uint32_t *c_mem) {
     vmpc_ctx *ctx = p->ctx;
     if (p4_jump_due(p)) {
