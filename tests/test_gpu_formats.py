@@ -133,3 +133,41 @@ def test_the_switch_changes_the_challenges(vm):
             vm.set_reference_format(**prev)
     assert len(set(seen.values())) == len(VARIANTS), {k: hex(v[0])[:12] for k, v in seen.items()}
     assert vm.get_reference_format() == {"point_brackets": "[]", "coord_signed": False, "scalar_signed": True}
+
+
+def test_text_delivered_in_pieces_equals_the_whole(vm, monkeypatch):
+    """vmpc_format_*_chunked_dev: the transcript text of a long vector reaches the host in pieces that are hashed as
+    they land (pivot._feed over text_chunks); here with 4-KiB pieces over a few thousand elements: the pieces joined are
+    the text formatted in one go minus its trailing separator, for points and for scalars, and a folded vector whose
+    text was produced slice by slice (PointVector.fold(stream_text=True)) hashes like the plain fold's."""
+    rng = random.Random(4242)
+    n = 3000
+    ctx = vm.get_context()
+    g = vm.PointVector.fixed_base(vm.Ed25519Point.generator, [rng.randrange(1, ELL) for _ in range(n)], keep_proj=True)
+    sv = vm.ScalarVector.from_ints([rng.randrange(ELL) for _ in range(n)])
+    whole_g, whole_s = bytes(g.text()), bytes(sv.text())
+    side_cls = type(ctx)
+    monkeypatch.setattr(side_cls, "TEXT_CHUNK_BYTES", 4096)
+    g.text_begin()
+    sv.text_begin()
+    assert g._pending_text[1].chunk_bytes == 4096
+    pieces = [bytes(p) for p in g.text_chunks()]
+    assert len(pieces) > 100 and b"".join(pieces) == whole_g[:-2]
+    assert b"".join(bytes(p) for p in sv.text_chunks()) == whole_s[:-2]
+    # a second pass over an already delivered text, and the synchronous path, give the same bytes
+    assert b"".join(bytes(p) for p in g.text_chunks()) == whole_g[:-2]
+    assert bytes(g.text()) == whole_g
+    # folds: slice by slice (512 + 512 + 384 elements here) against one launch
+    monkeypatch.setattr(vm.PointVector, "TEXT_SLICE", 512)
+    c = rng.randrange(ELL)
+    half = 1408
+    plain = g[:half].fold(g[half:2 * half], c)
+    sliced = g[:half].fold(g[half:2 * half], c, stream_text=True)
+    assert bytes(plain.text())[:-2] == b"".join(bytes(p) for p in sliced.text_chunks())
+    assert plain.affine_array().tobytes() == sliced.affine_array().tobytes()
+    # g + [h] right after g: the parent's text is reused, the extra point formatted on its own
+    h = vm.Ed25519Point.repeat(vm.Ed25519Point.generator, 77)
+    gh = g + [h]
+    joined = b"".join(bytes(p) for p in gh.text_chunks())
+    fresh = vm.PointVector.from_points(g.to_points() + [h])
+    assert joined == bytes(fresh.text())[:-2]

@@ -123,6 +123,27 @@ def test_product_never_imports_the_oracle():
                 assert "from oracle" not in text and "import oracle" not in text, f
 
 
+def test_commitment_fold_on_the_host_matches_the_oracle():
+    """vmpc_ed25519_fold_commitment_host (host arithmetic inside the HIP library, no device): Q' = A * Q**c * B**(c**2)
+    of compressed_pivot.py:66 as the oracle computes it, normalised - what the reference transcript hashes"""
+    import random
+    from oracle import ed25519_ref as ed
+    rng = random.Random(180)
+    for trial in range(6):
+        pts = [ed.pt_repeat(ed.BASE, rng.randrange(1, ed.ELL)) for _ in range(3)]
+        c = [rng.randrange(ed.ELL), 0, 1, ed.ELL - 1, rng.randrange(ed.ELL), 2][trial]
+        want = ed.pt_affine(ed.pt_add(ed.pt_add(pts[0], ed.pt_repeat(pts[1], c)), ed.pt_repeat(pts[2], c * c)))
+        enc = [b"".join(v.to_bytes(32, "little") for v in ed.pt_affine(p)) for p in pts]
+        raw = vm._native.fold_commitment_host(enc[0], enc[1], enc[2], c)
+        assert (int.from_bytes(raw[:32], "little"), int.from_bytes(raw[32:], "little")) == want
+    with pytest.raises(vm._native.VmpcError):           # a challenge that is not a canonical residue
+        lib = vm._native.load_library()
+        import ctypes
+        out = ctypes.create_string_buffer(64)
+        vm._native._check(lib.vmpc_ed25519_fold_commitment_host(enc[0], enc[1], enc[2], (ed.ELL).to_bytes(32, "little"), out),
+                          "vmpc_ed25519_fold_commitment_host")
+
+
 def test_missing_gpu_fails_loudly():
     n, _ = vm._native.backend_info()
     if n >= 1:
