@@ -70,26 +70,26 @@ k_scan_add(OutT *__restrict__ out, const OutT *__restrict__ tile_offsets, size_t
         if (base + i < n) out[base + i] += off;
 }
 
-// up to 16384 items in ONE workgroup of 1024 threads (the histogram of a short MSM: three launches for 8192
-// counters cost three dispatches)
-#define VMPC_SCAN_SMALL_MAX 16384
+// up to 32768 items in ONE workgroup of 1024 threads (the histogram of a short MSM - 16640 counters in a late
+// prover round: three launches cost three dispatches)
+#define VMPC_SCAN_SMALL_MAX 32768
 template <typename InT, typename OutT>
 __global__ void __launch_bounds__(1024)
 k_scan_small(const InT *__restrict__ in, OutT *__restrict__ out, OutT *__restrict__ total_out, size_t n) {
     __shared__ OutT lds[16];
-    const int per = (int)((n + 1023) / 1024);                  // <= 16 consecutive items per thread
+    const int per = (int)((n + 1023) / 1024);                  // <= 32 consecutive items per thread
     const size_t base = (size_t)threadIdx.x * per;
-    OutT v[16];
+    OutT v[32];
     OutT s = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < 32; i++) {
         v[i] = (i < per && base + i < n) ? (OutT)in[base + i] : (OutT)0;
         s += v[i];
     }
     OutT tot;
     OutT ex = vmpc_block_excl_scan<OutT>(s, &tot, lds);
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < 32; i++) {
         if (i < per && base + i < n) out[base + i] = ex;
         ex += v[i];
     }
