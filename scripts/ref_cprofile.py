@@ -23,3 +23,6 @@ proof = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, 777, gf, transcr
 pr.disable()
 print("prove ms", (time.perf_counter() - t0) * 1e3)
 st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+st.print_callers("sync")
+st.print_callers("upload")
+st.print_callers("download")

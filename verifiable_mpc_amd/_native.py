@@ -277,6 +277,7 @@ class PendingText:
     def __init__(self, ctx, pinned, dev, cap, keepalive=None, chunk_bytes=0):
         self.ctx, self.pinned, self.dev, self.cap = ctx, pinned, dev, cap
         self.chunk_bytes = chunk_bytes
+        self.n_chunks = -(-(cap - 16) // chunk_bytes) if chunk_bytes else 0      # the library copies cap - 16 bytes
         # the SOURCE vector's device block belongs to another context's block cache: hold it until this
         # stream has been synchronised, so that it cannot be recycled under the formatter's reads
         self.keepalive = keepalive
@@ -317,11 +318,23 @@ class PendingText:
                 return
             k += 1
 
+    def _landed(self):
+        """every byte this text's launches write has arrived (nothing of it is still queued on the stream)"""
+        if self.dev is None:
+            return True                               # result() synchronised the stream behind the copy
+        if self.chunk_bytes:
+            return int(np.frombuffer(self.pinned.array[:16], dtype=np.uint32)[2]) >= self.n_chunks
+        return False
+
     def __del__(self):
-        # the pinned block goes back to the pool only when nobody can still read the text
+        # the pinned block goes back to the pool only when nobody can still read the text - and only when the copies
+        # into it are over.  Synchronising the stream for that used to cost 30 ms per reference-transcript proof: a
+        # round's text dies when the next round's vector replaces it, i.e. right after the NEXT text's launches were
+        # queued on the same stream, and the wait covered those too.
         try:
             if self.pinned is not None and self.ctx is not None and self.ctx.handle:
-                self.ctx.sync()
+                if not self._landed():
+                    self.ctx.sync()
                 self._view = None
                 self.keepalive = None
                 self.ctx._give_pinned(self.cap + 16, self.pinned)
