@@ -107,13 +107,20 @@ gk_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ 
 }
 
 // ---- reduce: sum_b b * B_b per window ---------------------------------------------------------
-template <class C, class F>
+// SPLIT = 2 (few chunks: a 17-row table's single bucket set is 2^15 one-bucket chunks, 512 waves for 1024 SIMDs):
+// TWO lanes per chunk share the offset ladder - lane kind 0 takes the low `hb` bits of the chunk index, kind 1 the
+// high bits followed by hb doublings - and the workgroup tree adds the two halves like any two lanes' sums.  The
+// kinds sit on whole waves (threads 0..127 / 128..255), so no wave runs both codes.  Depth 9 x (doubling + addition)
+// instead of 15 x for 2^15 chunks; the workgroup covers 128 chunks, so a window leaves twice the partial sums.
+template <class C, class F, int SPLIT>
 __global__ void __launch_bounds__(MSM_BLOCK)
 gk_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ counts, int nb, int chunks,
-          int chunk_len, int log2_chunk_len, int red_blocks, uint32_t *__restrict__ partials) {
+          int chunk_len, int log2_chunk_len, int red_blocks, int hb, uint32_t *__restrict__ partials) {
     __shared__ uint32_t lds[MSM_BLOCK * C::ACC_WORDS];
+    constexpr int PER = MSM_BLOCK / SPLIT;                 // chunks per workgroup
     const int w = blockIdx.y;
-    const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
+    const int kind = SPLIT == 1 ? 0 : (int)threadIdx.x / PER;
+    const int chunk = blockIdx.x * PER + (int)threadIdx.x % PER;
     typename C::acc_t contrib = jac_identity<F>();
     if (chunk < chunks) {
         const int lo = chunk * chunk_len;
@@ -122,17 +129,21 @@ gk_reduce(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ cou
         typename C::acc_t acc = jac_identity<F>(), sum = jac_identity<F>();
         for (int j = chunk_len - 1; j >= 0; j--) {
             if (cw[j]) acc = jac_add<F>(acc, C::acc_ld(bw + (size_t)C::ACC_WORDS * j));
-            sum = jac_add<F>(sum, acc);
+            if (kind == 0) sum = jac_add<F>(sum, acc);
         }
-        if (chunk != 0) {
+        // this lane's share of the multiplier `chunk` of base = chunk_len * acc
+        const int mult = SPLIT == 1 ? chunk : (kind == 0 ? (chunk & ((1 << hb) - 1)) : (chunk >> hb));
+        if (mult != 0) {
             typename C::acc_t base = acc;
             for (int k = 0; k < log2_chunk_len; k++) base = jac_dbl<F>(base);
             typename C::acc_t r = jac_identity<F>();
-            int top = 31 - __clz(chunk);
+            int top = 31 - __clz(mult);
             for (int k = top; k >= 0; k--) {
                 r = jac_dbl<F>(r);
-                if ((chunk >> k) & 1) r = jac_add<F>(r, base);
+                if ((mult >> k) & 1) r = jac_add<F>(r, base);
             }
+            if (SPLIT > 1 && kind == 1)
+                for (int k = 0; k < hb; k++) r = jac_dbl<F>(r);
             sum = jac_add<F>(sum, r);
         }
         contrib = sum;
@@ -261,6 +272,12 @@ gk_fixed_base(const uint32_t *__restrict__ base, const uint32_t *__restrict__ sc
 
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
+// two lanes per chunk when the plan's chunk-lanes would leave half of the chip's SIMDs without a wave
+static inline bool bn_reduce_split(const msm_plan &p) {
+    return (size_t)p.chunks * p.W <= 32768 && p.chunks >= 512 && (p.chunks & (p.chunks - 1)) == 0 &&
+           p.chunks % (MSM_BLOCK / 2) == 0;
+}
+
 template <class C, class F>
 struct bn_kernels {
     static int prep(vmpc_ctx *ctx, const void *points, size_t n, uint32_t *entries);
@@ -298,16 +315,23 @@ int bn_kernels<C, F>::bucket(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const 
 
 template <class C, class F>
 int bn_kernels<C, F>::reduce(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
-    gk_reduce<C, F><<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, ctx->stream>>>(
-        w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, msm_ilog2(p.chunk_len), p.red_blocks, w.partials);
+    if (bn_reduce_split(p)) {
+        // balance 23 hb (low kind: hb ladder steps) against 23 (bits - hb) + 7 hb (high kind: its steps, then hb doublings)
+        const int bits = msm_ilog2(p.chunks), hb = (23 * bits + 19) / 39;
+        gk_reduce<C, F, 2><<<dim3(2 * p.red_blocks, p.W), MSM_BLOCK, 0, ctx->stream>>>(
+            w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, msm_ilog2(p.chunk_len), 2 * p.red_blocks, hb, w.partials);
+    } else {
+        gk_reduce<C, F, 1><<<dim3(p.red_blocks, p.W), MSM_BLOCK, 0, ctx->stream>>>(
+            w.buckets, w.counts, p.nb, p.chunks, p.chunk_len, msm_ilog2(p.chunk_len), p.red_blocks, 0, w.partials);
+    }
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }
 
 template <class C, class F>
 int bn_kernels<C, F>::final(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, void *out_affine, void *out_jac) {
-    gk_final<C, F><<<1, 64, 0, ctx->stream>>>(w.partials, p.W, p.red_blocks, p.c, (uint32_t *)out_affine,
-                                              (uint32_t *)out_jac);
+    gk_final<C, F><<<1, 64, 0, ctx->stream>>>(w.partials, p.W, bn_reduce_split(p) ? 2 * p.red_blocks : p.red_blocks, p.c,
+                                              (uint32_t *)out_affine, (uint32_t *)out_jac);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }
