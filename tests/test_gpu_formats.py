@@ -171,3 +171,14 @@ def test_text_delivered_in_pieces_equals_the_whole(vm, monkeypatch):
     joined = b"".join(bytes(p) for p in gh.text_chunks())
     fresh = vm.PointVector.from_points(g.to_points() + [h])
     assert joined == bytes(fresh.text())[:-2]
+
+
+@pytest.mark.parametrize("n", [2048, 2049, 16385, 32768, 32769])
+def test_text_offsets_across_the_scan_forms(vm, n):
+    """the formatter's text offsets are an exclusive scan of the items' lengths (csrc/scan.h): one tile, one workgroup
+    (2049 .. 32768 items) and the three-kernel form must give the same text - checked against Python's own decimals"""
+    rng = random.Random(n)
+    vals = [rng.randrange(ELL) >> rng.choice([0, 0, 100, 200, 250]) for _ in range(n)]
+    sv = vm.ScalarVector.from_ints(vals)
+    signed = [v if v <= ELL // 2 else v - ELL for v in vals] if vm.formats.scalar_signed() else vals
+    assert bytes(sv.text()).decode() == "".join(f"{v}, " for v in signed)
