@@ -399,6 +399,167 @@ def other_sizes_timing(vm, ctx, pows):
     return out
 
 
+def commitment_scalars(rng, n):
+    """The distribution of the committed vector [z] that SURVEY.md section 8d measured on the demo circuit
+    (circuit_sat_cb.py:91-103: inputs, gadget witnesses, zero pads, then polynomial evaluations): 54 % zeros, 9 % in
+    {1, 2}, 37 % uniform field elements.  (n, 32) uint8 little-endian, positions shuffled."""
+    a = rand_scalars(rng, n)
+    kind = rng.random(n)
+    a[kind < 0.54] = 0
+    small = (kind >= 0.54) & (kind < 0.63)
+    a[small] = 0
+    a[small, 0] = rng.integers(1, 3, size=int(small.sum()), dtype=np.uint8)
+    return a
+
+
+def distribution_timing(vm, ctx, pows):
+    """Uniform scalars beside the commitment distribution of [z] (zero / one / two buckets hold most of the terms: the
+    tiled sort and the split-bucket path of csrc/msm_sort.hip, msm.hip), at config 2's and the headline's size: one
+    commitment alone (host synchronises after each), back to back on one stream, and K per pass over the CRS table
+    (vmpc_msm_table_batch_dev).  Results are checked by the exponent identity against the product's fixed-base kernel."""
+    group = vm.EllipticCurve("Ed25519", "projective")
+    rng = np.random.default_rng(20200152)
+    out = {}
+    order = vm.groups.ORDER
+    for lg in pows:
+        n = 1 << lg
+        exps = rand_scalars(rng, n)
+        pts = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(exps), keep_proj=False)
+        tab = vm.PointVector(pts.a, None, ctx).precompute([])
+        t_ = tab._table
+        res = ctx.alloc(128)
+        entry = {"crs_table_rows": t_.rows}
+        reps = 20 if lg <= 16 else 10
+        for name, arr in (("uniform", rand_scalars(rng, n)), ("commitment_distribution", commitment_scalars(rng, n))):
+            sc = vm.ScalarVector.from_array(arr)
+            forms = {"prepared_per_call": lambda: ctx.msm(sc.ptr, pts.affine_ptr, n, None, None, 0, res.ptr, None),
+                     "over_crs_table": lambda: ctx.msm_table(t_.ptr, t_.n, 0, sc.ptr, n, None, res.ptr, None, rows=t_.rows)}
+            e = {}
+            want = None
+            for form, fn in forms.items():
+                for _ in range(2):
+                    fn()
+                ctx.sync()
+                got = vm.Ed25519Point.from_proj_bytes(ctx.download(res.ptr, 128).tobytes()[:96]).normalize()
+                if want is None:
+                    tot = exponent_sum(arr, exps, order)
+                    want = vm.PointVector.fixed_base(group.generator, [tot], keep_proj=False)[0]
+                assert got == want, f"MSM property check failed ({name}, {form}, n=2^{lg})"
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                    ctx.sync()
+                alone = (time.perf_counter() - t0) / reps
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                ctx.sync()
+                b2b = (time.perf_counter() - t0) / reps
+                e[form] = {"alone_ms": round(alone * 1e3, 4), "back_to_back_ms": round(b2b * 1e3, 4),
+                           "M_scalar_mults_per_s_back_to_back": round(n / b2b / 1e6, 1)}
+            e["nonzero_fraction"] = round(float((arr != 0).any(axis=1).mean()), 4)
+            entry[name] = e
+            del sc
+        for form in ("prepared_per_call", "over_crs_table"):
+            entry[f"commitment_over_uniform_{form}_alone"] = round(
+                entry["commitment_distribution"][form]["alone_ms"] / entry["uniform"][form]["alone_ms"], 3)
+        # K commitments per pass over the table (distinct uniform scalar vectors): the sort is per vector, the bucket
+        # reduction and the window recombination are paid once per pass
+        per_pass = {}
+        for K in (2, 4, 8):
+            vecs = [vm.ScalarVector.from_array(rand_scalars(rng, n)) for _ in range(K)]
+            outk = ctx.alloc(128 * K)
+            try:
+                for _ in range(2):
+                    ctx.msm_table_batch(t_.ptr, t_.n, 0, [v.ptr for v in vecs], n, None, outk.ptr, None, rows=t_.rows)
+                ctx.sync()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    ctx.msm_table_batch(t_.ptr, t_.n, 0, [v.ptr for v in vecs], n, None, outk.ptr, None, rows=t_.rows)
+                ctx.sync()
+                dt = (time.perf_counter() - t0) / reps
+                per_pass[f"K{K}"] = {"ms_per_pass": round(dt * 1e3, 4), "ms_per_commitment": round(dt / K * 1e3, 4),
+                                     "M_scalar_mults_per_s": round(K * n / dt / 1e6, 1)}
+            except Exception as ex:
+                per_pass[f"K{K}"] = {"error": f"{type(ex).__name__}: {ex}"}
+            del vecs, outk
+        entry["commitments_per_pass_over_crs_table"] = per_pass
+        out[f"n2^{lg}"] = entry
+        del tab, t_, pts
+    out["checked"] = "exponent identity against the product's fixed-base kernel, every (distribution, form)"
+    return out
+
+
+def clocks_sample():
+    """one reading of the GPU's clocks and power cap (rocm-smi), so that box-to-box spread of the headline has
+    something to be read against; best effort"""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    out = {}
+    try:
+        txt = subprocess.run([exe, "-d", "0", "--showclocks", "--showmaxpower", "--showpower", "--showperflevel"],
+                             capture_output=True, text=True, timeout=20).stdout
+        for line in txt.splitlines():
+            # "GPU[0]\t\t: sclk clock level: 1: (2400Mhz)" / "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0"
+            parts = [p_.strip() for p_ in line.split(":")]
+            if len(parts) < 3 or not parts[0].startswith("GPU["):
+                continue
+            low = parts[1].lower()
+            if any(w in low for w in ("sclk", "mclk", "fclk", "power", "performance level")):
+                out[parts[1][:60]] = ": ".join(parts[2:])
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def pinocchio_timing(vm, ctx, n_pow):
+    """BASELINE config 5 as ONE number: pynocchio.compute_proof (trinocchio/pynocchio.py:229-246 of the reference -
+    seven G1 sums and one twist sum over the evaluation key, c and h shared between them) over a prepared key of 2^n_pow
+    terms, scalars handed over as (n, 32) arrays.  Synthetic key (every entry the generator): timing only - parity of
+    compute_proof is tests/test_gpu_bn256.py::test_compute_proof_matches_reference_fixture."""
+    from verifiable_mpc_amd import pynocchio as pn
+    n = 1 << n_pow
+    g1 = (1).to_bytes(32, "little") + (pn.P - 2).to_bytes(32, "little")
+    g2 = b"".join(v.to_bytes(32, "little") for v in (
+        64746500191241794695844075326670126197795977525365406531717464316923369116492,
+        21167961636542580255011770066570541300993051739349375019639421053990175267184,
+        17778617556404439934652658462602675281523610326338642107814333856843981424549,
+        20666913350058776956210519119118544732556678129809273996262322366050359951122))
+    rng = np.random.default_rng(3)
+    key = pn.PreparedKey.__new__(pn.PreparedKey)
+    key.ctx, key.mid, key.vectors = ctx, list(range(n)), {}
+    key.mid_index, key.zk_missing = np.arange(n), {}
+    for name in list(pn._ELEMENTS) + ["h*g1"]:
+        grp, gen, width = (2, g2, 128) if name.endswith("g2") else (1, g1, 64)
+        extra = len(pn._ELEMENTS[name][1]) if name in pn._ELEMENTS else 0
+        # distinct points e_i * G: a repeated point would send every bucket sum down the doubling branch
+        ex = rng.integers(0, 256, size=(n + extra, 32), dtype=np.uint8)
+        ex[:, 31] &= 0x7F
+        dg, de = ctx.upload(np.frombuffer(gen, np.uint8)), ctx.upload(ex)
+        pts = ctx.alloc(width * (n + extra))
+        ctx.bn256_fixed_base(grp, dg.ptr, de.ptr, n + extra, pts.ptr)
+        ctx.sync()
+        key.vectors[name] = pn._KeyVector.from_device(ctx, grp, pts, n + extra)
+
+    class Delta:
+        v, w, y = 11, 22, 33
+    c = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    c[:, 31] &= 0x7F
+    h = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    h[:, 31] &= 0x7F
+    first = pn.compute_proof(None, c, h, key, Delta)
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        proof = pn.compute_proof(None, c, h, key, Delta)
+        times.append((time.perf_counter() - t0) * 1e3)
+    assert proof == first
+    return {"whole_proof_ms": round(sorted(times)[len(times) // 2], 3), "whole_proof_ms_min": round(min(times), 3),
+            "terms_per_sum": n, "sums": "7 x G1 + 1 x G2 (pynocchio.compute_proof over a PreparedKey)",
+            "key": "synthetic: distinct multiples of the generator, prepared (tabulated) once, untimed"}
+
+
 def sharded_prove_timing(vm, ctx, n_pow, world, rank, dist, torch, comm=None):
     """AC20 Protocol 5 (compact transcript) with g_hat in `world` blocks, one per rank
     (verifiable_mpc_amd/sharded.py): one exchange of two 128-byte points per rank and round.  With `comm` the
@@ -1022,6 +1183,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 (255-bit modular integers as 10 limbs of 25.5 bits, 32x32->64 multiply-adds)", "data": "synthetic",
             "checked": checked,
+            "checked_how": "exponent identity sum_i s_i (e_i B) == (sum_i s_i e_i mod l) B against the PRODUCT's own "
+                           "fixed-base kernel (not the oracle: tests/test_gpu_msm_large.py pins this path and that "
+                           "kernel against the C oracle bit for bit)",
             "config": {"workload": f"Pedersen vector-commitment MSM, n=2^{args.log2n} Ed25519 "
                                    f"generators per GPU, uniform 252-bit scalars",
                        "terms_per_gpu": n, "total_terms": world * n, "launches_in_flight": depth,
@@ -1050,6 +1214,7 @@ def main():
                                       if shard.collective else "none"),
                        "dist_backend": args.dist_backend if dist else None,
                        "comm": comm_info,
+                       "gpu_clocks": clocks_sample() if rank == 0 else None,
                        "launched_by": ("bench.py itself (child processes)" if os.environ.get("VMPC_BENCH_SELF_LAUNCHED")
                                        else "external launcher" if "WORLD_SIZE" in os.environ else "plain process")},
             "roofline": {"bound": "hbm", "kernel": "k_msm_bucket", "achieved": achieved,
@@ -1108,10 +1273,18 @@ def main():
             except Exception as e:
                 line["msm_other_sizes"] = {"error": f"{type(e).__name__}: {e}"}
             try:
+                line["msm_distributions"] = distribution_timing(vm, ctx, (16, 20))
+            except Exception as e:
+                line["msm_distributions"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
                 line["bn256_n2^18"] = {k: (round(v, 2) if isinstance(v, float) else v)
                                        for k, v in bn256_timing(vm, ctx, 18).items()}
             except Exception as e:
                 line["bn256_n2^18"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                line["bn256_n2^18"].update(pinocchio_timing(vm, ctx, 18))
+            except Exception as e:
+                line["bn256_n2^18"]["whole_proof_error"] = f"{type(e).__name__}: {e}"
     sharded_info, sharded_weak, cfg4 = None, None, None
     if dist and world > 1 and args.config4_log2n > 0:
         enter("config 4")

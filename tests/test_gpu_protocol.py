@@ -144,6 +144,45 @@ def test_protocol5_first_preimage_text(vm, golden_small, monkeypatch):
     assert texts == [h["text"] for h in case["hashes"]]
 
 
+def test_hash_input_dump_is_what_gets_hashed(vm, golden_small, monkeypatch):
+    """the DEBUG dump of logger "compressed_pivot_hash_inputs" (compressed_pivot.py:56-58,122-124) holds the very
+    pre-images of the reference fixture: Protocol 5's list once (the reference logs it before appending the 0 / 1
+    tails), then one list per round, for prover and verifier"""
+    import logging
+    case = golden_small["p5"][0]
+    group, gens = build_generators(vm, case, monkeypatch, case["seed"] + 1)
+    gf = vm.GF(group.order)
+    lg = logging.getLogger("compressed_pivot_hash_inputs")
+    records = []
+
+    class Keep(logging.Handler):
+        def emit(self, record):
+            records.append(record.getMessage())
+    handler = Keep()
+    lg.addHandler(handler)
+    lg.setLevel(logging.DEBUG)
+    try:
+        x = [gf(h2i(v)) for v in case["x"]]
+        L = vm.pivot.LinearForm([gf(h2i(v)) for v in case["L"]])
+        P = vm.Ed25519Point((h2i(case["P"][0]), h2i(case["P"][1]), 1))
+        monkeypatch.setattr(vm.compressed_pivot, "prng", random.Random(case["seed"] + 2))
+        proof = vm.compressed_pivot.protocol_5_prover(gens, P, L, gf(h2i(case["y"])), x, h2i(case["gamma"]), gf)
+        n_prover = len(records)
+        assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, gf(h2i(case["y"])), proof, gf) is True
+    finally:
+        lg.setLevel(logging.INFO)
+        lg.removeHandler(handler)
+    texts = [h["text"] for h in case["hashes"]]
+    tail = ", 0, 'First hash of compressed pivot']"
+    assert texts[0].endswith(tail)
+    want = [texts[0][:-len(tail)] + "]"] + texts[2:]
+    got = [r.split("input_list=\n", 1)[1] for r in records]
+    assert got[:n_prover] == want and got[n_prover:] == want
+    assert records[0].startswith("Method protocol_5_prover: Before fiat_shamir_hash, input_list=")
+    assert records[n_prover].startswith("Method protocol_5_verifier:")
+    assert records[n_prover + 1].startswith("Method protocol_4_verifier:")
+
+
 def test_protocol5_n1023_device_mode(vm, golden_n1023, monkeypatch, record_hashes):
     case = golden_n1023
     group, gens = build_generators(vm, case, monkeypatch, case["seed"] + 1)

@@ -79,11 +79,49 @@ def test_install_patches_reference_modules(monkeypatch):
         m = types.ModuleType(pkg + name)
         mods[pkg + name] = m
         monkeypatch.setitem(sys.modules, pkg + name, m)
+    original_calls = []
+    mods[pkg + ".pivot"].vector_commitment = lambda x, gamma, g, h: original_calls.append(h) or "theirs"
     patched = vm.install(pkg)
-    assert mods[pkg + ".pivot"].vector_commitment is pivot.vector_commitment
-    assert mods[pkg + ".compressed_pivot"].protocol_5_prover is vm.compressed_pivot.protocol_5_prover
-    assert mods[pkg + ".circuit_sat_r1cs"].create_generators is vm.circuit_sat.create_generators
-    assert len(patched) == 8
+    assert mods[pkg + ".pivot"].vector_commitment.__vmpc_accelerated__ is pivot.vector_commitment
+    assert mods[pkg + ".compressed_pivot"].protocol_5_prover.__vmpc_accelerated__ is vm.compressed_pivot.protocol_5_prover
+    assert mods[pkg + ".circuit_sat_r1cs"].create_generators.__vmpc_accelerated__ is vm.circuit_sat.create_generators
+    assert mods[pkg + ".pivot"].prove_linear_form_eval.__vmpc_accelerated__ is pivot.prove_linear_form_eval
+    assert len(patched) == 10
+    # a base that is not an Ed25519 element goes to what was there before; installing twice wraps once
+    assert mods[pkg + ".pivot"].vector_commitment([1], 2, [5], 7) == "theirs" and original_calls == [7]
+    before = mods[pkg + ".pivot"].vector_commitment
+    vm.install(pkg)
+    assert mods[pkg + ".pivot"].vector_commitment is before
+    assert f"{pkg}.pivot.vector_commitment" in vm.uninstall(pkg)
+    assert mods[pkg + ".pivot"].vector_commitment([1], 2, [5], 8) == "theirs"
+    assert not hasattr(mods[pkg + ".pivot"], "fiat_shamir_hash")
+
+
+def test_group_of_a_call_is_read_off_its_arguments():
+    """what decides between the GPU path and the reference's own function (dropin.py): order l over GF(2^255 - 19)
+    with three coordinates - not the Python class"""
+    import types
+    from verifiable_mpc_amd import groups
+    G = vm.Ed25519Point.generator
+    assert groups.is_ed25519_element(G) and groups.is_ed25519_group(vm.Ed25519Point)
+
+    def foreign(order, modulus, ncoords):
+        cls = type("Foreign", (), {"order": order, "field": types.SimpleNamespace(modulus=modulus)})
+        obj = cls()
+        obj.value = [types.SimpleNamespace(value=1)] * ncoords
+        return obj
+    assert groups.is_ed25519_element(foreign(groups.ORDER, groups.P, 3))
+    assert not groups.is_ed25519_element(foreign(groups.ORDER, groups.P, 4))        # 'extended' coordinates
+    assert not groups.is_ed25519_element(foreign(groups.ORDER, groups.P, 2))        # 'affine'
+    assert not groups.is_ed25519_element(foreign(groups.ORDER + 2, groups.P, 3))    # BN256 (jacobian: 3 coordinates)
+    assert not groups.is_ed25519_element(7) and not groups.is_ed25519_element(None)
+    import enum
+    theirs = enum.Enum("PivotChoice", "pivot compressed koe")
+    assert vm.circuit_sat.choice_name(theirs.compressed) == "compressed" == vm.circuit_sat.choice_name("compressed")
+    with pytest.raises(NotImplementedError):
+        vm.create_generators(3, theirs.koe, vm.Ed25519Point)
+    with pytest.raises(NotImplementedError, match="only Ed25519"):
+        vm.create_generators(3, theirs.compressed, types.SimpleNamespace(generator=foreign(11, 23, 1), order=11))
 
 
 def test_circuit_sat_harness_names_delegate_to_the_reference(monkeypatch):
@@ -107,7 +145,7 @@ def test_circuit_sat_harness_names_delegate_to_the_reference(monkeypatch):
     assert vm.circuit_sat_prover({"g": []}, None, [1], None) == {"proof": 1}
     assert vm.circuit_sat_verifier({"proof": 1}, {"g": []}, None, None, vm.PivotChoice.pivot) == {"ok": True}
     assert calls == [("p", cb.PivotChoice.compressed), ("v", cb.PivotChoice.pivot)]
-    assert mods[pkg + ".pivot"].vector_commitment is pivot.vector_commitment          # install() ran
+    assert mods[pkg + ".pivot"].vector_commitment.__vmpc_accelerated__ is pivot.vector_commitment    # install() ran
     monkeypatch.setattr(vm.circuit_sat, "REFERENCE_PACKAGE", "no_such_reference_pkg")
     with pytest.raises(ImportError, match="circuit front end"):
         vm.circuit_sat_prover({}, None, [], None)
@@ -206,3 +244,31 @@ def test_install_mpc_patches_reference_module(monkeypatch):
     patched = mpc_ac20.install_mpc(pkg)
     assert sys.modules[pkg + ".mpc_ac20"].protocol_5_prover is mpc_ac20.protocol_5_prover
     assert len(patched) == 4
+
+
+def test_hash_input_dump_streams_str_of_the_list():
+    """compressed_pivot.py:56-58,122-124: logger "compressed_pivot_hash_inputs" at DEBUG gets the pre-image; here in
+    pieces (one record per LOG_PIECE bytes) that concatenate to str(input_list); at INFO nothing is formatted"""
+    import logging
+    lg = logging.getLogger("compressed_pivot_hash_inputs")
+    records = []
+
+    class Keep(logging.Handler):
+        def emit(self, record):
+            records.append(record.getMessage())
+    handler = Keep()
+    lg.addHandler(handler)
+    G = vm.Ed25519Point.generator
+    lst = [G, {"g": [G, G]}, "s", pivot.LinearForm([1, 2])]
+    try:
+        pivot.log_hash_input(lg, "protocol_4_prover", lst)
+        assert records == []
+        lg.setLevel(logging.DEBUG)
+        old, pivot._LogSink.LOG_PIECE = pivot._LogSink.LOG_PIECE, 64
+        pivot.log_hash_input(lg, "protocol_4_prover", lst)
+        pivot._LogSink.LOG_PIECE = old
+    finally:
+        lg.setLevel(logging.INFO)
+        lg.removeHandler(handler)
+    assert records[0].startswith("Method protocol_4_prover: Before fiat_shamir_hash, input_list=\n[[1511")
+    assert len(records) > 3 and "".join(r.split("=\n", 1)[1] for r in records) == str(lst)

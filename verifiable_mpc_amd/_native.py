@@ -384,16 +384,19 @@ class Context:
 
     TEXT_CHUNK_BYTES = 8 << 20      # pieces of the transcript text on their way to the host (PendingText.chunks)
 
-    def format_begin(self, kind, src_ptr, n, is_signed=True, keepalive=None):
+    def format_begin(self, kind, src_ptr, n, is_signed=True, keepalive=None, own_signal=False):
         """enqueue formatting + D2H of a vector's transcript text; returns a PendingText.
-        `keepalive`: the owner of `src_ptr` when it lives in another context's block cache"""
+        `keepalive`: the owner of `src_ptr` when it lives in another context's block cache.
+        `own_signal`: deliver in pieces with a landed count whatever the size, so that a reader of THIS text waits
+        for this text only - not, through a stream synchronisation, for everything queued behind it (the slices of
+        PointVector.fold(stream_text=True) share one stream)"""
         per = (3 * 79 + 8) if kind == "points" else (78 + 3)       # 78 digits + a sign per coordinate
         cap = n * per + 16
         pinned = self._take_pinned(cap + 16)
         dev = DeviceBuffer(self, cap)
         host_len = ctypes.c_void_p(pinned.ptr)
         host_text = ctypes.c_void_p(pinned.ptr + 16)
-        chunk = self.TEXT_CHUNK_BYTES if cap > 2 * self.TEXT_CHUNK_BYTES else 0
+        chunk = self.TEXT_CHUNK_BYTES if (own_signal or cap > 2 * self.TEXT_CHUNK_BYTES) else 0
         if chunk:
             pinned.array[:16] = 0                                   # length, pieces landed
             if kind == "points":

@@ -14,7 +14,7 @@ from enum import Enum
 from random import SystemRandom
 
 from .device import PointVector
-from .groups import Ed25519Point
+from .groups import Ed25519Point, adopt_notation, as_point, is_ed25519_group
 
 prng = SystemRandom()
 
@@ -26,10 +26,10 @@ class PivotChoice(Enum):
     koe = 3
 
 
-def _our_point(obj):
-    if isinstance(obj, Ed25519Point):
-        return obj
-    return Ed25519Point((int(obj[0]), int(obj[1]), int(obj[2])))
+def choice_name(pivot_choice):
+    """'pivot' / 'compressed' / 'koe' for a member of ANY PivotChoice enum - the reference's callers pass members of
+    circuit_sat_r1cs.PivotChoice (demos/demo_zkp_ac20.py:27,78), not of the class above - or for the bare name"""
+    return getattr(pivot_choice, "name", pivot_choice)
 
 
 # Generators are a CRS: up to this many get a fixed-base table at creation (at most 2 KiB each, capped
@@ -42,16 +42,22 @@ def create_generators(g_length, pivot_choice, group=None, progress_bar=False):
     """Create generators g, h, k with g_i = h ** r_i on the GPU (one lane per generator,
     csrc/exact.hip k_repeat).  Exponents are drawn from `prng` in the reference's order:
     r_0 .. r_{g_length-1}, then k's exponent (circuit_sat_r1cs.py:64,81)."""
-    if pivot_choice not in (PivotChoice.pivot, PivotChoice.compressed):
-        # the KoE pivot lives on BN256 with pairings: not part of the accelerated path
+    choice = choice_name(pivot_choice)
+    if choice not in ("pivot", "compressed"):
+        # the KoE pivot lives on BN256 with pairings: not part of the accelerated path (an installed reference
+        # keeps its own create_generators for it, dropin.py)
         raise NotImplementedError
     assert group is not None
-    h = _our_point(group.generator)
+    if not is_ed25519_group(group):
+        raise NotImplementedError(f"{getattr(group, '__name__', group)}: only Ed25519 (projective) is accelerated; "
+                                  "install() leaves other groups with the reference's own create_generators")
+    adopt_notation(group)
+    h = as_point(group.generator)
     random_exponents = list(prng.randrange(1, group.order) for i in range(g_length))
     if progress_bar:
         print("Generating keys: on device", end="\r")
     g = PointVector.fixed_base(h, random_exponents)
-    if pivot_choice == PivotChoice.pivot:
+    if choice == "pivot":
         if g_length <= PRECOMPUTE_MAX:
             g.precompute([h])
         return {"g": g, "h": h}

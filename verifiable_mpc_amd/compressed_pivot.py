@@ -28,7 +28,7 @@ from random import SystemRandom
 from . import _native, pivot
 from .device import PointVector, ScalarVector, reduce_scalar
 from .groups import EllipticCurvePoint as EllipticCurveElement
-from .groups import Ed25519Point
+from .groups import Ed25519Point, as_point
 
 prng = SystemRandom()
 
@@ -49,11 +49,7 @@ TAIL_BASE = 1 << 16
 
 # ---- group glue on single elements (independent of the is_additive/is_multiplicative flags) ----
 
-def _pt(obj):
-    """Accept our points or any 3-coordinate projective element (e.g. an MPyC point)."""
-    if isinstance(obj, Ed25519Point):
-        return obj
-    return Ed25519Point((int(obj[0]), int(obj[1]), int(obj[2])))
+_pt = as_point      # our points, or any 3-coordinate projective element (e.g. an MPyC point) converted
 
 
 def _gmul(a, b):
@@ -226,10 +222,11 @@ class _Transcript:
             raise ValueError(f"unknown transcript mode {mode!r}")
         self.mode, self.order, self.state = mode, order, state
 
-    def round_challenge(self, round_i, A, B, g_hat, k, Q, L_tilde):
+    def round_challenge(self, round_i, A, B, g_hat, k, Q, L_tilde, who="protocol_4_prover"):
         if self.mode == "reference":
             # compressed_pivot.py:51-59: A, B, Q normalised; g_hat, k as they are
             input_list = [A.normalize(), B.normalize(), g_hat, k, Q.normalize(), L_tilde]
+            pivot.log_hash_input(logger_cp_hin, who, input_list)
             return pivot.fiat_shamir_hash(input_list, self.order)
         self.state = hashlib.sha256(self.state + round_i.to_bytes(4, "little")
                                     + A.to_affine_bytes() + B.to_affine_bytes()).digest()
@@ -498,7 +495,7 @@ def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=N
         g_l, g_r = g_hat[:half], g_hat[half:]
         A = _pt(proof["A" + str(round_i)])
         B = _pt(proof["B" + str(round_i)])
-        c = transcript.round_challenge(round_i, A, B, g_hat, k, Q, L_tilde)
+        c = transcript.round_challenge(round_i, A, B, g_hat, k, Q, L_tilde, who="protocol_4_verifier")
         g_prime = g_l.fold(g_r, c, stream_text=transcript.mode == "reference" and half > 2)
         if transcript.mode == "reference":
             Q = _fold_commitment(A, Q, B, c)
@@ -520,10 +517,11 @@ def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=N
 
 # ---- Protocol 5 ----------------------------------------------------------------------------------------
 
-def _p5_challenges(mode, order, generators, t, A, P, L, y):
+def _p5_challenges(mode, order, generators, t, A, P, L, y, who="protocol_5_prover"):
     if mode == "reference":
         # compressed_pivot.py:117-130
         input_list = [t, A.normalize(), generators, P.normalize(), L, y]
+        pivot.log_hash_input(logger_cp_hin, who, input_list)
         tag = "First hash of compressed pivot"
         c0, c1 = pivot.fiat_shamir_hash_variants(input_list, [[0, tag], [1, tag]], order)
         return c0, c1, None
@@ -662,7 +660,8 @@ def protocol_5_verifier(generators, P, L, y, proof, gf, transcript=None):
     A = _pt(proof["A"])
     gens_for_hash = {"g": g if isinstance(g, PointVector) or mode == "compact" else list(g),
                      "h": generators["h"], "k": generators["k"]}
-    c0, c1, seed = _p5_challenges(mode, order, gens_for_hash, t, A, P, L, y)
+    c0, c1, seed = _p5_challenges(mode, order, gens_for_hash, t, A, P, L, y, who="protocol_5_verifier")
+    logger_cp_hout.debug(f"After hash, hash=\n{c0}, {c1}")
     g_hat = pivot._points_on_device(g) + [h]
     Q = _LazyQ(A, P, k, c0, int(c1 * (c0 * y + t)), order)
     if mode == "reference":

@@ -376,6 +376,12 @@ void vmpc_stage_end(vmpc_ctx *ctx, int handle) {
     hipStream_t on = ctx->stage_stream ? ctx->stage_stream : ctx->stream;
     VMPC_IGNORE(hipEventRecord(ctx->stages[handle].pending.back().second, on));
     if (debug_stages()) {
+        // never synchronise a stream that waits on THIS thread (rounds queued ahead of their challenge,
+        // prover.hip): the stage is reported as queued instead
+        if (ctx->stream_waits) {
+            fprintf(stderr, "[vmpc] stage %s queued behind a challenge wait\n", ctx->stages[handle].name);
+            return;
+        }
         const hipError_t e = hipStreamSynchronize(on);
         fprintf(stderr, "[vmpc] stage %s done (%s)\n", ctx->stages[handle].name, hipGetErrorString(e));
     }

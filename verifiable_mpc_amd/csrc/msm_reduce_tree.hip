@@ -205,6 +205,11 @@ k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_
         if (out_packed) fe_st8(out_packed + 32 * (size_t)w + 8 * q, R);      // one bucket set per commitment: its result
         else fe_st(out + EXT_WORDS * (size_t)w + FE_LIMBS * q, R);
     }
+    // only wave 0 is left here (no workgroup barrier after the early return above).  The four lanes' stores and lane
+    // 0's publish are instructions of ONE wave, issued in program order; the release fence inside vmpc_publish_done
+    // waits for all of the wave's outstanding stores (the memory counters are per wave).  The wave barrier keeps the
+    // compiler from moving the stores below it.
+    __builtin_amdgcn_wave_barrier();
     if (out_packed && done_flag && threadIdx.x == 0) vmpc_publish_done(done_counter, done_flag, done_seq);
 }
 

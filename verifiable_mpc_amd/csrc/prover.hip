@@ -41,6 +41,7 @@
 
 #include <array>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -792,14 +793,32 @@ p4_mailbox p4_mail(vmpc_ctx *ctx) {            // behind the results (256 B) and
     m.challenge_d = (const uint32_t *)(d + 1152);
     return m;
 }
-bool p4_poll(volatile uint32_t *word, uint32_t want, double seconds) {
+inline void p4_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
+// Spin on a pinned completion word.  Every 4096 spins the stream itself is asked: anything but "not ready" /
+// "success" is a fault on the queue (a kernel that died never publishes), reported at once instead of after the
+// timeout.  1 = the word arrived, 0 = timeout, -1 = stream error.
+int p4_poll(volatile uint32_t *word, uint32_t want, double seconds, hipStream_t st) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; spins++) {
-        if (*word == want) return true;
-        __builtin_ia32_pause();
-        if ((spins & 0xfff) == 0xfff &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds)
-            return false;
+        if (*word == want) return 1;
+        p4_cpu_relax();
+        if ((spins & 0xfff) == 0xfff) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q != hipSuccess && q != hipErrorNotReady) return -1;
+            if (q == hipSuccess && *word != want) {
+                // the queue drained and nobody published: a commitment path that did not consume done_flag_dev
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                return *word == want ? 1 : 0;
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return 0;
+        }
     }
 }
 }  // namespace
@@ -885,8 +904,10 @@ extern "C" int vmpc_p4_run_compact(vmpc_p4 *p, uint8_t state[32], int first_roun
             if (rc != VMPC_OK) return bail(rc);
         }
         // round i's pair
-        if (!p4_poll(mb.done_h, done_seq, 20.0)) {
-            snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "vmpc_p4_run_compact: round %d did not complete", i);
+        const int arrived = p4_poll(mb.done_h, done_seq, 20.0, st);
+        if (arrived != 1) {
+            snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "vmpc_p4_run_compact: round %d %s", i,
+                     arrived < 0 ? "failed on the stream" : "did not publish its completion");
             return bail(VMPC_E_HIP);
         }
         p->committed++;

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 from . import _native, formats
-from .groups import ORDER, Ed25519Point
+from .groups import ORDER, Ed25519Point, as_point
 
 _CTX = None
 
@@ -232,7 +232,7 @@ class FixedBaseTable:
     def extra_index(self, point):
         """position of `point` among the extras, or None"""
         try:
-            return self.extra_bytes.index(point.to_affine_bytes())
+            return self.extra_bytes.index(as_point(point).to_affine_bytes())
         except ValueError:
             return None
 
@@ -255,8 +255,10 @@ class PointVector:
     # ---- construction ----------------------------------------------------------------------
     @classmethod
     def from_points(cls, points, ctx=None, keep_proj=True):
-        """From host Ed25519Point objects (representatives preserved)."""
+        """From host elements - ours or foreign three-coordinate projective ones, e.g. the list of MPyC points a
+        reference caller holds (representatives preserved)."""
         ctx = ctx or get_context()
+        points = [as_point(p) for p in points]
         n = len(points)
         proj = np.frombuffer(b"".join(p.to_proj_bytes() for p in points), dtype=np.uint8)
         pbuf = ctx.upload(proj.reshape(n, 96) if n else np.zeros((0, 96), np.uint8))
@@ -372,6 +374,7 @@ class PointVector:
 
     def concat(self, points):
         """self + [pt, ...] as a new vector (g_hat = g + [h], compressed_pivot.py:138)."""
+        points = [as_point(p) for p in points]
         n, m = len(self), len(points)
         t = self._table
         tabulated = t is not None and self._table_tail == 0 and n == t.n and \
@@ -421,7 +424,7 @@ class PointVector:
         bucket stage gathers table entries at random, and far past the Infinity Cache that costs what
         the shorter recombination saves (at 2^20 generators every choice is within 3 % for one
         commitment; 8 rows is the best for the prover, see TABLE_BUDGET_BYTES)."""
-        extras = list(extras)
+        extras = [as_point(p) for p in extras]
         if rows is None and os.environ.get("VMPC_TABLE_ROWS"):
             rows = int(os.environ["VMPC_TABLE_ROWS"])          # tuning knob
         if rows is None:
@@ -464,7 +467,7 @@ class PointVector:
             self.ctx.fold(lp + stride * a, rp + stride * a, not use_proj, reduce_scalar(c), cnt, pbuf.ptr + 96 * a,
                           abuf.ptr + 64 * a)
             side.wait_for(self.ctx)
-            pieces.append(side.format_begin("points", pbuf.ptr + 96 * a, cnt, keepalive=pbuf))
+            pieces.append(side.format_begin("points", pbuf.ptr + 96 * a, cnt, keepalive=pbuf, own_signal=True))
         out._pending_text = (formats.point_style(), _native.TextSequence(pieces))
         return out
 

@@ -219,6 +219,69 @@ Ed25519Point.identity = Ed25519Point((0, 1, 1))
 Ed25519Point.generator = Ed25519Point((BASE_X, BASE_Y, 1))
 
 
+def is_ed25519_element(obj):
+    """True for this package's points and for any foreign element of the SAME group in the same coordinates -
+    e.g. an element of MPyC's EllipticCurve('Ed25519', 'projective') (demos/demo_zkp_ac20.py:46): a class of
+    order l over GF(2^255 - 19) whose value holds exactly three coordinates.  Everything else (QuadraticResidues,
+    BN256 in Jacobian coordinates, Ed25519 in 'extended' or 'affine' coordinates) is somebody else's group: the
+    installed functions hand those calls back to the reference's own Python (dropin.py)."""
+    if isinstance(obj, Ed25519Point):
+        return True
+    return _is_foreign_ed25519_class(type(obj)) and _three_coordinates(obj)
+
+
+def _is_foreign_ed25519_class(cls):
+    if getattr(cls, "order", None) != ORDER:
+        return False
+    field = getattr(cls, "field", None)
+    modulus = getattr(field, "modulus", None)
+    if modulus is None:
+        modulus = getattr(field, "order", None)
+    return modulus == P
+
+
+def _three_coordinates(obj):
+    value = getattr(obj, "value", None)
+    try:
+        return len(value) == 3
+    except TypeError:
+        return False
+
+
+def is_ed25519_group(group):
+    """the `group` argument of create_generators (circuit_sat_r1cs.py:47): a class whose generator is_ed25519_element"""
+    if isinstance(group, type) and issubclass(group, Ed25519Point):
+        return True
+    gen = getattr(group, "generator", None)
+    return gen is not None and is_ed25519_element(gen)
+
+
+def as_point(obj):
+    """Our element for `obj`: itself, or the conversion of a foreign three-coordinate projective element (the
+    representative is kept: it is part of what the reference hashes and prints)."""
+    if isinstance(obj, Ed25519Point):
+        return obj
+    if _three_coordinates(obj):
+        x, y, z = obj.value
+    elif isinstance(obj, (tuple, list)) and len(obj) == 3:
+        x, y, z = obj
+    else:
+        raise TypeError(f"not an Ed25519 projective element: {type(obj).__name__}")
+    return Ed25519Point((int(x), int(y), int(z)))
+
+
+def adopt_notation(group):
+    """A caller that flips `is_additive` / `is_multiplicative` on ITS group class (demos/demo_zkp_ac20.py:47-48)
+    goes on to write `a * b` and `a ** n` on the elements the installed functions return: those are ours, so the
+    flags are mirrored (class-wide, like MPyC's own)."""
+    if isinstance(group, type) and issubclass(group, Ed25519Point):
+        return
+    for flag in ("is_additive", "is_multiplicative"):
+        v = getattr(group, flag, None)
+        if isinstance(v, bool):
+            setattr(Ed25519Point, flag, v)
+
+
 def EllipticCurve(curvename="Ed25519", coordinates="projective"):
     """Only the group of the accelerated path exists here; every other group of the
     reference (QuadraticResidues, BN256) stays with the reference's own Python."""

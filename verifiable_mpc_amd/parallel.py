@@ -67,7 +67,7 @@ class HipBackend:
             from ._native import SharedStream
             self.bucket_stream = SharedStream(ctx.device, int(os.environ.get("VMPC_BUCKET_STREAM_PRIORITY", "-1")))
         self.bucket_wgs = wgs
-        self.pipelined = False      # set by a driver that keeps several launches in flight (bench.run_steps)
+        self._pipelined = False     # set by a driver that keeps several launches in flight (bench.run_steps)
         self.max_batch = 16
         world = comm.world if comm is not None else 1
         if comm is not None or torch is None:
@@ -91,15 +91,34 @@ class HipBackend:
     def n_slots(self):
         return len(self.ctxs)
 
+    @property
+    def pipelined(self):
+        return self._pipelined
+
+    @pipelined.setter
+    def pipelined(self, on):
+        """A driver that keeps several launches in flight.  Turning it on orders every slot stream ONCE behind what the
+        main context's stream holds at this moment (the producers of the inputs); after that launch_partial() skips the
+        per-launch wait.  A driver that produces fresh device inputs later says so with inputs_ready()."""
+        self._pipelined = bool(on)
+        if self._pipelined:
+            self.inputs_ready()
+
+    def inputs_ready(self):
+        """everything enqueued on the main context's stream so far happens-before the next launch on any slot"""
+        for ctx in self.ctxs[1:]:
+            ctx.wait_for(self.ctxs[0])
+
     def launch_partial(self, scalars, points, slot, want_affine):
         # the partial (or, single-GPU, final) sum stays in extended coordinates on the device;
         # normalising one point is O(1) host glue
         ctx = self.ctxs[slot]
         if ctx is not self.ctxs[0] and not self.pipelined:
             # inputs produced on the main context's stream just before this call (a prover's scalars).  A driver
-            # that keeps several launches in flight (pipelined) has completed its inputs beforehand - there this
-            # wait would chain every slot behind the main slot's commitment IN FLIGHT and march the slots in
-            # lockstep (round 4 trace: profiles/r04_probes/timeline_lockstep.txt)
+            # that keeps several launches in flight (pipelined) was ordered behind its inputs when it said so
+            # (the `pipelined` setter / inputs_ready()) - a wait per launch would chain every slot behind the main
+            # slot's commitment IN FLIGHT and march the slots in lockstep (round 4 trace:
+            # profiles/r04_probes/timeline_lockstep.txt)
             ctx.wait_for(self.ctxs[0])
         if self.bucket_stream is not None and self.pipelined:
             # for this call only: the contexts also serve callers that run one commitment at a time (the prover),

@@ -22,7 +22,7 @@ from random import SystemRandom
 from .device import DeviceScalar, PointVector, ScalarVector, get_context, reduce_scalar
 from .fields import FiniteFieldElement
 from .groups import EllipticCurvePoint as EllipticCurveElement
-from .groups import Ed25519Point
+from .groups import Ed25519Point, as_point
 
 prng = SystemRandom()
 
@@ -214,14 +214,14 @@ def _feed(h, obj):
         _feed(h, obj.coeffs)
         h.update(b", ")
         _feed(h, obj.constant)
-    elif isinstance(obj, list):
+    elif type(obj) is list:
         h.update(b"[")
         for i, item in enumerate(obj):
             if i:
                 h.update(b", ")
             _feed(h, item)
         h.update(b"]")
-    elif isinstance(obj, dict):
+    elif type(obj) is dict:
         h.update(b"{")
         for i, (k, v) in enumerate(obj.items()):
             if i:
@@ -231,6 +231,42 @@ def _feed(h, obj):
         h.update(b"}")
     else:
         h.update(repr(obj).encode("utf-8"))
+
+
+class _LogSink:
+    """update() target for _feed that writes the pre-image to a logger: one record per LOG_PIECE bytes, so that the
+    ~250 MB text of a 2^20-generator round never exists as one Python string"""
+    LOG_PIECE = 1 << 20
+
+    def __init__(self, logger, method):
+        self.logger, self.method, self.buf, self.part = logger, method, bytearray(), 0
+
+    def update(self, b):
+        self.buf += b
+        while len(self.buf) >= self.LOG_PIECE:
+            self._emit(self.buf[:self.LOG_PIECE])
+            del self.buf[:self.LOG_PIECE]
+
+    def _emit(self, piece):
+        what = "Before fiat_shamir_hash, input_list=" if self.part == 0 else f"input_list continued (part {self.part})="
+        self.logger.debug(f"Method {self.method}: {what}\n{bytes(piece).decode('utf-8')}")
+        self.part += 1
+
+    def close(self):
+        if self.buf or self.part == 0:
+            self._emit(self.buf)
+        self.buf = bytearray()
+
+
+def log_hash_input(logger, method, input_list):
+    """The reference's hash-input dump (compressed_pivot.py:56-58,122-124,171-173,226-228: logger
+    "compressed_pivot_hash_inputs" at DEBUG): `Method <name>: Before fiat_shamir_hash, input_list=\n<str(input_list)>`.
+    Costs a second formatting of the pre-image, so nothing happens unless the logger is enabled for DEBUG."""
+    if not logger.isEnabledFor(logging.DEBUG):
+        return
+    sink = _LogSink(logger, method)
+    _feed(sink, input_list)
+    sink.close()
 
 
 def fiat_shamir_hash(input_list, order):
@@ -334,10 +370,7 @@ def vector_commitment(x, gamma, g, h, exact_representative=None):
     return _commit_launch(xs, gamma, gv, _as_point(h), gv.ctx).result()
 
 
-def _as_point(obj):
-    if isinstance(obj, Ed25519Point):
-        return obj
-    return Ed25519Point((int(obj[0]), int(obj[1]), int(obj[2])))
+_as_point = as_point       # ours, or a foreign three-coordinate element converted (groups.as_point)
 
 
 class _PendingCommitment:
@@ -482,7 +515,7 @@ def verify_linear_form_proof(g, h, P, L, y, z, phi, c):
     """Verifier of Pi_s (pivot.py:184-205): recompute the announcement from the response
     and compare challenges."""
     L, y = affine_to_linear(L, y, len(z))
-    P = P if isinstance(P, Ed25519Point) else Ed25519Point((int(P[0]), int(P[1]), int(P[2])))
+    P = as_point(P)
     # A = commit(z, phi) / P^c
     P_c_inv = Ed25519Point.inversion(Ed25519Point.repeat(P, int(c)))
     A_check = Ed25519Point.operation(vector_commitment(z, phi, g, h), P_c_inv)
