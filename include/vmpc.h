@@ -333,6 +333,14 @@ int vmpc_bn256_table_build_dev(vmpc_ctx *ctx, int group, const void *points, siz
  * point at infinity) - the Jacobian form skips the inversion chain that one lane would run */
 int vmpc_bn256_table_msm_dev(vmpc_ctx *ctx, int group, const void *table, size_t table_n,
                              const void *scalars, size_t m, void *out_affine, void *out_jacobian);
+/* n_tables (<= 16) prepared keys of the SAME length table_n, ONE scalar vector: out_jacobian[k] (96 / 192 B each,
+ * consecutive) = sum_{i<m} scalars[i] * P_k[i].  The shape of trinocchio/pynocchio.py:229-246, where the sums
+ * r_v*v_mid*g1, r_y*y_mid*g1, r_v*alpha_v*v_mid*g1, ... all run over c_mid: recoding, bucket sort and plan happen once,
+ * every table gets its own bucket launch over the one sorted index list, the bucket sets are reduced and finished
+ * together.  A column that holds the point at infinity (all-zero entry) in table k contributes nothing to sum k, so
+ * sums that differ in a few trailing terms (the zero-knowledge deltas) still share every scalar. */
+int vmpc_bn256_table_msm_multi_dev(vmpc_ctx *ctx, int group, const void *const *tables, int n_tables, size_t table_n,
+                                   const void *scalars, size_t m, void *out_jacobian);
 
 /* SHA-256 of every `chunk_bytes`-sized piece of a device buffer (last piece may be short):
  * out_digests[i] = SHA256(data[i*chunk : (i+1)*chunk]), 32 bytes each.  Leaves of the compact

@@ -8,22 +8,9 @@ import verifiable_mpc_amd as vm
 from verifiable_mpc_amd import pynocchio as pn
 
 ctx = vm.get_context()
-G1 = (1).to_bytes(32, "little") + (pn.P - 2).to_bytes(32, "little")
-G2v = (64746500191241794695844075326670126197795977525365406531717464316923369116492,
-       21167961636542580255011770066570541300993051739349375019639421053990175267184,
-       17778617556404439934652658462602675281523610326338642107814333856843981424549,
-       20666913350058776956210519119118544732556678129809273996262322366050359951122)
-G2 = b"".join(v.to_bytes(32, "little") for v in G2v)
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 n = 1 << lg
-key = pn.PreparedKey.__new__(pn.PreparedKey)
-key.ctx, key.mid, key.vectors = ctx, list(range(n)), {}
-key.mid_index, key.zk_missing = np.arange(n), {}
-for name in list(pn._ELEMENTS) + ["h*g1"]:
-    grp, gen, width = (2, G2, 128) if name.endswith("g2") else (1, G1, 64)
-    extra = len(pn._ELEMENTS[name][1]) if name in pn._ELEMENTS else 0
-    pts = ctx.upload(np.tile(np.frombuffer(gen, np.uint8), (n + extra, 1)))
-    key.vectors[name] = pn._KeyVector.from_device(ctx, grp, pts, n + extra)
+key = pn.PreparedKey.synthetic(ctx, n)
 rng = np.random.default_rng(2)
 
 

@@ -234,3 +234,46 @@ def test_full_size_exponent_identity(vm, gi):
     want = E.mul(tot, G)
     assert from_b(ctx.download(res.ptr, width).tobytes()) == want
     assert from_b(ctx.download(res2.ptr, width).tobytes()) == want
+
+
+@pytest.mark.parametrize("gi,n,K", [(0, 1, 1), (0, 40, 3), (0, 3000, 6), (1, 700, 2)])
+def test_multi_key_pass_against_exponent_identity(vm, gi, n, K):
+    """vmpc_bn256_table_msm_multi_dev: K prepared keys of one length, ONE scalar vector (the six G1 sums of
+    trinocchio/pynocchio.py:229-246 over c_mid).  Every sum against the oracle's exponent identity; a column that
+    holds the point at infinity in one key is left out of that key's sum only; a prefix m < table_n; and every sum
+    equal to the single-key pass over the same table."""
+    from verifiable_mpc_amd import _native
+    from verifiable_mpc_amd import pynocchio as pn
+    grp, E, G, to_b, from_b, width = groups()[gi]
+    ctx = vm.get_context()
+    rng = random.Random(77 * grp + n + K)
+    keys = [walk_points(E, G, rng, n) for _ in range(K)]
+    sc = [rng.randrange(bn.N) for _ in range(n)]
+    for i, v in enumerate([0, 1, bn.N - 1, 2**255]):
+        if i < n:
+            sc[i] = v
+    holes = [rng.randrange(n) for _ in range(K)]             # key k has infinity at column holes[k]
+    tables = []
+    for k, (exps, pts) in enumerate(keys):
+        raw = bytearray(b"".join(to_b(p) for p in pts))
+        if n > 1:
+            raw[width * holes[k]:width * (holes[k] + 1)] = bytes(width)
+        dp = ctx.upload(np.frombuffer(bytes(raw), np.uint8).reshape(n, width))
+        assert ctx.bn256_validate(grp, dp.ptr, n) == 0
+        tables.append(ctx.bn256_table_build(grp, dp.ptr, n))
+    ds = ctx.upload(_native.ints_to_array(sc, 32))
+    jw = 3 * width // 2
+    for m in sorted({n, max(1, n // 3)}):
+        out = ctx.alloc(jw * K)
+        ctx.bn256_table_msm_multi(grp, [t.ptr for t in tables], n, ds.ptr, m, out.ptr)
+        ctx.sync()
+        raw = ctx.download(out.ptr, jw * K).tobytes()
+        for k, (exps, _) in enumerate(keys):
+            tot = sum(s * e for i, (s, e) in enumerate(zip(sc[:m], exps[:m])) if n == 1 or i != holes[k]) % bn.N
+            got = pn._from_jacobian(grp, raw[jw * k:jw * (k + 1)])
+            want = E.mul(tot, G)
+            assert from_b(got.to_bytes()) == want, (k, m)
+            one = ctx.alloc(jw)
+            ctx.bn256_table_msm(grp, tables[k].ptr, n, ds.ptr, m, None, one.ptr)
+            ctx.sync()
+            assert pn._from_jacobian(grp, ctx.download(one.ptr, jw).tobytes()) == got

@@ -38,7 +38,7 @@ SYMBOLS = [
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev", "vmpc_fr_tail_scalars_block_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
     "vmpc_bn256_validate_dev", "vmpc_bn256_fixed_base_dev",
-    "vmpc_msm_table_fold_dev", "vmpc_msm_table_fold_table_dev", "vmpc_p4_create", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_run_compact", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev",
+    "vmpc_msm_table_fold_dev", "vmpc_msm_table_fold_table_dev", "vmpc_p4_create", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_run_compact", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev", "vmpc_bn256_table_msm_multi_dev",
     "vmpc_comm_unique_id", "vmpc_comm_create_rccl", "vmpc_comm_create_callback", "vmpc_comm_destroy", "vmpc_comm_info",
     "vmpc_comm_allgather_dev", "vmpc_comm_points_allsum_dev", "vmpc_p4_create_sharded", "vmpc_gather_probe_dev", "vmpc_bn256_madd_rate",
     "vmpc_stream_create", "vmpc_stream_destroy", "vmpc_ctx_set_bucket_stream",
@@ -147,6 +147,7 @@ def load_library():
         "vmpc_bn256_table_bytes": (i32, [i32, sz, vp]),
         "vmpc_bn256_table_build_dev": (i32, [vp, i32, vp, sz, vp]),
         "vmpc_bn256_table_msm_dev": (i32, [vp, i32, vp, sz, vp, sz, vp, vp]),
+        "vmpc_bn256_table_msm_multi_dev": (i32, [vp, i32, vp, i32, sz, vp, sz, vp]),
         "vmpc_comm_unique_id": (i32, [vp]),
         "vmpc_comm_create_rccl": (i32, [vp, vp, i32, i32, ctypes.POINTER(vp)]),
         "vmpc_comm_create_callback": (i32, [i32, i32, EXCHANGE_FN, vp, ctypes.POINTER(vp)]),
@@ -756,6 +757,14 @@ class Context:
                                                  ctypes.c_void_p(scalars_ptr), m, ctypes.c_void_p(out_ptr),
                                                  ctypes.c_void_p(out_jac_ptr)),
                "vmpc_bn256_table_msm_dev")
+
+    def bn256_table_msm_multi(self, group, table_ptrs, table_n, scalars_ptr, m, out_jac_ptr):
+        """len(table_ptrs) prepared keys of the same length, one scalar vector: Jacobian sums, consecutive"""
+        k = len(table_ptrs)
+        tabs = (ctypes.c_void_p * k)(*[ctypes.c_void_p(p) for p in table_ptrs])
+        _check(self.lib.vmpc_bn256_table_msm_multi_dev(self.handle, group, tabs, k, table_n,
+                                                       ctypes.c_void_p(scalars_ptr), m, ctypes.c_void_p(out_jac_ptr)),
+               "vmpc_bn256_table_msm_multi_dev")
 
     def bn256_fixed_base(self, group, base_ptr, scalars_ptr, n, out_ptr):
         _check(self.lib.vmpc_bn256_fixed_base_dev(self.handle, group, ctypes.c_void_p(base_ptr),

@@ -169,6 +169,10 @@ __global__ void __launch_bounds__(64)
 gk_final(const uint32_t *__restrict__ partials, int W, int red_blocks, int c,
          uint32_t *__restrict__ out_aff, uint32_t *__restrict__ out_jac) {
     __shared__ uint32_t lds[64 * C::ACC_WORDS];
+    // block k = sum k of a multi-key pass (bn_table_msm_multi_dev): its own W * red_blocks partial sums and output slot
+    partials += (size_t)C::ACC_WORDS * blockIdx.x * W * red_blocks;
+    if (out_aff) out_aff += (size_t)C::AFF_WORDS * blockIdx.x;
+    if (out_jac) out_jac += (size_t)3 * F::WORDS * blockIdx.x;
     // window sums: lpw lanes share a window (strided partial sums), then a short LDS tree
     int lpw = 1;
     while (lpw * 2 * W <= 64 && lpw * 2 <= red_blocks) lpw *= 2;
@@ -284,6 +288,8 @@ struct bn_kernels {
     static int bucket(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uint32_t *entries);
     static int reduce(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w);
     static int final(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, void *out_affine, void *out_jac);
+    // K one-window sums side by side (w.partials: K x red_blocks), Jacobian out, K x 3 field elements
+    static int final_multi(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, void *out_jac, int K);
     static int table_build(vmpc_ctx *ctx, const void *points, size_t n, size_t stride, void *table);
     static int validate(vmpc_ctx *ctx, const void *points, size_t n, unsigned long long *d_bad);
     static int fixed_base(vmpc_ctx *ctx, const void *base_affine, const void *scalars, size_t n, void *out_affine);
@@ -332,6 +338,14 @@ template <class C, class F>
 int bn_kernels<C, F>::final(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, void *out_affine, void *out_jac) {
     gk_final<C, F><<<1, 64, 0, ctx->stream>>>(w.partials, p.W, bn_reduce_split(p) ? 2 * p.red_blocks : p.red_blocks, p.c,
                                               (uint32_t *)out_affine, (uint32_t *)out_jac);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+template <class C, class F>
+int bn_kernels<C, F>::final_multi(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, void *out_jac, int K) {
+    gk_final<C, F><<<K, 64, 0, ctx->stream>>>(w.partials, 1, bn_reduce_split(p) ? 2 * p.red_blocks : p.red_blocks, p.c,
+                                              nullptr, (uint32_t *)out_jac);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
 }

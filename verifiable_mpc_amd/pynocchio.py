@@ -140,6 +140,31 @@ def _from_jacobian(group, raw):
     return BN256TwistPoint((x[0], x[1], y[0], y[1]))
 
 
+def _from_jacobian_many_g1(raws):
+    """several G1 sums (X : Y : Z) -> affine, ONE modular inversion for all of them (Montgomery's trick)"""
+    vals = [[int.from_bytes(r[32 * i:32 * i + 32], "little") for i in range(3)] for r in raws]
+    zs = [v[2] for v in vals if v[2]]
+    prefix, run = [], 1
+    for z in zs:
+        prefix.append(run)
+        run = run * z % P
+    inv = pow(run, P - 2, P) if zs else 0
+    zinv = [0] * len(zs)
+    for i in range(len(zs) - 1, -1, -1):
+        zinv[i] = inv * prefix[i] % P
+        inv = inv * zs[i] % P
+    out, j = [], 0
+    for X, Y, Z in vals:
+        if Z == 0:
+            out.append(BN256Point(None))
+            continue
+        zi = zinv[j]
+        j += 1
+        zi2 = zi * zi % P
+        out.append(BN256Point((X * zi2 % P, Y * zi2 % P * zi % P)))
+    return out
+
+
 class _KeyVector:
     """One evaluation-key vector on the device: points uploaded, validated and tabulated once."""
 
@@ -208,13 +233,66 @@ class PreparedKey:
             missing = [zname for _, zname in zk if zname not in evalkey]
             if missing:
                 self.zk_missing[name] = missing
-            else:
-                points += [evalkey[zname] for _, zname in zk]
+            points += _tail_points(name, zk, evalkey, bool(missing))
             self.vectors[name] = _KeyVector(self.ctx, points)
         powers = []
         while "s^" + str(len(powers)) + "*g1" in evalkey:
             powers.append(evalkey["s^" + str(len(powers)) + "*g1"])
         self.vectors["h*g1"] = _KeyVector(self.ctx, powers)
+
+    @classmethod
+    def synthetic(cls, ctx, n, seed=3):
+        """A key of n `mid` wires whose every entry is a distinct multiple of its group's generator, built on the
+        device: the shape of a real prepared key without a circuit (bench.py, scripts/pinocchio_probe.py - timing
+        only; parity of compute_proof is pinned on the reference-made fixture)."""
+        g1 = (1).to_bytes(32, "little") + (P - 2).to_bytes(32, "little")
+        g2 = b"".join(v.to_bytes(32, "little") for v in (
+            64746500191241794695844075326670126197795977525365406531717464316923369116492,
+            21167961636542580255011770066570541300993051739349375019639421053990175267184,
+            17778617556404439934652658462602675281523610326338642107814333856843981424549,
+            20666913350058776956210519119118544732556678129809273996262322366050359951122))
+        rng = np.random.default_rng(seed)
+        key = cls.__new__(cls)
+        key.ctx, key.mid, key.vectors = ctx, list(range(n)), {}
+        key.mid_index, key.zk_missing = np.arange(n), {}
+        for name in list(_ELEMENTS) + ["h*g1"]:
+            grp, gen, width = (2, g2, 128) if name.endswith("g2") else (1, g1, 64)
+            zk = _ELEMENTS[name][1] if name in _ELEMENTS else ()
+            tail = _tail_slots(name, zk)
+            ex = rng.integers(0, 256, size=(n + len(tail), 32), dtype=np.uint8)
+            ex[:, 31] &= 0x7F
+            dg, de = ctx.upload(np.frombuffer(gen, np.uint8)), ctx.upload(ex)
+            pts = ctx.alloc(width * (n + len(tail)))
+            ctx.bn256_fixed_base(grp, dg.ptr, de.ptr, n + len(tail), pts.ptr)
+            for j, used in enumerate(tail):          # columns of deltas this element does not use: infinity
+                if not used:
+                    ctx.upload_into(pts.ptr + width * (n + j), np.zeros(width, np.uint8))
+            ctx.sync()
+            key.vectors[name] = _KeyVector.from_device(ctx, grp, pts, n + len(tail))
+        return key
+
+
+# The six G1 sums over c_mid (pynocchio.py:229-246) go through ONE multi-key pass (vmpc_bn256_table_msm_multi_dev):
+# they share the scalar vector c_mid || (delta_v, delta_w, delta_y), so each of their key vectors carries three
+# trailing columns in that order - the element's zero-knowledge point where it uses the delta, the point at infinity
+# where it does not (an infinity entry adds nothing, csrc/bn256_curve.h).
+_DELTAS = ("v", "w", "y")
+_SHARED_G1 = tuple(name for name in _ELEMENTS if name.endswith("g1"))
+
+
+def _tail_slots(name, zk):
+    """for each trailing column of the element's key vector: does the element use that delta?"""
+    if name in _SHARED_G1:
+        used = {attr for attr, _ in zk}
+        return [d in used for d in _DELTAS]
+    return [True] * len(zk)
+
+
+def _tail_points(name, zk, evalkey, missing):
+    if name in _SHARED_G1:
+        by_delta = {attr: zname for attr, zname in zk}
+        return [evalkey[by_delta[d]] if (d in by_delta and not missing) else BN256Point(None) for d in _DELTAS]
+    return [] if missing else [evalkey[zname] for _, zname in zk]
 
 
 def scalars_to_array(values):
@@ -247,10 +325,12 @@ def scalars_to_array(values):
 
 
 def _compute_proof_prepared(key, c, h, deltas):
-    """The eight sums over a prepared key.  The shared `c_mid` scalars are converted and uploaded once and the
-    seven sums over them enqueued on three streams (their bucket reductions and recombinations are latency
-    chains that overlap the next sum's bucket pass); ONLY THEN are h's coefficients converted - on the host,
-    while the GPU works through those seven - and the last sum enqueued.
+    """The eight sums over a prepared key.  The shared `c_mid` scalars are converted and uploaded once; the SIX G1 sums
+    over them are one multi-key pass (one recoding, sort and plan; six bucket launches over the one sorted index
+    list; one reduction and one finishing launch), the twist sum over them runs beside it on a second stream; ONLY
+    THEN are h's coefficients converted - on the host, while the GPU works through those seven - and the last sum
+    enqueued.  The sums come back in Jacobian coordinates; their inversions are shared on the host (one modular
+    inversion for all seven G1 results).
     c: indexable by qap.indices_mid (the reference's list of ints / field elements), or an (n_wires, 32) uint8
     array of canonical residues (rows taken by index); h: the reference's polynomial (.coeffs), a list, or an
     (len, 32) uint8 array."""
@@ -262,24 +342,59 @@ def _compute_proof_prepared(key, c, h, deltas):
         raise KeyError("zero-knowledge deltas given but the prepared key lacks "
                        + ", ".join(sorted(n for names in key.zk_missing.values() for n in names)))
     if isinstance(c, np.ndarray):
-        c_mid = np.ascontiguousarray(_native.as_bytes_array(c, 32)[key.mid_index])
+        c_all = _native.as_bytes_array(c, 32)
+        # (a key whose mid wires are ALL the wires, in order, needs no gather: 8 MB less to copy at 2^18 terms)
+        c_mid = c_all if _mid_is_identity(key, len(c_all)) else np.ascontiguousarray(c_all[key.mid_index])
     else:
         c_mid = scalars_to_array([c[i] for i in key.mid])
-    head = ctx.upload(c_mid) if n_mid else None
-    streams = [ctx, get_aux_context(20), get_aux_context(21)]
-    pending = {}
-    for idx, (name, (_, zk)) in enumerate(_ELEMENTS.items()):
-        cctx = streams[idx % len(streams)]
-        if cctx is not ctx:
-            cctx.wait_for(ctx)
-        tail = [int(getattr(deltas, attr)) for attr, _ in zk] if deltas is not None else []
-        pending[name] = key.vectors[name].launch(cctx, head, n_mid, tail)
+    dvals = [int(getattr(deltas, d)) % ORDER for d in _DELTAS] if deltas is not None else []
+    # c_mid || (delta_v, delta_w, delta_y): the scalar vector of the six G1 sums (and, through its own tail, the twist's)
+    n_shared = n_mid + len(dvals)
+    head = ctx.alloc(max(32, 32 * n_shared))
+    if n_mid:
+        ctx.upload_into(head.ptr, c_mid)
+    if dvals:
+        ctx.upload_into(head.ptr + 32 * n_mid, _native.ints_to_array(dvals, 32))
     hv = key.vectors["h*g1"]
+    h_ctx = get_aux_context(21)
     h_coeffs = h if isinstance(h, (np.ndarray, list)) else h.coeffs
-    h_arr = scalars_to_array(h_coeffs if isinstance(h_coeffs, np.ndarray) else [h_coeffs[i] for i in range(len(h))])
-    h_head = ctx.upload(h_arr) if len(h_arr) else None
-    pending["h*g1"] = hv.launch(ctx, h_head, len(h_arr))
-    return {name: key.vectors[name].result(p) for name, p in pending.items()}
+    h_head = None
+    if isinstance(h_coeffs, np.ndarray):           # nothing to convert: h goes up before anything is launched
+        h_arr = scalars_to_array(h_coeffs)
+        h_head = h_ctx.upload(h_arr) if len(h_arr) else None
+    g1 = [key.vectors[name] for name in _SHARED_G1]
+    out_g1 = ctx.alloc(96 * len(g1))
+    # three streams: the twist sum (the longest single one) first, the six-sum pass beside it, h's sum on a third -
+    # the bucket kernels take turns on the chip, the reductions and recombinations (latency chains) overlap them
+    twist_ctx = get_aux_context(20)
+    twist_ctx.wait_for(ctx)               # `head` was filled on the main stream
+    pending_twist = None
+    for name, (_, zk) in _ELEMENTS.items():
+        if name not in _SHARED_G1:
+            tail = [int(getattr(deltas, attr)) for attr, _ in zk] if deltas is not None else []
+            pending_twist = (name, key.vectors[name].launch(twist_ctx, head, n_mid, tail))
+    ctx.bn256_table_msm_multi(1, [v.table.ptr for v in g1], g1[0].n, head.ptr, n_shared, out_g1.ptr)
+    if h_head is None and not isinstance(h_coeffs, np.ndarray):
+        # the reference's ints: converted on the host while the GPU works through the seven sums over c
+        h_arr = scalars_to_array([h_coeffs[i] for i in range(len(h))])
+        h_head = h_ctx.upload(h_arr) if len(h_arr) else None
+    pending_h = hv.launch(h_ctx, h_head, len(h_arr))
+    ctx.sync()
+    h_ctx.sync()
+    raw = ctx.download(out_g1.ptr, 96 * len(g1)).tobytes() + h_ctx.download(pending_h[1].ptr, 96).tobytes()
+    points = _from_jacobian_many_g1([raw[96 * i:96 * i + 96] for i in range(len(g1) + 1)])
+    out = dict(zip(_SHARED_G1, points[:-1]))
+    out[pending_twist[0]] = key.vectors[pending_twist[0]].result(pending_twist[1])
+    out["h*g1"] = points[-1]
+    return {name: out[name] for name in list(_ELEMENTS) + ["h*g1"]}
+
+
+def _mid_is_identity(key, n_wires):
+    flag = getattr(key, "_mid_identity", None)
+    if flag is None:
+        flag = key._mid_identity = bool(len(key.mid) and key.mid[0] == 0 and key.mid[-1] == len(key.mid) - 1
+                                        and np.array_equal(key.mid_index, np.arange(len(key.mid))))
+    return flag and n_wires == len(key.mid)
 
 
 def compute_proof(qap, c, h, evalkey, deltas=None):
