@@ -38,6 +38,9 @@ extern "C" {
 #define VMPC_E_NOMEM (-12)
 #define VMPC_E_HIP (-5)         /* HIP runtime error, see vmpc_last_error() */
 #define VMPC_E_NODEV (-19)      /* no GPU visible */
+#define VMPC_E_AGAIN (-11)      /* vmpc_ctx_sync: a commitment took the fused short path (16-row table of <= 2^17 columns)
+                                 * and its scalars were skewed beyond that path's fixed capacities; nothing of the call's
+                                 * output is valid - switch the path off (vmpc_ctx_set_short_path) and repeat the call */
 
 #define VMPC_SCALAR_BYTES 32
 #define VMPC_AFFINE_BYTES 64
@@ -55,6 +58,10 @@ int vmpc_ctx_destroy(vmpc_ctx *ctx);
 /* run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
 int vmpc_ctx_set_stream(vmpc_ctx *ctx, void *hip_stream);
 int vmpc_ctx_sync(vmpc_ctx *ctx);
+/* Commitments over a 16-row fixed-base table of at most 2^17 columns (BASELINE config 2, every prover round after the
+ * fold jump) take a fused three-launch path (csrc/msm_short.hip) with fixed capacities; on: the default.  A call whose
+ * scalars overflow them is reported by vmpc_ctx_sync as VMPC_E_AGAIN: switch the path off, repeat, switch it on. */
+int vmpc_ctx_set_short_path(vmpc_ctx *ctx, int on);
 /* non-blocking: *done = 1 when everything enqueued on the context's stream has completed (a driver that keeps
  * several commitments in flight refills whichever context finishes first) */
 int vmpc_ctx_query(vmpc_ctx *ctx, int *done);

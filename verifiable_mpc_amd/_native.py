@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VMPC_LIB_PATH") or os.path.join(_HERE, "libvmpc_hip.so")   # override: developer A/B builds
 
 OK = 0
-E_INVAL, E_NONCANON, E_NOTONCURVE, E_NOMEM, E_HIP, E_NODEV = -22, -34, -33, -12, -5, -19
-_ERR_NAMES = {E_INVAL: "VMPC_E_INVAL", E_NONCANON: "VMPC_E_NONCANON",
+E_INVAL, E_NONCANON, E_NOTONCURVE, E_NOMEM, E_HIP, E_NODEV, E_AGAIN = -22, -34, -33, -12, -5, -19, -11
+_ERR_NAMES = {E_AGAIN: "VMPC_E_AGAIN", E_INVAL: "VMPC_E_INVAL", E_NONCANON: "VMPC_E_NONCANON",
               E_NOTONCURVE: "VMPC_E_NOTONCURVE", E_NOMEM: "VMPC_E_NOMEM", E_HIP: "VMPC_E_HIP",
               E_NODEV: "VMPC_E_NODEV"}
 
@@ -26,7 +26,7 @@ SCALAR_BYTES, AFFINE_BYTES, PROJ_BYTES, EXT_BYTES = 32, 64, 96, 128
 # against the header and against the built library)
 SYMBOLS = [
     "vmpc_backend_info", "vmpc_last_error", "vmpc_ctx_create", "vmpc_ctx_destroy",
-    "vmpc_ctx_set_stream", "vmpc_ctx_sync", "vmpc_ctx_query", "vmpc_ctx_wait_for", "vmpc_malloc", "vmpc_free", "vmpc_memcpy_h2d",
+    "vmpc_ctx_set_stream", "vmpc_ctx_sync", "vmpc_ctx_set_short_path", "vmpc_ctx_query", "vmpc_ctx_wait_for", "vmpc_malloc", "vmpc_free", "vmpc_memcpy_h2d",
     "vmpc_memcpy_d2h", "vmpc_memcpy_d2d", "vmpc_ctx_profile", "vmpc_ctx_profile_read",
     "vmpc_ctx_set_window", "vmpc_ed25519_msm_plan", "vmpc_ed25519_madd_rate", "vmpc_ed25519_msm", "vmpc_ed25519_fold",
     "vmpc_ed25519_fixed_base_batch", "vmpc_fr_axpy", "vmpc_fr_dot", "vmpc_points_validate_dev",
@@ -76,6 +76,7 @@ def load_library():
         "vmpc_ctx_destroy": (i32, [vp]),
         "vmpc_ctx_set_stream": (i32, [vp, vp]),
         "vmpc_ctx_sync": (i32, [vp]),
+        "vmpc_ctx_set_short_path": (i32, [vp, i32]),
         "vmpc_ctx_query": (i32, [vp, ctypes.POINTER(i32)]),
         "vmpc_ctx_wait_for": (i32, [vp, vp]),
         "vmpc_malloc": (i32, [vp, sz, ctypes.POINTER(vp)]),
@@ -177,7 +178,7 @@ def library_loaded():
 
 def _check(rc, where):
     if rc != OK:
-        detail = load_library().vmpc_last_error().decode(errors="replace") if rc == E_HIP or rc == E_NONCANON or rc == E_NOMEM or rc == E_NODEV else ""
+        detail = load_library().vmpc_last_error().decode(errors="replace") if rc in (E_HIP, E_NONCANON, E_NOMEM, E_NODEV, E_AGAIN) else ""
         raise VmpcError(rc, where, detail)
 
 
@@ -494,6 +495,19 @@ class Context:
 
     def sync(self):
         _check(self.lib.vmpc_ctx_sync(self.handle), "vmpc_ctx_sync")
+
+    def set_short_path(self, on):
+        """commitments over short 16-row tables: the fused three-launch path (csrc/msm_short.hip) on / off"""
+        _check(self.lib.vmpc_ctx_set_short_path(self.handle, 1 if on else 0), "vmpc_ctx_set_short_path")
+
+    def on_general_path(self, fn):
+        """fn() once more with the short path off: what a caller does after sync() raised VMPC_E_AGAIN (a commitment's
+        scalars were skewed beyond the short path's fixed capacities; its result is void)"""
+        self.set_short_path(False)
+        try:
+            return fn()
+        finally:
+            self.set_short_path(True)
 
     def done(self):
         """True when all work enqueued on this context's stream has completed (does not block)"""

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvmpc_hip.so")
-UNITS = ["api", "msm", "msm_sort", "msm_reduce_tree", "exact", "frvec", "format", "sha256", "bn256", "bn256_g1", "bn256_g2_bucket", "bn256_g2_reduce", "bn256_g2_final", "bn256_g2_table", "fold_jump", "prover", "comm", "probe", "bn256_probe"]
+UNITS = ["api", "msm", "msm_sort", "msm_reduce_tree", "msm_short", "exact", "frvec", "format", "sha256", "bn256", "bn256_g1", "bn256_g2_bucket", "bn256_g2_reduce", "bn256_g2_final", "bn256_g2_table", "fold_jump", "prover", "comm", "probe", "bn256_probe"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("VMPC_EXTRA_FLAGS", "").split()
 

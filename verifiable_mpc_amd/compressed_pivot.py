@@ -347,27 +347,40 @@ def _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, tran
     table = g_hat._table
     assert L_tilde.constant == 0, "Next line assumes L_tilde is a linear form, not affine form."
     Lc = _coeffs_dev(L_tilde)
-    rounds = P4Rounds(g_hat.ctx, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, Lc.ptr,
-                      n_total=len(z_hat))
+    def run():
+        rounds = P4Rounds(g_hat.ctx, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, Lc.ptr,
+                          n_total=len(z_hat))
+        try:
+            n_rounds = len(z_hat).bit_length() - 2
+            if NATIVE_CHAIN:
+                state, pairs, z_prime = rounds.run_compact(transcript.state, round_i, n_rounds)
+                transcript.state = state
+                for i, (a, b) in enumerate(pairs):
+                    proof["A" + str(round_i + i)] = Ed25519Point.from_affine_bytes(a)
+                    proof["B" + str(round_i + i)] = Ed25519Point.from_affine_bytes(b)
+            else:
+                c = None
+                for i in range(n_rounds):
+                    a, b = rounds.round(c)
+                    A, B = Ed25519Point.from_affine_bytes(a), Ed25519Point.from_affine_bytes(b)
+                    proof["A" + str(round_i + i)] = A
+                    proof["B" + str(round_i + i)] = B
+                    c = transcript.round_challenge(round_i + i, A, B, None, k, None, None)
+                z_prime = rounds.finish(c)
+            proof["z_prime"] = [gf(v) for v in z_prime]
+        finally:
+            rounds.close()
+    state0 = transcript.state
     try:
-        n_rounds = len(z_hat).bit_length() - 2
-        if NATIVE_CHAIN:
-            transcript.state, pairs, z_prime = rounds.run_compact(transcript.state, round_i, n_rounds)
-            for i, (a, b) in enumerate(pairs):
-                proof["A" + str(round_i + i)] = Ed25519Point.from_affine_bytes(a)
-                proof["B" + str(round_i + i)] = Ed25519Point.from_affine_bytes(b)
-        else:
-            c = None
-            for i in range(n_rounds):
-                a, b = rounds.round(c)
-                A, B = Ed25519Point.from_affine_bytes(a), Ed25519Point.from_affine_bytes(b)
-                proof["A" + str(round_i + i)] = A
-                proof["B" + str(round_i + i)] = B
-                c = transcript.round_challenge(round_i + i, A, B, None, k, None, None)
-            z_prime = rounds.finish(c)
-        proof["z_prime"] = [gf(v) for v in z_prime]
-    finally:
-        rounds.close()
+        run()
+    except _native.VmpcError as e:
+        # a round's commitments over the folded vector's table took the fused short path and met scalars beyond its
+        # capacities (csrc/msm_short.hip: VMPC_E_AGAIN, reported when the rounds finish): the whole of Protocol 4 once
+        # more on the general path - its inputs (z_hat, L~) were copied into the round context, they are intact
+        if e.code != _native.E_AGAIN:
+            raise
+        transcript.state = state0
+        g_hat.ctx.on_general_path(run)
     return proof
 
 

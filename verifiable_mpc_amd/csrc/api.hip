@@ -66,6 +66,8 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
     }
     const char *w = getenv("VMPC_MSM_WINDOW");
     if (w) c->window_override = atoi(w);
+    const char *sp = getenv("VMPC_SHORT_PATH");          // 0: commitments over short 16-row tables take the general path
+    if (sp) c->short_path = atoi(sp) != 0;
     // measured and left at their defaults (only with VMPC_EXPERIMENTAL=1):
     const char *bw = vmpc_getenv_experimental("VMPC_BUCKET_WGS_PER_CU");
     if (bw && atoi(bw) >= 0) c->bucket_wgs_per_cu = atoi(bw);
@@ -106,6 +108,7 @@ extern "C" int vmpc_ctx_destroy(vmpc_ctx *ctx) {
     if (ctx->p4_pool) VMPC_IGNORE(hipFree(ctx->p4_pool));
     if (ctx->p4_kblock) VMPC_IGNORE(hipFree(ctx->p4_kblock));
     if (ctx->d_status) VMPC_IGNORE(hipFree(ctx->d_status));
+    if (ctx->short_cursors) VMPC_IGNORE(hipFree(ctx->short_cursors));
     if (ctx->own_stream) VMPC_IGNORE(hipStreamDestroy(ctx->stream));
     delete ctx;
     return VMPC_OK;
@@ -145,6 +148,20 @@ extern "C" int vmpc_ctx_sync(vmpc_ctx *ctx) {
         VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         return VMPC_E_NONCANON;
     }
+    if (st[VMPC_ST_SHORT_OVERFLOW]) {
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf,
+                 "the short-commitment path met scalars beyond its fixed capacities: repeat the call on the general path "
+                 "(vmpc_ctx_set_short_path(ctx, 0))");
+        VMPC_HIP_CHECK(hipMemsetAsync(ctx->d_status, 0, VMPC_ST_WORDS * sizeof(uint32_t), ctx->stream));
+        VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return VMPC_E_AGAIN;
+    }
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_ctx_set_short_path(vmpc_ctx *ctx, int on) {
+    if (!ctx) return VMPC_E_INVAL;
+    ctx->short_path = on ? 1 : 0;
     return VMPC_OK;
 }
 

@@ -31,6 +31,8 @@ extern thread_local char vmpc_err_buf[512];
 
 // device-side status word layout (ctx->d_status, 4 x u32)
 #define VMPC_ST_NONCANON 0  // count of non-canonical scalars seen by recode kernels
+#define VMPC_ST_SHORT_OVERFLOW 1  // the fused short-commitment path (msm_short.hip) met a bin or bucket beyond its fixed
+                                  // capacities: the call's result is void, vmpc_ctx_sync returns VMPC_E_AGAIN
 #define VMPC_ST_WORDS 4
 
 struct vmpc_stage {
@@ -53,6 +55,9 @@ struct vmpc_ctx {
     int bucket_wgs_per_cu = 0;     // > 0: persistent bucket kernel with this many 256-thread workgroups per CU
     int reduce_max_chunks = 32768; // most chunk-lanes per bucket set in the bucket reduction (msm_sort.hip)
     int reduce_chunks_override = 0; // > 0: chunk-lanes per bucket set, fixed (power of two)
+    int short_path = 1;            // commitments over a 16-row table of <= 2^17 columns: the fused path (msm_short.hip)
+    bool short_ready = false;      // its kernels' dynamic-LDS limits are set on this context's device
+    uint32_t *short_cursors = nullptr;   // [2][128] bin fill counts, zero between calls (the path's last kernel re-arms them)
     int reduce_tree = 1;           // short chunks: weights from the quad tree (msm_reduce_tree.hip), not per-lane ladders
     bool reduce_tree_ready = false; // its kernels' dynamic-LDS limits are set on this context's device
     int seg_shift_min = -3;        // shortest bucket segments the plan may choose: 64 >> 3 entries (msm_sort.hip)

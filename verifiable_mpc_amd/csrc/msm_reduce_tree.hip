@@ -23,93 +23,7 @@
 #include "ptio.h"
 #include "quad.h"
 
-#define RT_THREADS 1024
-#define RT_LEAVES 256
-
-__device__ __forceinline__ fe rt_ld(const uint32_t *arr, int idx, int q) { return fe_ld(arr + EXT_WORDS * (size_t)idx + FE_LIMBS * q); }
-__device__ __forceinline__ void rt_st(uint32_t *arr, int idx, int q, const fe &v) { fe_st(arr + EXT_WORDS * (size_t)idx + FE_LIMBS * q, v); }
-__device__ __forceinline__ fe rt_identity(int q) { return (q == 1 || q == 2) ? fe_one() : fe_zero(); }   // (0 : 1 : 1 : 0)
-__device__ __forceinline__ fe rt_add(const fe &P, const fe &Q, int q) { return quadD_add_cached(P, quadD_to_cached(Q, q), q); }
-__device__ __forceinline__ int rt_pad16(int v) { return (v + 15) & ~15; }
-
-// The weighted tree over n leaves (a power of two >= 2) held in LDS, in place.  In: TA[t] = A_t and, when present,
-// US[t], EX[t] (plain sums that ride along).  Out: RR[0] = sum t A_t, DD[0] = n sum A_t, US[0], EX[0] and, with
-// KEEP_T, TA[0] = sum A_t.
-// A round covers a contiguous range of j with every kind of job; the quads are laid out in SEGMENTS of one
-// operation each (plain additions | R: two additions | D: addition + doubling), every segment starting on a wave,
-// so no wave diverges.  A job reads entries 2j, 2j+1 and writes entry j of its arrays: everything a round reads is
-// loaded before the barrier that precedes its stores, and earlier rounds only wrote entries below the range - in
-// place is safe.
-template <bool KEEP_T, bool HAS_U, bool HAS_E>
-__device__ __forceinline__ void rt_tree(uint32_t *TA, uint32_t *US, uint32_t *EX, uint32_t *RR, uint32_t *DD, int n) {
-    enum { OP_ADD = 0, OP_R = 1, OP_D = 2, OP_PAIR = 3 };
-    const int qd = threadIdx.x >> 2, q = threadIdx.x & 3, nquads = blockDim.x >> 2;
-    int lvl = 0;
-    for (int m = n >> 1; m >= 1; m >>= 1, lvl++) {
-        const int nplain = (lvl == 0 ? 0 : (KEEP_T ? 1 : 0)) + (HAS_U ? 1 : 0) + (HAS_E ? 1 : 0);
-        int cnt = m;
-        while (rt_pad16(cnt * nplain) + (lvl == 0 ? 1 : 2) * rt_pad16(cnt) > nquads) cnt >>= 1;
-        const int nA = rt_pad16(cnt * nplain), nC = rt_pad16(cnt);
-        const int total = nA + (lvl == 0 ? 1 : 2) * nC;
-        // this quad's job within a round
-        int op, jl;
-        bool on;
-        uint32_t *arr;
-        {
-            int plain_at = lvl == 0 ? nC : 0;
-            if (qd >= plain_at && qd < plain_at + nA) {
-                int pk = (qd - plain_at) / cnt;
-                jl = (qd - plain_at) % cnt;
-                on = pk < nplain;
-                op = OP_ADD;
-                arr = US;
-                if (KEEP_T && lvl > 0) {
-                    if (pk == 0) arr = TA;
-                    pk--;
-                }
-                if (HAS_U) {
-                    if (pk == 0) arr = US;
-                    pk--;
-                }
-                if (HAS_E && pk == 0) arr = EX;
-            } else if (lvl == 0) {
-                op = OP_PAIR; jl = qd; on = qd < cnt; arr = TA;
-            } else if (qd < nA + nC) {
-                op = OP_R; jl = qd - nA; on = jl < cnt; arr = RR;
-            } else {
-                op = OP_D; jl = qd - nA - nC; on = jl < cnt; arr = DD;
-            }
-            if (!on) arr = TA;
-        }
-        const bool wave_on = (qd & ~15) < total;
-        for (int j0 = 0; j0 < m; j0 += cnt) {
-            const int j = j0 + jl, jj = on ? j : 0;
-            fe x, y, z;
-            if (wave_on) {
-                x = rt_ld(arr, 2 * jj, q);
-                y = rt_ld(arr, 2 * jj + 1, q);
-                if (op == OP_R) z = rt_ld(DD, 2 * jj + 1, q);
-            }
-            __syncthreads();
-            if (wave_on) {
-                const fe s = rt_add(x, y, q);
-                fe s2 = s;
-                if (op == OP_R) s2 = rt_add(s, z, q);
-                else if (op == OP_D || op == OP_PAIR) s2 = quadD_dbl(s, q);
-                if (on) {
-                    if (op == OP_PAIR) {
-                        if (KEEP_T) rt_st(TA, j, q, s);
-                        rt_st(RR, j, q, y);          // R = 0 * A_2j + 1 * A_2j+1
-                        rt_st(DD, j, q, s2);         // D = 2 (A_2j + A_2j+1)
-                    } else {
-                        rt_st(arr, j, q, s2);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
+#include "rt_tree.h"
 
 // workgroup (g, w): chunks 256 g .. 256 g + 255 of window w; out3[(w G + g) 3 + {0, 1, 2}] = U_g, Rw_g, D_g
 // Chunk sums: L <= 2 - a quad per chunk (1024 threads); longer chunks - a LANE per chunk (LANE_P1: the running sums
@@ -177,9 +91,13 @@ k_msm_reduce_tree(const uint32_t *__restrict__ buckets, const uint32_t *__restri
 }
 
 // workgroup w: R_w = X + L (Y + Z) from the G triples of the window:  X = sum U_g, Y = sum Rw_g, Z = sum g D_g
+// spl > 1 (msm_short.hip): every group's triple arrives as spl PARTIAL triples (the group's entries were shared out
+// among spl workgroups); a triple is linear in the bucket sums, so the parts are added on the way in.
+// reset: words this workgroup zeroes for the next call (the short path's bin cursors), or NULL.
 __global__ void __launch_bounds__(RT_THREADS)
 k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_t *__restrict__ out,
-                     uint32_t *__restrict__ out_packed, uint32_t *done_counter, uint32_t *done_flag, uint32_t done_seq) {
+                     uint32_t *__restrict__ out_packed, uint32_t *done_counter, uint32_t *done_flag, uint32_t done_seq,
+                     int spl, uint32_t *__restrict__ reset, int reset_words) {
     extern __shared__ __align__(16) uint32_t rt_lds[];
     uint32_t *TA = rt_lds;
     uint32_t *US = TA + (size_t)G * EXT_WORDS;
@@ -187,13 +105,26 @@ k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_
     uint32_t *RR = EX + (size_t)G * EXT_WORDS;
     uint32_t *DD = RR + (size_t)(G > 1 ? G / 2 : 1) * EXT_WORDS;
     const int w = blockIdx.x;
-    const uint32_t *src = in3 + (size_t)EXT_WORDS * 3 * (size_t)w * G;
+    const uint32_t *src = in3 + (size_t)EXT_WORDS * 3 * (size_t)w * G * spl;
+    if (reset)
+        for (int i = threadIdx.x; i < reset_words; i += blockDim.x) reset[(size_t)w * reset_words + i] = 0;
     for (int i = threadIdx.x; i < G * 3 * EXT_WORDS; i += blockDim.x) {
         const int g = i / (3 * EXT_WORDS), r = i % (3 * EXT_WORDS), k = r / EXT_WORDS, e = r % EXT_WORDS;
         uint32_t *dst = k == 0 ? US : k == 1 ? EX : TA;
-        dst[g * EXT_WORDS + e] = src[i];
+        dst[g * EXT_WORDS + e] = src[(size_t)g * spl * 3 * EXT_WORDS + r];
     }
     __syncthreads();
+    for (int part = 1; part < spl; part++) {
+        // one quad per (group, array): LDS entry += the part's entry, read straight from global memory
+        const int q = threadIdx.x & 3;
+        for (int job = threadIdx.x >> 2; job < 3 * G; job += blockDim.x >> 2) {
+            const int g = job / 3, k = job % 3;
+            uint32_t *dst = k == 0 ? US : k == 1 ? EX : TA;
+            const fe y = fe_ld(src + ((size_t)(g * spl + part) * 3 + k) * EXT_WORDS + FE_LIMBS * q);
+            rt_st(dst, g, q, rt_add(rt_ld(dst, g, q), y, q));
+        }
+        __syncthreads();
+    }
     if (G > 1) rt_tree<false, true, true>(TA, US, EX, RR, DD, G);
     if (threadIdx.x >= 64) return;
     const int q = threadIdx.x & 3;
@@ -247,7 +178,23 @@ int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st,
     VMPC_KERNEL_CHECK();
     k_msm_reduce_combine<<<p.W, RT_THREADS, lds_b, st>>>(triples, G, msm_ilog2(L), w.partials, (uint32_t *)out_packed,
                                                          ctx->d_status + VMPC_ST_WORDS, out_packed ? ctx->done_flag_dev : nullptr,
-                                                         ctx->done_seq);
+                                                         ctx->done_seq, 1, nullptr, 0);
+    if (out_packed) ctx->done_flag_dev = nullptr;
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
+// the second kernel alone, for triples somebody else produced (msm_short.hip): W windows of G groups x spl parts
+int msm_reduce_combine_launch(vmpc_ctx *ctx, const uint32_t *triples, int W, int G, int spl, uint32_t *scratch_out,
+                              void *out_packed, uint32_t *reset, int reset_words) {
+    hipStream_t st = ctx->stream;
+    if (!ctx->reduce_tree_ready && !ctx->short_ready)
+        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_reduce_combine,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 * 128 + 1) * EXT_WORDS * 4)));
+    const size_t lds_b = (size_t)(4 * G + 1) * EXT_WORDS * 4;
+    k_msm_reduce_combine<<<W, RT_THREADS, lds_b, st>>>(triples, G, 0, scratch_out, (uint32_t *)out_packed,
+                                                       ctx->d_status + VMPC_ST_WORDS, out_packed ? ctx->done_flag_dev : nullptr,
+                                                       ctx->done_seq, spl, reset, reset_words);
     if (out_packed) ctx->done_flag_dev = nullptr;
     VMPC_KERNEL_CHECK();
     return VMPC_OK;

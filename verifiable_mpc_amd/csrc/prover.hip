@@ -640,8 +640,13 @@ static int p4_round_enqueue(vmpc_p4 *p, const uint32_t *c_mem) {
         if (const char *e = vmpc_getenv_experimental("VMPC_P4_FILL_SHIFT")) ctx->plan_fill_shift = atoi(e);
         // (narrower digits on a folded vector's table were measured in rounds 2-3 and lose at every size - DESIGN.md
         // section 10 - the knob is gone)
+        // (under a communicator the fused short path stays off: its overflow answer - repeat on the general path - would
+        // have to be agreed between the ranks)
+        const int keep_short = ctx->short_path;
+        if (p->comm) ctx->short_path = 0;
         const int rc = vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
                                                 pair_out, nullptr);
+        ctx->short_path = keep_short;
         ctx->plan_fill_shift = 0;
         VMPC_CHECK(rc);
     }

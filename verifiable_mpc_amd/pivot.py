@@ -19,6 +19,7 @@ import time
 import logging
 from random import SystemRandom
 
+from . import _native
 from .device import DeviceScalar, PointVector, ScalarVector, get_context, reduce_scalar
 from .fields import FiniteFieldElement
 from .groups import EllipticCurvePoint as EllipticCurveElement
@@ -374,13 +375,20 @@ _as_point = as_point       # ours, or a foreign three-coordinate element convert
 
 
 class _PendingCommitment:
-    """An MSM enqueued on a context; result() synchronises that context and fetches the point."""
+    """An MSM enqueued on a context; result() synchronises that context and fetches the point.  `relaunch`
+    enqueues the same commitment again: used once, on the general path, when the fused short path reports scalars
+    beyond its capacities (VMPC_E_AGAIN, csrc/msm_short.hip)."""
 
-    def __init__(self, ctx, out, keepalive):
-        self.ctx, self.out, self.keepalive = ctx, out, keepalive
+    def __init__(self, ctx, out, keepalive, relaunch=None):
+        self.ctx, self.out, self.keepalive, self.relaunch = ctx, out, keepalive, relaunch
 
     def result(self):
-        self.ctx.sync()
+        try:
+            self.ctx.sync()
+        except _native.VmpcError as e:
+            if e.code != _native.E_AGAIN or self.relaunch is None:
+                raise
+            self.ctx.on_general_path(lambda: (self.relaunch(), self.ctx.sync()))
         # the kernel leaves the sum in extended coordinates; the one field inversion of
         # .normalize() is O(1) host glue (25 us of big-int pow vs a 120 us single-lane chain)
         raw = self.ctx.download(self.out.ptr, 96).tobytes()
@@ -414,16 +422,54 @@ def _table_args(xs, gamma, gv, h, ctx):
     return table, min(n, n_main), gam
 
 
+# A generator vector somebody commits to a SECOND time is a CRS (pivot.py:139-145 is called with the same g, h for every
+# proof): it is tabulated then, without being asked (PointVector.precompute), and every later commitment over it skips
+# the point preparation and most of the window recombination.  Rows by a budget of 512 MiB per table - the form with
+# the shortest latency for one commitment alone (bench.py `alone`: 4 rows at 2^20, 16 up to 2^18) - and at most
+# AUTO_TABLE_TOTAL bytes of such tables alive per process.
+AUTO_TABLE_MIN = 1 << 10
+AUTO_TABLE_BUDGET = 512 << 20
+AUTO_TABLE_TOTAL = 8 << 30
+_auto_table_bytes = [0]
+
+
+def _auto_tabulate(gv, h):
+    if gv._table is not None or not isinstance(gv, PointVector) or len(gv) < AUTO_TABLE_MIN:
+        return
+    gv._commit_uses = getattr(gv, "_commit_uses", 0) + 1
+    if gv._commit_uses != 2:
+        return
+    rows = 16
+    while rows > 1 and rows * 128 * (len(gv) + 1) > AUTO_TABLE_BUDGET:
+        rows //= 2
+    nbytes = rows * 128 * (len(gv) + 1)
+    if _auto_table_bytes[0] + nbytes > AUTO_TABLE_TOTAL:
+        return
+    import weakref
+    gv.precompute([h], rows=rows)
+    _auto_table_bytes[0] += nbytes
+    weakref.finalize(gv._table, _auto_table_released, nbytes)
+
+
+def _auto_table_released(nbytes):
+    _auto_table_bytes[0] -= nbytes
+
+
 def _commit_launch(xs, gamma, gv, h, ctx):
     """enqueue h^gamma * prod g_i^{x_i} on `ctx` (device vectors in, 64-byte affine out)"""
     import numpy as np
     n = len(xs)
     out = ctx.alloc(128)
+    if ctx is gv.ctx:
+        _auto_tabulate(gv, h)
     targs = _table_args(xs, gamma, gv, h, ctx)
     if targs is not None:
         table, m, gam = targs
-        ctx.msm_table(table.ptr, table.n, len(table.extra_bytes), xs.ptr, m, gam.ptr, out.ptr, None, rows=table.rows)
-        return _PendingCommitment(ctx, out, (gam, xs, gv, table))
+
+        def launch():
+            ctx.msm_table(table.ptr, table.n, len(table.extra_bytes), xs.ptr, m, gam.ptr, out.ptr, None, rows=table.rows)
+        launch()
+        return _PendingCommitment(ctx, out, (gam, xs, gv, table), launch)
     if isinstance(gamma, DeviceScalar):
         gam = gamma
     else:
@@ -451,9 +497,17 @@ def vector_commitment_pair(x_a, gamma_a, g_a, x_b, gamma_b, g_b, h):
         if ta is not None and tb is not None and ta[1] == tb[1]:
             table, m = ta[0], ta[1]
             out = ctx.alloc(256)
-            ctx.msm_table_batch(table.ptr, table.n, len(table.extra_bytes), [xa.ptr, xb.ptr], m,
-                                [ta[2].ptr, tb[2].ptr], out.ptr, None, rows=table.rows)
-            ctx.sync()
+
+            def launch():
+                ctx.msm_table_batch(table.ptr, table.n, len(table.extra_bytes), [xa.ptr, xb.ptr], m,
+                                    [ta[2].ptr, tb[2].ptr], out.ptr, None, rows=table.rows)
+                ctx.sync()
+            try:
+                launch()
+            except _native.VmpcError as e:
+                if e.code != _native.E_AGAIN:
+                    raise
+                ctx.on_general_path(launch)
             raw = ctx.download(out.ptr, 256).tobytes()
             return (Ed25519Point.from_proj_bytes(raw[:96]).normalize(),
                     Ed25519Point.from_proj_bytes(raw[128:224]).normalize())
