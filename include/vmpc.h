@@ -62,6 +62,10 @@ int vmpc_ctx_sync(vmpc_ctx *ctx);
  * fold jump) take a fused three-launch path (csrc/msm_short.hip) with fixed capacities; on: the default.  A call whose
  * scalars overflow them is reported by vmpc_ctx_sync as VMPC_E_AGAIN: switch the path off, repeat, switch it on. */
 int vmpc_ctx_set_short_path(vmpc_ctx *ctx, int on);
+/* test hook: mark the context as holding a queued stream wait (vmpc_p4_run_compact's state between two rounds) -
+ * every call that would have to grow the workspace or the pinned block must then fail with VMPC_E_INVAL instead of
+ * synchronising a stream that waits on the calling thread */
+int vmpc_ctx_debug_hold_wait(vmpc_ctx *ctx, int on);
 /* non-blocking: *done = 1 when everything enqueued on the context's stream has completed (a driver that keeps
  * several commitments in flight refills whichever context finishes first) */
 int vmpc_ctx_query(vmpc_ctx *ctx, int *done);

@@ -47,6 +47,60 @@ __global__ void k_madd(const uint32_t *in, uint32_t *out, int iters) {
     fe_store(out + 8 * i, fe_add(fe_add(p.X, p.Y), fe_add(p.Z, p.T)));
 }
 
+// ---- round 5: the 9-limb alternative --------------------------------------------------------
+// 2^255 - 19 in nine limbs of 29 bits (radix 2^29, 261 bits, 2^261 = 1216 mod p): 81 multiply-adds into 17 column
+// accumulators instead of 100 into 10 - but the wrap constant no longer fits a pre-multiplied 32-bit operand
+// (1216 * 2^29 > 2^32), so the high columns have to be carried down to 29-bit limbs before they can be folded, and
+// the result carried once more: two carry passes (17 + 9 columns) and nine more multiply-adds where the 10-limb form
+// has one pass of ten.  Correct for reduced inputs (limbs < 2^29 + slack: 9 * 2^58 < 2^64); no room for the lazy sums
+// the point formulas of ge25519.h live on (operands up to 2^31).  Product only: a chain of dependent products.
+struct fe9 {
+    uint32_t v[9];
+};
+__device__ __forceinline__ fe9 fe9_mul(const fe9 &f, const fe9 &g) {
+    uint64_t c[17];
+#pragma unroll
+    for (int k = 0; k < 17; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)f.v[i] * g.v[j];
+    // carry the 17 columns down to 29-bit limbs (the last carry is an 18th limb)
+    uint32_t r[18];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        const uint64_t t = c[k] + carry;
+        r[k] = (uint32_t)t & 0x1fffffffu;
+        carry = t >> 29;
+    }
+    r[17] = (uint32_t)carry;
+    // fold limbs 9..17 (weight 2^261 * 2^(29 (k - 9))) with 1216, carry again
+    fe9 o;
+    carry = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const uint64_t t = (uint64_t)r[k] + (uint64_t)r[k + 9] * 1216u + carry;
+        o.v[k] = (uint32_t)t & 0x1fffffffu;
+        carry = t >> 29;
+    }
+    o.v[0] += (uint32_t)carry * 1216u;          // < 2^29 + 2^22: within the slack of a reduced limb
+    return o;
+}
+__global__ void k_chain9(const uint32_t *in, uint32_t *out, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fe9 x, y;
+    for (int k = 0; k < 9; k++) {
+        x.v[k] = in[8 * (i & 1023) + (k & 7)] & 0x1fffffffu;
+        y.v[k] = in[8 * ((i + 7) & 1023) + (k & 7)] & 0x1fffffffu;
+    }
+    for (int k = 0; k < iters; k++) {
+        x = fe9_mul(x, y);
+        y = fe9_mul(y, x);
+    }
+    for (int k = 0; k < 8; k++) out[8 * i + k] = x.v[k] + y.v[k] + (k == 0 ? x.v[8] ^ y.v[8] : 0);
+}
+
 template <typename K> double run(K kern, int blocks, int threads, const uint32_t *din, uint32_t *dout, int iters) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -79,6 +133,10 @@ int main() {
     thr4 = run(k_chain4<1>, B, T, din, dout, iters / 2);
     printf("fe_sqr  latency %.1f ns (1 wave) | %.1f G/s (chain) | %.1f G/s (4 chains)\n", lat * 1e6 / (2.0 * iters),
            2.0 * iters * B * T / (thr * 1e-3) / 1e9, 4.0 * (iters / 2) * B * T / (thr4 * 1e-3) / 1e9);
+    lat = run(k_chain9, 1, 64, din, dout, iters);
+    thr = run(k_chain9, B, T, din, dout, iters);
+    printf("fe9_mul (9 x 29-bit limbs, product only) latency %.1f ns (1 wave) | %.1f G/s (chain)\n",
+           lat * 1e6 / (2.0 * iters), 2.0 * iters * B * T / (thr * 1e-3) / 1e9);
     for (int blocks : {256 * 2, 256 * 3, 256 * 4, 256 * 8}) {
         double m = run(k_madd, blocks, T, din, dout, 500);
         printf("ge_madd %d blocks x 256: %.2f G madd/s  (%.1f G fe_mul-equivalents/s)\n", blocks,

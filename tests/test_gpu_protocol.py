@@ -476,6 +476,36 @@ def test_rounds_queued_ahead_of_their_challenge(vm, monkeypatch, log_n, jump_k, 
         assert vm.compressed_pivot.protocol_5_verifier(gens, P, Lf, y, proof, gf, transcript="compact") is True
 
 
+def test_nothing_grows_while_a_wait_is_queued(vm):
+    """The invariant the queued-ahead rounds rest on (csrc/prover.hip): with a stream wait pending that only the calling
+    thread can release, a call that would have to grow the context's workspace or its pinned block - both synchronise
+    the stream to do so - returns an error instead of hanging.  The state is set through the library's test hook."""
+    import numpy as np
+    from verifiable_mpc_amd import _native
+    ctx = _native.Context(0)
+    try:
+        lib = ctx.lib
+        n = 1 << 12
+        pts = ctx.alloc(64 * n)
+        base = ctx.upload(np.frombuffer(vm.Ed25519Point.generator.to_affine_bytes(), np.uint8))
+        sc = ctx.upload(_native.ints_to_array(list(range(1, n + 1)), 32))
+        ctx.fixed_base(base.ptr, sc.ptr, n, pts.ptr)
+        out = ctx.alloc(128)
+        ctx.msm(sc.ptr, pts.ptr, 64, None, None, 0, out.ptr, None)          # a small workspace exists now
+        ctx.sync()
+        assert lib.vmpc_ctx_debug_hold_wait(ctx.handle, 1) == 0
+        with pytest.raises(_native.VmpcError) as ei:
+            ctx.msm(sc.ptr, pts.ptr, n, None, None, 0, out.ptr, None)       # 64x the terms: the arena has to grow
+        assert ei.value.code == _native.E_INVAL
+        assert b"would grow while the stream waits" in lib.vmpc_last_error()
+        assert lib.vmpc_ctx_debug_hold_wait(ctx.handle, 0) == 0
+        ctx.msm(sc.ptr, pts.ptr, n, None, None, 0, out.ptr, None)           # and afterwards it simply grows
+        ctx.sync()
+    finally:
+        ctx.lib.vmpc_ctx_debug_hold_wait(ctx.handle, 0)
+        ctx.close()
+
+
 @pytest.mark.parametrize("n_table,with_h", [(128, False), (127, True)])
 def test_protocol4_over_a_prefix_of_a_tabulated_crs(vm, n_table, with_h):
     """protocol_4_prover(g[:m], ...) with g[:m] a STRICT prefix of a tabulated vector (PointVector slices keep

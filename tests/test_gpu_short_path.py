@@ -138,6 +138,38 @@ def test_short_path_exponent_identity_and_general_path(nat, ctx, lg):
         assert ext_affine(r) == ed.pt_affine(ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(x, exps)) % ELL))
 
 
+@pytest.mark.parametrize("kind", ["three_values", "same_scalar", "same_small"])
+def test_short_path_heavy_buckets(nat, ctx, kind):
+    """several whole-workgroup buckets in one bin (scalars from {1, 2, 3}); every term the same scalar (one bucket per
+    window takes everything: 6000 entries per workgroup, or - when two windows' digits share a bin - more than a bin
+    holds, and then the answer must be VMPC_E_AGAIN, never a wrong point)"""
+    rng = random.Random(len(kind))
+    n = 12345 if kind != "three_values" else 6000
+    exps = [rng.randrange(1, ELL) for _ in range(n)]
+    pts = gpu_points(nat, ctx, exps)
+    table = ctx.msm_table_build(pts.ptr, n, None, 0, 16)
+    out = ctx.alloc(128)
+    for trial in range(4):
+        if kind == "three_values":
+            x = [rng.randrange(1, 4) for _ in range(n)]
+        elif kind == "same_scalar":
+            x = [rng.randrange(ELL)] * n
+        else:
+            x = [rng.randrange(1, 1 << 40)] * n
+        ds = ctx.upload(sc_bytes(nat, x))
+        want = ed.pt_affine(ed.pt_repeat(ed.BASE, sum(a * b for a, b in zip(x, exps)) % ELL))
+
+        def launch():
+            ctx.msm_table(table.ptr, n, 0, ds.ptr, n, None, out.ptr, None, 16)
+            ctx.sync()
+        try:
+            launch()
+        except nat.VmpcError as e:
+            assert e.code == nat.E_AGAIN and kind != "three_values"
+            ctx.on_general_path(launch)
+        assert ext_affine(ctx.download(out.ptr, 128).tobytes()) == want, (kind, trial)
+
+
 def test_short_path_reports_non_canonical_scalars(nat, ctx):
     rng = random.Random(5)
     exps = [rng.randrange(1, ELL) for _ in range(40)]

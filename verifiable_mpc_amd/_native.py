@@ -26,7 +26,7 @@ SCALAR_BYTES, AFFINE_BYTES, PROJ_BYTES, EXT_BYTES = 32, 64, 96, 128
 # against the header and against the built library)
 SYMBOLS = [
     "vmpc_backend_info", "vmpc_last_error", "vmpc_ctx_create", "vmpc_ctx_destroy",
-    "vmpc_ctx_set_stream", "vmpc_ctx_sync", "vmpc_ctx_set_short_path", "vmpc_ctx_query", "vmpc_ctx_wait_for", "vmpc_malloc", "vmpc_free", "vmpc_memcpy_h2d",
+    "vmpc_ctx_set_stream", "vmpc_ctx_sync", "vmpc_ctx_set_short_path", "vmpc_ctx_debug_hold_wait", "vmpc_ctx_query", "vmpc_ctx_wait_for", "vmpc_malloc", "vmpc_free", "vmpc_memcpy_h2d",
     "vmpc_memcpy_d2h", "vmpc_memcpy_d2d", "vmpc_ctx_profile", "vmpc_ctx_profile_read",
     "vmpc_ctx_set_window", "vmpc_ed25519_msm_plan", "vmpc_ed25519_madd_rate", "vmpc_ed25519_msm", "vmpc_ed25519_fold",
     "vmpc_ed25519_fixed_base_batch", "vmpc_fr_axpy", "vmpc_fr_dot", "vmpc_points_validate_dev",
@@ -77,6 +77,7 @@ def load_library():
         "vmpc_ctx_set_stream": (i32, [vp, vp]),
         "vmpc_ctx_sync": (i32, [vp]),
         "vmpc_ctx_set_short_path": (i32, [vp, i32]),
+        "vmpc_ctx_debug_hold_wait": (i32, [vp, i32]),
         "vmpc_ctx_query": (i32, [vp, ctypes.POINTER(i32)]),
         "vmpc_ctx_wait_for": (i32, [vp, vp]),
         "vmpc_malloc": (i32, [vp, sz, ctypes.POINTER(vp)]),

@@ -159,6 +159,16 @@ extern "C" int vmpc_ctx_sync(vmpc_ctx *ctx) {
     return VMPC_OK;
 }
 
+// Test hook for the one invariant of the queued-ahead prover (prover.hip): while work sits behind a
+// hipStreamWaitValue32 that only this thread can release, nothing may synchronise the stream - so the arena and the
+// pinned block must REFUSE to grow (an error, not a deadlock).  Marks the context as holding such a wait without
+// queueing one; tests/test_gpu_protocol.py::test_nothing_grows_while_a_wait_is_queued.
+extern "C" int vmpc_ctx_debug_hold_wait(vmpc_ctx *ctx, int on) {
+    if (!ctx) return VMPC_E_INVAL;
+    ctx->stream_waits = on != 0;
+    return VMPC_OK;
+}
+
 extern "C" int vmpc_ctx_set_short_path(vmpc_ctx *ctx, int on) {
     if (!ctx) return VMPC_E_INVAL;
     ctx->short_path = on ? 1 : 0;
