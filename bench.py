@@ -492,9 +492,13 @@ def distribution_timing(vm, ctx, pows):
 
 def clocks_sample():
     """one reading of the GPU's clocks and power cap (rocm-smi), so that box-to-box spread of the headline has
-    something to be read against; best effort"""
+    something to be read against; best effort.  Taken FIRST, before this process touches the GPU (a child started
+    later would be a program exec'd from a GPU-initialised process), and not at all under a profiler's preload
+    (rocprofv3 initialises the GPU inside every process it is preloaded into, the child included)."""
     import shutil
     import subprocess
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return {"skipped": "running under a profiler preload"}
     exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     out = {}
     try:
@@ -894,6 +898,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    gpu_clocks = clocks_sample() if rank == 0 else None          # before anything below initialises the GPU
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import torch
     ndev = torch.cuda.device_count()
@@ -1223,7 +1228,7 @@ def main():
                                       if shard.collective else "none"),
                        "dist_backend": args.dist_backend if dist else None,
                        "comm": comm_info,
-                       "gpu_clocks": clocks_sample() if rank == 0 else None,
+                       "gpu_clocks": gpu_clocks,
                        "launched_by": ("bench.py itself (child processes)" if os.environ.get("VMPC_BENCH_SELF_LAUNCHED")
                                        else "external launcher" if "WORLD_SIZE" in os.environ else "plain process")},
             "roofline": {"bound": "hbm", "kernel": "k_msm_bucket", "achieved": achieved,

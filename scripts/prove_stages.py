@@ -55,6 +55,11 @@ if len(sys.argv) > 2:
     r = vm.ScalarVector.from_array(rs(rng, n))
     proof = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, 777, gf, transcript="compact", r=r, rho=5)
     for i, (wall, st) in enumerate(log):
+        if "short_bins" in st:       # the fused three-launch path (csrc/msm_short.hip)
+            print(f"round {i:2d} wall {wall:6.3f} ms  short path: scatter {st.get('short_scatter')} bins {st.get('short_bins')} "
+                  f"combine {st.get('short_combine')} fold {st.get('table_fold')} "
+                  f"scal {sum(st.get(k, 0) for k in ('p4_fold_dots','fr_tail_scalars','p4_extras'))}")
+            continue
         print(f"round {i:2d} wall {wall:6.3f} ms  bucket {st.get('msm_bucket')} reduce {st.get('msm_reduce')} final {st.get('msm_final')} "
               f"sort {sum(st.get(k, 0) for k in ('msm_recode','msm_hist','msm_part','msm_sort','msm_plan'))} fold {st.get('table_fold')} "
               f"finish {st.get('msm_bucket_finish')} scal {sum(st.get(k, 0) for k in ('p4_fold_dots','fr_tail_scalars','p4_extras'))}")

@@ -648,7 +648,8 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
     int lb = p.c - 1;
     if (lb > 9) lb = 9;
     while (lb > 0 && (p.nb >> lb) < 512 && (p.n_total >> (p.c - 1 - lb)) > 8192) lb--;
-    if (ctx->sort_fine_bits >= 0 && ctx->sort_fine_bits <= lb && (p.nb >> ctx->sort_fine_bits) <= 4096)
+    if (ctx->sort_fine_bits >= 0 && ctx->sort_fine_bits <= 9 && ctx->sort_fine_bits <= p.c - 1 &&
+        (p.nb >> ctx->sort_fine_bits) <= 4096)
         lb = ctx->sort_fine_bits;                                                          // tuning knob
     p.LB = lb;
     p.NC = p.nb >> lb;                                       // <= 4096 (c <= 16, lb >= 3 whenever nb > 4096)

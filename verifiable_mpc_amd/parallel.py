@@ -131,6 +131,17 @@ class HipBackend:
         return self._launch_partial(ctx, scalars, points, slot)
 
     def _launch_partial(self, ctx, scalars, points, slot):
+        # The fused short path (csrc/msm_short.hip) answers scalars beyond its capacities with "repeat this call" at the
+        # next synchronisation - an answer a pipeline of launches in flight, let alone one followed by a collective
+        # that has already summed the void partial on every rank, cannot act on: this backend's commitments always
+        # take the general path.
+        ctx.set_short_path(False)
+        try:
+            self._launch_partial_general(ctx, scalars, points, slot)
+        finally:
+            ctx.set_short_path(True)
+
+    def _launch_partial_general(self, ctx, scalars, points, slot):
         table = getattr(points, "_table", None)
         if isinstance(scalars, (list, tuple)):
             # a BATCH of commitments over the same prepared generators in one pass (vmpc_msm_table_batch_dev):
