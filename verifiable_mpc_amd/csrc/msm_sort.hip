@@ -645,9 +645,15 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
     // so narrow that a chunk's run of a bin (8192 / NC entries) drops below a quarter line.
     p.idx_bits = 1;
     while (((size_t)1 << p.idx_bits) < p.n_pad) p.idx_bits++;
+    // (Rows of 2^22 positions and more - the digit rows of a 4- / 8- / 16-row table over a large CRS - stop at 256
+    // coarse bins: the histogram and partition kernels scan and scatter per BIN, the fine sort's tiled path takes the
+    // 16-32 K entries of such a bin in its stride; round 5, scripts/pair_sort_probe.py: one commitment over the 4-row
+    // table at 2^20 1.187 -> 1.17 ms, a prover round's pair over the 8-row table 1.18 -> 1.16 ms, 2^21 over 4 rows
+    // 2.09 -> 2.02 ms; 128 bins are better still for the pair and worse for a single vector, 64 are 0.4 ms worse.)
+    const int nc_target = p.n_total >= ((size_t)1 << 22) ? 256 : 512;
     int lb = p.c - 1;
     if (lb > 9) lb = 9;
-    while (lb > 0 && (p.nb >> lb) < 512 && (p.n_total >> (p.c - 1 - lb)) > 8192) lb--;
+    while (lb > 0 && (p.nb >> lb) < nc_target && (p.n_total >> (p.c - 1 - lb)) > 8192) lb--;
     if (ctx->sort_fine_bits >= 0 && ctx->sort_fine_bits <= 9 && ctx->sort_fine_bits <= p.c - 1 &&
         (p.nb >> ctx->sort_fine_bits) <= 4096)
         lb = ctx->sort_fine_bits;                                                          // tuning knob
