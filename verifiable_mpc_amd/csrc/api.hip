@@ -69,6 +69,8 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
     const char *sp = getenv("VMPC_SHORT_PATH");          // 0: commitments over short 16-row tables take the general path
     if (sp) c->short_path = atoi(sp) != 0;
     // measured and left at their defaults (only with VMPC_EXPERIMENTAL=1):
+    const char *bb = vmpc_getenv_experimental("VMPC_BUCKET_BLOCK");
+    if (bb && atoi(bb) == 1024) c->bucket_block = 1024;
     const char *bw = vmpc_getenv_experimental("VMPC_BUCKET_WGS_PER_CU");
     if (bw && atoi(bw) >= 0) c->bucket_wgs_per_cu = atoi(bw);
     const char *sf = vmpc_getenv_experimental("VMPC_SORT_FINE_BITS");   // fine bits of the two-level bucket sort

@@ -52,6 +52,7 @@ struct vmpc_ctx {
     size_t ws_used = 0;
     uint32_t *d_status = nullptr;
     int window_override = 0;
+    int bucket_block = 256;        // threads per workgroup of k_msm_bucket (1024: experiment, msm.hip)
     int bucket_wgs_per_cu = 0;     // > 0: persistent bucket kernel with this many 256-thread workgroups per CU
     int reduce_max_chunks = 32768; // most chunk-lanes per bucket set in the bucket reduction (msm_sort.hip)
     int reduce_chunks_override = 0; // > 0: chunk-lanes per bucket set, fixed (power of two)

@@ -63,7 +63,8 @@ __device__ __forceinline__ ge_niels niels_ld(const uint32_t *niels, uint32_t e) 
 #ifndef MSM_BUCKET_WAVES
 #define MSM_BUCKET_WAVES 4
 #endif
-__global__ void __launch_bounds__(MSM_BLOCK, MSM_BUCKET_WAVES)
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, BLOCK == MSM_BLOCK ? MSM_BUCKET_WAVES : 1)
 k_msm_bucket(const uint32_t *__restrict__ niels, const uint32_t *__restrict__ sorted,
              const uint32_t *__restrict__ starts, const uint32_t *__restrict__ counts,
              const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ seg_starts,
@@ -427,9 +428,17 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
         unsigned grid = (unsigned)((w.t_max + MSM_BLOCK - 1) / MSM_BLOCK);
         if (ctx->bucket_wgs_per_cu > 0 && (unsigned)(ctx->bucket_wgs_per_cu * ctx->cu_count) < grid)
             grid = (unsigned)(ctx->bucket_wgs_per_cu * ctx->cu_count);
-        k_msm_bucket<<<grid, MSM_BLOCK, 0, bst>>>(
-            entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
-            (int)msm_seg_len(p), p.balanced, w.buckets, w.seg_partial);
+        if (ctx->bucket_block == 1024) {
+            // experiment (VMPC_EXPERIMENTAL=1 VMPC_BUCKET_BLOCK=1024): one workgroup fills a CU, so a retiring one frees
+            // a whole CU at once - room for the 1024-thread sort workgroups of the other streams
+            k_msm_bucket<1024><<<(grid + 3) / 4, 1024, 0, bst>>>(
+                entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
+                (int)msm_seg_len(p), p.balanced, w.buckets, w.seg_partial);
+        } else {
+            k_msm_bucket<MSM_BLOCK><<<grid, MSM_BLOCK, 0, bst>>>(
+                entries, w.sorted, w.starts, w.counts, w.nseg, w.seg_starts, w.tasks, w.ctrl + 1, p.nb1,
+                (int)msm_seg_len(p), p.balanced, w.buckets, w.seg_partial);
+        }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             ctx->stage_stream = nullptr;
