@@ -24,7 +24,11 @@ def counter_avgs(dirname, counter):
             for r in csv.DictReader(f):
                 if r.get("Counter_Name") != counter:
                     continue
+                # "void k_msm_bucket<256>(unsigned int const*, ...)" -> "k_msm_bucket": templated kernels carry their
+                # return type and arguments in the profiler's name
                 name = r["Kernel_Name"].split("(")[0]
+                name = name[5:] if name.startswith("void ") else name
+                name = name.split("<")[0]
                 rows.setdefault(name, []).append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in rows.items()}
 

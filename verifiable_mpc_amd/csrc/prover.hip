@@ -828,6 +828,16 @@ int p4_poll(volatile uint32_t *word, uint32_t want, double seconds, hipStream_t 
 }
 }  // namespace
 
+// A queued round is detected by the completion word its commitment's LAST kernel publishes; the launch of that kernel
+// takes ctx->done_flag_dev (k_msm_final, k_msm_reduce_combine, k_p4_direct_sum).  A commitment path that does not
+// would leave the host polling for 20 s: fail at once instead.
+static int p4_flag_consumed(vmpc_ctx *ctx) {
+    if (!ctx->done_flag_dev) return VMPC_OK;
+    ctx->done_flag_dev = nullptr;
+    snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "vmpc_p4_run_compact: the round's commitment did not take the completion word");
+    return VMPC_E_HIP;
+}
+
 static bool p4_can_queue_ahead(vmpc_p4 *p) {
     if (p->comm || vmpc_getenv_experimental("VMPC_P4_NO_QUEUE_AHEAD")) return false;
     int can = 0;
@@ -888,6 +898,7 @@ extern "C" int vmpc_p4_run_compact(vmpc_p4 *p, uint8_t state[32], int first_roun
             ctx->done_flag_dev = mb.done_d;                  // the commitment's last kernel publishes the completion
             ctx->done_seq = done_seq;
             if (rc == VMPC_OK) rc = p4_round_enqueue(p, nullptr);
+            if (rc == VMPC_OK) rc = p4_flag_consumed(ctx);
             if (rc != VMPC_OK) return bail(rc);
         }
         // queue round i + 1 behind the wait, unless its fold of the witness is followed by a fold of the generators
@@ -906,6 +917,7 @@ extern "C" int vmpc_p4_run_compact(vmpc_p4 *p, uint8_t state[32], int first_roun
             ctx->done_flag_dev = mb.done_d;
             ctx->done_seq = go_seq + 1;
             if (rc == VMPC_OK) rc = p4_round_enqueue(p, mb.challenge_d);
+            if (rc == VMPC_OK) rc = p4_flag_consumed(ctx);
             if (rc != VMPC_OK) return bail(rc);
         }
         // round i's pair
