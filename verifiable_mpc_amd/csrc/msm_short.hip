@@ -218,21 +218,31 @@ k_short_bins(const uint32_t *__restrict__ table, const uint32_t *__restrict__ bi
         acc = sh_sum(table, srt, s0 + (uint32_t)h, c <= SH_HEAVY ? s0 + c : s0, 2);
     }
     // a bucket that holds a large share of the workgroup's entries (small witness values: most scalars of a circuit's
-    // wire vector are 0, 1 or 2, circuit_sat_cb.py:91-103): every lane sums a stride of it, the 512 partial sums go
+    // wire vector are 0, 1 or 2, circuit_sat_cb.py:91-103): a group of lanes sums it in strides, the partial sums go
     // through a quad tree in the staging area, the bucket's first lane takes the result
-    for (uint32_t hi = 0; hi < n_heavy; hi++) {
-        const uint32_t hb = heavy[1 + hi], c = cnt[hb], s0 = start[hb];
-        const ge_ext part = sh_sum(table, srt, s0 + (uint32_t)tid, s0 + c, SH_THREADS);
-        __syncthreads();                 // (the previous bucket's result has been read)
+    // ALL of the workgroup's heavy buckets at once: 512 / (their number, rounded up to a power of two) lanes each
+    if (n_heavy) {
+        int groups = 1;
+        while ((uint32_t)groups < n_heavy) groups <<= 1;
+        const int lanes_per = SH_THREADS / groups;
+        const int gi = tid / lanes_per, li = tid % lanes_per;
+        ge_ext part = ge_ext_identity();
+        if ((uint32_t)gi < n_heavy) {
+            const uint32_t hb = heavy[1 + gi], c = cnt[hb], s0 = start[hb];
+            part = sh_sum(table, srt, s0 + (uint32_t)li, s0 + c, (uint32_t)lanes_per);
+        }
         ext_st(stage + EXT_WORDS * tid, part);
         __syncthreads();
         const int q = tid & 3;
-        for (int mm = SH_THREADS / 2; mm >= 1; mm >>= 1) {
-            for (int j = tid >> 2; j < mm; j += SH_THREADS / 4)
-                rt_st(stage, j, q, rt_add(rt_ld(stage, j, q), rt_ld(stage, j + mm, q), q));
+        for (int mm = lanes_per / 2; mm >= 1; mm >>= 1) {
+            for (int job = tid >> 2; job < groups * mm; job += SH_THREADS / 4) {
+                const int base = (job / mm) * lanes_per, j = job % mm;
+                rt_st(stage, base + j, q, rt_add(rt_ld(stage, base + j, q), rt_ld(stage, base + j + mm, q), q));
+            }
             __syncthreads();
         }
-        if (tid == 2 * (int)hb) acc = ge_add(acc, ext_ld(stage));
+        for (uint32_t hi = 0; hi < n_heavy; hi++)
+            if (tid == 2 * (int)heavy[1 + hi]) acc = ge_add(acc, ext_ld(stage + EXT_WORDS * (size_t)hi * lanes_per));
     }
     __syncthreads();
     // the two lanes of a bucket -> its sum, as leaf b of the tree
