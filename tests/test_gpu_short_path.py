@@ -202,8 +202,16 @@ def test_vector_commitment_repeats_an_overflowing_call_on_the_general_path():
     assert vm.pivot.vector_commitment(ones, 5, g, h) == want
     a, b = vm.pivot.vector_commitment_pair(ones, 5, g, ones, 6, g, h)
     assert a == want and b == vm.Ed25519Point.repeat(group.generator, (tot + 6) % ELL)
-    # and the context is back on the short path afterwards
+    # two commitments pending on ONE context, the second one overflows: whoever synchronises first collects the
+    # context's status word, but a void result says so itself (Z = 0) - both come out right
     uni = vm.ScalarVector.from_array(exps)
+    ctx = g.ctx
+    first = vm.pivot._commit_launch(uni, 7, g, h, ctx)
+    second = vm.pivot._commit_launch(ones, 9, g, h, ctx)
+    dot = sum(int.from_bytes(bytes(e), "little") ** 2 for e in exps) % ELL
+    assert first.result() == vm.Ed25519Point.repeat(group.generator, (dot + 7) % ELL)
+    assert second.result() == vm.Ed25519Point.repeat(group.generator, (tot + 9) % ELL)
+    # and the context is back on the short path afterwards
     ctx = g.ctx
     ctx.profile(True)
     ctx.profile_read(reset=True)

@@ -97,7 +97,7 @@ k_msm_reduce_tree(const uint32_t *__restrict__ buckets, const uint32_t *__restri
 __global__ void __launch_bounds__(RT_THREADS)
 k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_t *__restrict__ out,
                      uint32_t *__restrict__ out_packed, uint32_t *done_counter, uint32_t *done_flag, uint32_t done_seq,
-                     int spl, uint32_t *__restrict__ reset, int reset_words) {
+                     int spl, uint32_t *__restrict__ reset, int reset_words, const uint32_t *__restrict__ poison) {
     extern __shared__ __align__(16) uint32_t rt_lds[];
     uint32_t *TA = rt_lds;
     uint32_t *US = TA + (size_t)G * EXT_WORDS;
@@ -132,6 +132,10 @@ k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_
     if (G > 1) R = rt_add(R, rt_ld(RR, 0, q), q);
     for (int k = 0; k < log2L; k++) R = quadD_dbl(R, q);
     R = rt_add(R, rt_ld(US, 0, q), q);
+    // poison[w] != 0 (msm_short.hip: THIS commitment's scalars were beyond the fused path's capacities): the result is
+    // void and goes out as all zeros - Z = 0 is no point, so a consumer can tell which of several commitments on a
+    // context it was, whoever collected the context's status word
+    if (poison && poison[w]) R = fe_zero();
     if (threadIdx.x < 4) {
         if (out_packed) fe_st8(out_packed + 32 * (size_t)w + 8 * q, R);      // one bucket set per commitment: its result
         else fe_st(out + EXT_WORDS * (size_t)w + FE_LIMBS * q, R);
@@ -178,7 +182,7 @@ int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st,
     VMPC_KERNEL_CHECK();
     k_msm_reduce_combine<<<p.W, RT_THREADS, lds_b, st>>>(triples, G, msm_ilog2(L), w.partials, (uint32_t *)out_packed,
                                                          ctx->d_status + VMPC_ST_WORDS, out_packed ? ctx->done_flag_dev : nullptr,
-                                                         ctx->done_seq, 1, nullptr, 0);
+                                                         ctx->done_seq, 1, nullptr, 0, nullptr);
     if (out_packed) ctx->done_flag_dev = nullptr;
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
@@ -186,7 +190,7 @@ int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st,
 
 // the second kernel alone, for triples somebody else produced (msm_short.hip): W windows of G groups x spl parts
 int msm_reduce_combine_launch(vmpc_ctx *ctx, const uint32_t *triples, int W, int G, int spl, uint32_t *scratch_out,
-                              void *out_packed, uint32_t *reset, int reset_words) {
+                              void *out_packed, uint32_t *reset, int reset_words, const uint32_t *poison) {
     hipStream_t st = ctx->stream;
     if (!ctx->reduce_tree_ready && !ctx->short_ready)
         VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_reduce_combine,
@@ -194,7 +198,7 @@ int msm_reduce_combine_launch(vmpc_ctx *ctx, const uint32_t *triples, int W, int
     const size_t lds_b = (size_t)(4 * G + 1) * EXT_WORDS * 4;
     k_msm_reduce_combine<<<W, RT_THREADS, lds_b, st>>>(triples, G, 0, scratch_out, (uint32_t *)out_packed,
                                                        ctx->d_status + VMPC_ST_WORDS, out_packed ? ctx->done_flag_dev : nullptr,
-                                                       ctx->done_seq, spl, reset, reset_words);
+                                                       ctx->done_seq, spl, reset, reset_words, poison);
     if (out_packed) ctx->done_flag_dev = nullptr;
     VMPC_KERNEL_CHECK();
     return VMPC_OK;

@@ -21,7 +21,8 @@
 // 2 x 128: the chip's 256 CUs each get one.  Capacities are fixed (SH_T entries per workgroup, SH_MAX_HEAVY whole-
 // workgroup buckets); an input beyond them - only possible for adversarially skewed scalars - raises
 // VMPC_ST_SHORT_OVERFLOW, vmpc_ctx_sync answers VMPC_E_AGAIN and the caller repeats the call on the general path
-// (verifiable_mpc_amd/pivot.py, compressed_pivot.py).  The group element is the same as the general path's; its
+// (verifiable_mpc_amd/pivot.py, compressed_pivot.py); the void result itself goes out as all zeros (Z = 0 is no point),
+// so that with several commitments pending on one context each can tell whether it was the one.  The group element is the same as the general path's; its
 // extended representative (X : Y : Z : T) is not defined (lists are filled in atomic order) - every consumer
 // normalises.
 #include "common.h"
@@ -49,9 +50,11 @@ struct sh_scalars {
 // ---- 1. recode + bin -------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(MSM_BLOCK)
 k_short_scatter(sh_scalars a, size_t m, size_t table_n, size_t n_extra, size_t stride, msm_modulus mod, uint32_t cap,
-                uint32_t *__restrict__ cursors, uint32_t *__restrict__ bins, uint32_t *__restrict__ status) {
+                uint32_t *__restrict__ cursors, uint32_t *__restrict__ bins, uint32_t *__restrict__ status,
+                uint32_t *__restrict__ poison) {
     __shared__ uint32_t cnt[SH_BINS], base[SH_BINS];
     const int k = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) poison[k] = 0;      // this call's own overflow word (set by k_short_bins)
     const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (threadIdx.x < SH_BINS) cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -141,7 +144,8 @@ __device__ __forceinline__ ge_ext sh_sum(const uint32_t *__restrict__ table, con
 
 __global__ void __launch_bounds__(SH_THREADS)
 k_short_bins(const uint32_t *__restrict__ table, const uint32_t *__restrict__ bins, const uint32_t *__restrict__ cursors,
-             uint32_t cap, int spl, uint32_t *__restrict__ out3, uint32_t *__restrict__ status) {
+             uint32_t cap, int spl, uint32_t *__restrict__ out3, uint32_t *__restrict__ status,
+             uint32_t *__restrict__ poison) {
     extern __shared__ __align__(16) uint32_t sh_lds[];
     uint32_t *srt = sh_lds;                        // [SH_T] entries in bucket order
     uint32_t *stage = srt + SH_T;                  // [SH_STAGE_WORDS]
@@ -209,7 +213,10 @@ k_short_bins(const uint32_t *__restrict__ table, const uint32_t *__restrict__ bi
         n_heavy = SH_MAX_HEAVY;
         overflow = true;
     }
-    if (overflow && tid == 0) atomicAdd(&status[VMPC_ST_SHORT_OVERFLOW], 1u);
+    if (overflow && tid == 0) {
+        atomicAdd(&status[VMPC_ST_SHORT_OVERFLOW], 1u);
+        poison[k] = 1;               // the combine kernel voids THIS commitment's output
+    }
     // every bucket: two lanes, entries of even / odd rank
     const int b = tid >> 1, h = tid & 1;
     ge_ext acc;
@@ -268,7 +275,7 @@ k_short_bins(const uint32_t *__restrict__ table, const uint32_t *__restrict__ bi
 
 // ---- host side --------------------------------------------------------------------------------------------------------
 int msm_reduce_combine_launch(vmpc_ctx *ctx, const uint32_t *triples, int W, int G, int spl, uint32_t *scratch_out,
-                              void *out_packed, uint32_t *reset, int reset_words);      // msm_reduce_tree.hip
+                              void *out_packed, uint32_t *reset, int reset_words, const uint32_t *poison);  // msm_reduce_tree.hip
 
 bool msm_short_fits(const vmpc_ctx *ctx, size_t table_n, size_t table_extra, size_t m, int rows, int c, int K,
                     const void *out_ext, const void *out_affine) {
@@ -298,10 +305,11 @@ int msm_short_batch(vmpc_ctx *ctx, const void *table, size_t table_n, size_t tab
     const size_t bins_bytes = vmpc_align((size_t)K * SH_BINS * cap * 4);
     const size_t tri_bytes = vmpc_align((size_t)K * SH_BINS * spl * 3 * EXT_WORDS * 4);
     const size_t out_bytes = vmpc_align((size_t)K * EXT_WORDS * 4);
-    VMPC_CHECK(vmpc_ws_reserve(ctx, bins_bytes + tri_bytes + out_bytes + 1024));
+    VMPC_CHECK(vmpc_ws_reserve(ctx, bins_bytes + tri_bytes + out_bytes + 2048));
     uint32_t *bins = (uint32_t *)vmpc_ws_take(ctx, bins_bytes);
     uint32_t *triples = (uint32_t *)vmpc_ws_take(ctx, tri_bytes);
     uint32_t *scratch = (uint32_t *)vmpc_ws_take(ctx, out_bytes);
+    uint32_t *poison = (uint32_t *)vmpc_ws_take(ctx, 256);
     sh_scalars a;
     for (int k = 0; k < 2; k++) {
         a.sc[k] = k < K ? (const uint32_t *)scalars[k] : nullptr;
@@ -311,18 +319,19 @@ int msm_short_batch(vmpc_ctx *ctx, const void *table, size_t table_n, size_t tab
     {
         vmpc_stage_scope s(ctx, "short_scatter");
         k_short_scatter<<<dim3((unsigned)((n_cols + MSM_BLOCK - 1) / MSM_BLOCK), K), MSM_BLOCK, 0, st>>>(
-            a, m, table_n, table_extra, stride, modulus, cap, ctx->short_cursors, bins, ctx->d_status);
+            a, m, table_n, table_extra, stride, modulus, cap, ctx->short_cursors, bins, ctx->d_status, poison);
         VMPC_KERNEL_CHECK();
     }
     {
         vmpc_stage_scope s(ctx, "short_bins");
         k_short_bins<<<dim3(SH_BINS, K * spl), SH_THREADS, lds_bytes, st>>>((const uint32_t *)table, bins, ctx->short_cursors,
-                                                                          cap, spl, triples, ctx->d_status);
+                                                                          cap, spl, triples, ctx->d_status, poison);
         VMPC_KERNEL_CHECK();
     }
     {
         vmpc_stage_scope s(ctx, "short_combine");
-        VMPC_CHECK(msm_reduce_combine_launch(ctx, triples, K, SH_BINS, spl, scratch, out_ext, ctx->short_cursors, SH_BINS));
+        VMPC_CHECK(msm_reduce_combine_launch(ctx, triples, K, SH_BINS, spl, scratch, out_ext, ctx->short_cursors, SH_BINS,
+                                             poison));
     }
     ctx->short_ready = true;      // (the combine launcher sets its kernel's LDS limit while this is still false)
     return VMPC_OK;

@@ -385,15 +385,27 @@ class _PendingCommitment:
     def result(self):
         try:
             self.ctx.sync()
+            raw = self.ctx.download(self.out.ptr, 96).tobytes()
+            again = _void_point(raw)        # this commitment overflowed, another caller collected the status word
         except _native.VmpcError as e:
             if e.code != _native.E_AGAIN or self.relaunch is None:
                 raise
+            again = True
+        if again:
+            if self.relaunch is None:
+                raise _native.VmpcError(_native.E_AGAIN, "vector_commitment")
             self.ctx.on_general_path(lambda: (self.relaunch(), self.ctx.sync()))
+            raw = self.ctx.download(self.out.ptr, 96).tobytes()
         # the kernel leaves the sum in extended coordinates; the one field inversion of
         # .normalize() is O(1) host glue (25 us of big-int pow vs a 120 us single-lane chain)
-        raw = self.ctx.download(self.out.ptr, 96).tobytes()
         self.keepalive = None
         return Ed25519Point.from_proj_bytes(raw).normalize()
+
+
+def _void_point(raw):
+    """Z = 0: what the fused short path writes for a commitment whose scalars were beyond its capacities
+    (csrc/msm_short.hip, csrc/msm_reduce_tree.hip `poison`) - no point of the curve has it"""
+    return raw[64:96] == bytes(32)
 
 
 def _table_args(xs, gamma, gv, h, ctx):
@@ -504,11 +516,15 @@ def vector_commitment_pair(x_a, gamma_a, g_a, x_b, gamma_b, g_b, h):
                 ctx.sync()
             try:
                 launch()
+                raw = ctx.download(out.ptr, 256).tobytes()
+                again = _void_point(raw[:96]) or _void_point(raw[128:224])
             except _native.VmpcError as e:
                 if e.code != _native.E_AGAIN:
                     raise
+                again = True
+            if again:
                 ctx.on_general_path(launch)
-            raw = ctx.download(out.ptr, 256).tobytes()
+                raw = ctx.download(out.ptr, 256).tobytes()
             return (Ed25519Point.from_proj_bytes(raw[:96]).normalize(),
                     Ed25519Point.from_proj_bytes(raw[128:224]).normalize())
     main, aux = gva.ctx, get_aux_context()
