@@ -183,8 +183,12 @@ def test_hash_input_dump_is_what_gets_hashed(vm, golden_small, monkeypatch):
     assert records[n_prover + 1].startswith("Method protocol_4_verifier:")
 
 
-def test_protocol5_n1023_device_mode(vm, golden_n1023, monkeypatch, record_hashes):
+@pytest.mark.parametrize("early_pair", [False, True])
+def test_protocol5_n1023_device_mode(vm, golden_n1023, monkeypatch, record_hashes, early_pair):
+    """N = 1024 in device mode against the reference-made fixture; also with the next round's pair committed over the
+    unfolded vector beside the fold (compressed_pivot._early_pair_*, an experiment that is off by default)"""
     case = golden_n1023
+    monkeypatch.setattr(vm.compressed_pivot, "EARLY_PAIR_MIN", 64 if early_pair else 0)
     group, gens = build_generators(vm, case, monkeypatch, case["seed"] + 1)
     gf = vm.GF(group.order)
     x = vm.ScalarVector.from_ints([h2i(v) for v in case["x"]])

@@ -45,6 +45,13 @@ CHUNK = 4096
 # latency (a 253-doubling chain per round); the remaining rounds keep the generators fixed and
 # put the challenge products into the MSM scalars instead (csrc/frvec.hip k_fr_tail_scalars)
 TAIL_BASE = 1 << 16
+# reference transcript, device mode: down to this vector length the NEXT round's A, B are committed over the vector as it
+# is BEFORE its fold (the challenge goes into the scalars), beside the fold instead of behind it (_early_pair_*).
+# OFF (0): measured in rounds 4 and 5 (EXPERIMENTS.md R5.9) it LOSES - 485 against 472 ms per proof: the pair no longer
+# waits for the fold (15 instead of 42 ms inside vector_commitment_pair), but its four commitments take the vector
+# ALUs the fold needs, the text arrives later and the hash waits longer than before.  VMPC_EXPERIMENTAL=1
+# VMPC_EARLY_PAIR_MIN=16384 turns it on; parity is the same either way (tests/test_gpu_protocol.py runs both).
+EARLY_PAIR_MIN = int(os.environ.get("VMPC_EARLY_PAIR_MIN", "0")) if os.environ.get("VMPC_EXPERIMENTAL", "0") != "0" else 0
 
 
 # ---- group glue on single elements (independent of the is_additive/is_multiplicative flags) ----
@@ -395,6 +402,7 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
     if transcript.mode == "reference" and isinstance(Q, _LazyQ):
         Q = Q.point()
     tail_cs = None           # challenges not yet applied to g_hat (compact tail)
+    early = None             # this round's A, B, launched during the previous round (_early_pair)
     while True:
         if _on_device(L_tilde.coeffs, z_hat):
             z_hat = pivot._as_device(z_hat)
@@ -410,7 +418,10 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
                 and len(g_hat) == m and m >= 4 and (len(g_hat) <= TAIL_BASE or _tabulated(g_hat, k)):
             tail_cs = []
             tail_products = ScalarVector.empty(len(g_hat), g_hat.ctx)     # challenge products per generator
-        if tail_cs is not None:
+        if early is not None:
+            A, B = early()
+            early = None
+        elif tail_cs is not None:
             ctx = g_hat.ctx
             v_a, v_b = ScalarVector.empty(len(g_hat), ctx), ScalarVector.empty(len(g_hat), ctx)
             ctx.fr_tail_scalars_inc(tail_cs[-1] if tail_cs else 0, len(tail_cs), len(g_hat).bit_length() - 1,
@@ -425,26 +436,72 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
         c = transcript.round_challenge(round_i, A, B, g_hat, k, Q, L_tilde)
         logger_cp_hout.debug(f"After hash, hash=\n{c}")
 
+        L_next = _fold_form(L_tilde, c, half, gf)
+        z_next = _fold_witness(z_l, z_r, c, half)
         if tail_cs is not None:
             tail_cs.append(c)
         else:
+            g_l, g_r = g_hat[:half], g_hat[half:]
+            unfolded = g_hat
+            ahead = transcript.mode == "reference" and isinstance(z_next, ScalarVector) and len(g_hat) == m \
+                and isinstance(L_next.coeffs, ScalarVector) and 0 < EARLY_PAIR_MIN <= m and m & (m - 1) == 0
+            # (its scalars on the main stream and two side streams ordered behind them BEFORE the fold is enqueued)
+            prep = _early_pair_prepare(g_hat.ctx, L_next, z_next, c, half, gf) if ahead else None
             # reference transcript: the folded vector's text is the bulk of the next pre-image - folded, formatted
             # and copied slice by slice (PointVector.fold), hashed while the rest is still on its way
             g_hat = g_l.fold(g_r, c, stream_text=transcript.mode == "reference")
+            if ahead:
+                early = _early_pair_launch(unfolded, k, half, prep)
         if transcript.mode == "reference":
             # only the reference pre-image contains Q (compressed_pivot.py:52); the compact
             # chain binds Q once at the start, so the prover need not track it
             Q = _fold_commitment(A, Q, B, c)
-        L_tilde = _fold_form(L_tilde, c, half, gf)
+        L_tilde = L_next
         if transcript.mode == "reference" and isinstance(L_tilde.coeffs, ScalarVector):
             L_tilde.coeffs.text_begin()
-        z_hat = _fold_witness(z_l, z_r, c, half)
+        z_hat = z_next
         if len(z_hat) <= 2:
             if isinstance(z_hat, ScalarVector):
                 z_hat = [gf(v) for v in z_hat.to_ints()]
             proof["z_prime"] = z_hat
             return proof
         round_i += 1
+
+
+def _early_pair_prepare(main, L_next, z_next, c, half, gf):
+    """The next round's A, B WITHOUT waiting for this round's generator fold (reference transcript, device vectors).
+
+    The reference's next round commits to halves of the folded vector g' = [(g_l[i] ** c) * g_r[i]]
+    (compressed_pivot.py:41-42,64); an exact 2^19-element fold takes 8.6 ms and the pair leads the next pre-image
+    (compressed_pivot.py:52), so hashing cannot start before it.  With q = half / 2 and z' = z'_l || z'_r:
+        A' = <z'_l, g'_r> = <c z'_l, g_l[q:]> + <z'_l, g_r[q:]>        B' = <z'_r, g'_l> = <c z'_r, g_l[:q]> + <z'_r, g_r[:q]>
+    - four commitments over slices of the vector as it is NOW, the same group elements (twice the terms: 2 ms of
+    work at 2^20 against the fold's 8.6 on the critical path).  The fold still runs - its text is the bulk of that
+    pre-image - but beside the pair, slice by slice under the hash, not in front of it.
+    This half: the scalars (on the main stream) and two side streams ordered behind THEM - called before the fold is
+    enqueued on the main stream, so that what runs on the side streams does not wait for it."""
+    from .device import get_aux_context
+    q = half // 2
+    z_l, z_r, gamma_a, gamma_b = _round_prover_scalars(L_next, z_next, q, gf)
+    cz_l, cz_r = z_l.scale(c), z_r.scale(c)
+    sa, sb = get_aux_context(5), get_aux_context(6)
+    sa.wait_for(main)
+    sb.wait_for(main)
+    return q, (z_l, z_r, cz_l, cz_r, gamma_a, gamma_b), (sa, sb)
+
+
+def _early_pair_launch(g_hat, k, half, prep):
+    """... and this half: the four commitments over the unfolded vector on the side streams -> a callable that
+    collects (A', B')"""
+    q, (z_l, z_r, cz_l, cz_r, gamma_a, gamma_b), (sa, sb) = prep
+    g_l, g_r = g_hat[:half], g_hat[half:]
+    parts = [pivot._commit_launch(cz_l, 0, g_l[q:], k, sa), pivot._commit_launch(z_l, gamma_a, g_r[q:], k, sa),
+             pivot._commit_launch(cz_r, 0, g_l[:q], k, sb), pivot._commit_launch(z_r, gamma_b, g_r[:q], k, sb)]
+
+    def collect():
+        pts = [p.result() for p in parts]
+        return _gmul(pts[0], pts[1]), _gmul(pts[2], pts[3])
+    return collect
 
 
 def _protocol_4_verifier_compact(g_hat, k, Q, L_tilde, gf, proof, round_i, transcript):
