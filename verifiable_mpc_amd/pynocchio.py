@@ -358,10 +358,6 @@ def _compute_proof_prepared(key, c, h, deltas):
     hv = key.vectors["h*g1"]
     h_ctx = get_aux_context(21)
     h_coeffs = h if isinstance(h, (np.ndarray, list)) else h.coeffs
-    h_head = None
-    if isinstance(h_coeffs, np.ndarray):           # nothing to convert: h goes up before anything is launched
-        h_arr = scalars_to_array(h_coeffs)
-        h_head = h_ctx.upload(h_arr) if len(h_arr) else None
     g1 = [key.vectors[name] for name in _SHARED_G1]
     out_g1 = ctx.alloc(96 * len(g1))
     # three streams: the twist sum (the longest single one) first, the six-sum pass beside it, h's sum on a third -
@@ -374,10 +370,13 @@ def _compute_proof_prepared(key, c, h, deltas):
             tail = [int(getattr(deltas, attr)) for attr, _ in zk] if deltas is not None else []
             pending_twist = (name, key.vectors[name].launch(twist_ctx, head, n_mid, tail))
     ctx.bn256_table_msm_multi(1, [v.table.ptr for v in g1], g1[0].n, head.ptr, n_shared, out_g1.ptr)
-    if h_head is None and not isinstance(h_coeffs, np.ndarray):
-        # the reference's ints: converted on the host while the GPU works through the seven sums over c
+    # h's coefficients: converted (the reference's ints) and uploaded on the third stream while the GPU works through
+    # the seven sums over c (an upload only synchronises the stream it is issued on)
+    if isinstance(h_coeffs, np.ndarray):
+        h_arr = scalars_to_array(h_coeffs)
+    else:
         h_arr = scalars_to_array([h_coeffs[i] for i in range(len(h))])
-        h_head = h_ctx.upload(h_arr) if len(h_arr) else None
+    h_head = h_ctx.upload(h_arr) if len(h_arr) else None
     pending_h = hv.launch(h_ctx, h_head, len(h_arr))
     ctx.sync()
     h_ctx.sync()
