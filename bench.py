@@ -844,6 +844,25 @@ def self_launch(args, argv):
     return worst
 
 
+def oracle_commitment_check(points_affine, scalar_arrs, need, got):
+    """Every commitment in `got` ({scalar-vector index: point}) recomputed by the oracle's C restatement of the
+    reference algorithm over the same host arrays; asserts equality of the canonical affine bytes."""
+    from oracle import c_oracle
+    t0 = time.perf_counter()
+    threads = c_oracle.host_threads()
+    prev = c_oracle.set_threads(threads)
+    try:
+        zero = np.zeros(32, np.uint8)
+        ident = np.zeros(64, np.uint8)
+        ident[32] = 1                                        # (0, 1): h ** 0 times the product
+        for i in need:
+            _, want = c_oracle.vector_commitment(scalar_arrs[i], zero, points_affine, ident)
+            assert got[i].to_affine_bytes() == bytes(want), f"commitment {i} differs from the C oracle"
+    finally:
+        c_oracle.set_threads(prev)
+    return {"commitments": len(need), "threads": threads, "seconds": round(time.perf_counter() - t0, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1150,7 +1169,7 @@ def main():
     # size-independent correctness property at full size, for every commitment of the last launch:
     #     sum_i s_i * (e_i * B) == (sum_i s_i e_i mod l) * B,     the sum running over ALL ranks' shards
     enter("result check")
-    checked = False
+    checked, oracle_check = False, None
     if not no_check:
         need = sorted(set(result_idx) | set(other_idx))
         mine = {i: exponent_sum(scalar_arrs[i], exps_arr, vm.groups.ORDER) for i in need}
@@ -1167,6 +1186,14 @@ def main():
             for pt, i in zip(res, idx):
                 assert pt == want[i], f"MSM property check failed (rank {rank}, scalar vector {i})"
         checked = True
+        if world == 1 and os.environ.get("VMPC_BENCH_ORACLE_CHECK", "1") != "0":
+            # and bit for bit against the C restatement of the REFERENCE algorithm (pivot.py:139-145: a ladder per
+            # term + the product tree; oracle/ed25519_oracle.c, ladders spread over the host's cores) - the same
+            # library the cpu_baseline leg times, here as the checker only, outside every timed region
+            oracle_check = oracle_commitment_check(points_plain.affine_array(), scalar_arrs, need,
+                                                   {i: pt for res, idx in ((results, result_idx),
+                                                                           (other_results, other_idx))
+                                                    for pt, i in zip(res, idx)})
 
     line = None
     if rank == 0:
@@ -1191,9 +1218,15 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 (255-bit modular integers as 10 limbs of 25.5 bits, 32x32->64 multiply-adds)", "data": "synthetic",
             "checked": checked,
-            "checked_how": "exponent identity sum_i s_i (e_i B) == (sum_i s_i e_i mod l) B against the PRODUCT's own "
-                           "fixed-base kernel (not the oracle: tests/test_gpu_msm_large.py pins this path and that "
-                           "kernel against the C oracle bit for bit)",
+            "checked_how": (f"C oracle (reference algorithm: one double-and-add ladder per term + product tree, "
+                            f"pivot.py:139-145), bit-exact on the affine result of {oracle_check['commitments']} "
+                            f"commitment(s) of n=2^{args.log2n} from the last timed launches, "
+                            f"{oracle_check['threads']} host threads, {oracle_check['seconds']} s, outside the timed "
+                            f"region; and the exponent identity on all of them"
+                            if oracle_check else
+                            "exponent identity sum_i s_i (e_i B) == (sum_i s_i e_i mod l) B across ranks against the "
+                            "product's fixed-base kernel (N > 1: each rank holds a shard; the single-GPU line and "
+                            "tests/test_gpu_full_size.py check against the C oracle bit for bit)"),
             "config": {"workload": f"Pedersen vector-commitment MSM, n=2^{args.log2n} Ed25519 "
                                    f"generators per GPU, uniform 252-bit scalars",
                        "terms_per_gpu": n, "total_terms": world * n, "launches_in_flight": depth,

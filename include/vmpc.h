@@ -39,8 +39,10 @@ extern "C" {
 #define VMPC_E_HIP (-5)         /* HIP runtime error, see vmpc_last_error() */
 #define VMPC_E_NODEV (-19)      /* no GPU visible */
 #define VMPC_E_AGAIN (-11)      /* vmpc_ctx_sync: a commitment took the fused short path (16-row table of <= 2^17 columns)
-                                 * and its scalars were skewed beyond that path's fixed capacities; nothing of the call's
-                                 * output is valid - switch the path off (vmpc_ctx_set_short_path) and repeat the call */
+                                 * and its scalars were skewed beyond that path's fixed capacities (e.g. a witness of
+                                 * mostly small values: > ~24 K non-zero digits in one bin); nothing of the call's
+                                 * output is valid - switch the path off (vmpc_ctx_set_short_path) and repeat the call.
+                                 * The context then skips the short path for its next 64 eligible calls by itself. */
 
 #define VMPC_SCALAR_BYTES 32
 #define VMPC_AFFINE_BYTES 64
@@ -60,8 +62,10 @@ int vmpc_ctx_set_stream(vmpc_ctx *ctx, void *hip_stream);
 int vmpc_ctx_sync(vmpc_ctx *ctx);
 /* Commitments over a 16-row fixed-base table of at most 2^17 columns (BASELINE config 2, every prover round after the
  * fold jump) take a fused three-launch path (csrc/msm_short.hip) with fixed capacities; on: the default.  A call whose
- * scalars overflow them is reported by vmpc_ctx_sync as VMPC_E_AGAIN: switch the path off, repeat, switch it on. */
+ * scalars overflow them is reported by vmpc_ctx_sync as VMPC_E_AGAIN: switch the path off, repeat, switch it on.
+ * on = 2: on, and the 64-call back-off that follows an overflow is cleared. */
 int vmpc_ctx_set_short_path(vmpc_ctx *ctx, int on);
+int vmpc_ctx_get_short_path(vmpc_ctx *ctx, int *on);       /* the current setting (callers that switch it off for a call restore THIS) */
 /* test hook: mark the context as holding a queued stream wait (vmpc_p4_run_compact's state between two rounds) -
  * every call that would have to grow the workspace or the pinned block must then fail with VMPC_E_INVAL instead of
  * synchronising a stream that waits on the calling thread */

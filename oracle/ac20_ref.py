@@ -74,6 +74,8 @@ def vector_commitment(x, gamma, g, h, signed_exponents=True):
     `signed_exponents`: field-element exponents pass through pivot._int
     (pivot.py:119-128), i.e. the signed residue; plain Python ints are used as is."""
     assert len(g) >= len(x), "Not enough generators."
+    if hasattr(g, "commit"):        # a c_oracle.PointArray: the same ladders + tree in C (threaded)
+        return g.commit(x, gamma, h, signed_exponents)
     conv = ed.scalar_int if signed_exponents else (lambda v: v)
     terms = [ed.pt_repeat(g[i], conv(x_i)) for i, x_i in enumerate(x)]
     prod = ed.tree_reduce(ed.pt_add, terms, initial=ed.IDENTITY)
@@ -154,7 +156,8 @@ def _sc(v):
 
 
 def compact_generators_digest(generators):
-    data = b"".join(ed.affine_to_bytes(p) for p in generators["g"])
+    g = generators["g"]
+    data = g.affine().tobytes() if hasattr(g, "affine") else b"".join(ed.affine_to_bytes(p) for p in g)
     data += ed.affine_to_bytes(generators["h"]) + ed.affine_to_bytes(generators["k"])
     return chunked_digest(b"vmpc-ac20/gens/v1", data)
 
@@ -201,6 +204,8 @@ def _dot(a, b):
 
 def fold_generators(g_l, g_r, c):
     """compressed_pivot.py:64 / :178: g'_i = (g_l[i] ** c) * g_r[i]."""
+    if hasattr(g_l, "fold"):        # c_oracle.PointArray
+        return g_l.fold(g_r, c)
     return [ed.pt_add(ed.pt_repeat(g_l[i], c), g_r[i]) for i in range(len(g_l))]
 
 
@@ -274,7 +279,7 @@ def protocol_5_prover(generators, P, coeffs, constant, y, x, gamma, r, rho,
     z = [(c0 * x_i + r[i]) % ELL for i, x_i in enumerate(x)]                     # :134
     phi = (c0 * gamma + rho) % ELL                                               # :135
     z_hat = z + [phi]
-    g_hat = list(g) + [h]                                                        # :138
+    g_hat = g.appended(h) if hasattr(g, "appended") else list(g) + [h]                                                        # :138
     Q = ed.pt_add(ed.pt_add(A, ed.pt_repeat(P, c0)),
                   ed.pt_repeat(k, ed.scalar_int(c1 * (c0 * y + t))))             # :140
     Lt = [(c * c1) % ELL for c in coeffs] + [0]                                  # :141
@@ -328,7 +333,7 @@ def protocol_5_verifier(generators, P, coeffs, constant, y, proof, mode="referen
         seed = compact_p5_seed(generators, P, coeffs, y, t, A)
         c0 = compact_challenge(hashlib.sha256(seed + b"\x00").digest())
         c1 = compact_challenge(hashlib.sha256(seed + b"\x01").digest())
-    g_hat = list(g) + [h]
+    g_hat = g.appended(h) if hasattr(g, "appended") else list(g) + [h]
     Q = ed.pt_add(ed.pt_add(A, ed.pt_repeat(P, c0)),
                   ed.pt_repeat(k, ed.scalar_int(c1 * (c0 * y + t))))
     Lt = [(c * c1) % ELL for c in coeffs] + [0]

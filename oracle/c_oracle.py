@@ -20,7 +20,8 @@ _lib = None
 def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", LIB, SRC])
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-pthread", "-o", LIB + ".tmp", SRC])
+        os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
@@ -32,6 +33,10 @@ def lib():
         vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
         _lib.oracle_vector_commitment.restype = i32
         _lib.oracle_vector_commitment.argtypes = [vp, vp, vp, vp, sz, i32, i32, vp, vp]
+        _lib.oracle_vector_commitment_ex.restype = i32
+        _lib.oracle_vector_commitment_ex.argtypes = [vp, vp, i32, vp, vp, sz, i32, i32, vp, vp]
+        _lib.oracle_set_threads.argtypes = [i32]
+        _lib.oracle_get_threads.restype = i32
         _lib.oracle_fold.restype = i32
         _lib.oracle_fold.argtypes = [vp, vp, vp, sz, i32, vp, vp]
         _lib.oracle_fixed_base.restype = i32
@@ -47,13 +52,31 @@ def _u8(a):
     return np.ascontiguousarray(a, dtype=np.uint8)
 
 
-def vector_commitment(x, gamma, g, h, proj_in=False, signed_exp=False):
-    """x: (n,32) u8; gamma: (32,) u8; g: (n,64|96) u8; h: (64|96,) u8 -> (proj 96 B, affine 64 B)."""
+def set_threads(n):
+    """Threads for the independent pieces (ladders, fold elements, one tree level); 1 = the reference's
+    single thread, which is what bench.py's cpu_baseline times.  Returns the previous setting."""
+    prev = lib().oracle_get_threads()
+    lib().oracle_set_threads(int(n))
+    return prev
+
+
+def host_threads():
+    """the cores this process may run on"""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
+def vector_commitment(x, gamma, g, h, proj_in=False, signed_exp=False, gamma_neg=False):
+    """x: (n,32) u8; gamma: (32,) u8; g: (n,64|96) u8; h: (64|96,) u8 -> (proj 96 B, affine 64 B).
+    gamma_neg: `gamma` is the magnitude of a negative exponent."""
     x, gamma, g, h = _u8(x), _u8(gamma), _u8(g), _u8(h)
     n = len(x)
+    assert len(g) >= n
     op, oa = np.zeros(96, np.uint8), np.zeros(64, np.uint8)
-    rc = lib().oracle_vector_commitment(_p(x), _p(gamma), _p(g), _p(h), n, int(proj_in), int(signed_exp),
-                                        _p(op), _p(oa))
+    rc = lib().oracle_vector_commitment_ex(_p(x), _p(gamma), int(gamma_neg), _p(g), _p(h), n, int(proj_in),
+                                           int(signed_exp), _p(op), _p(oa))
     assert rc == 0
     return op, oa
 
@@ -72,6 +95,79 @@ def fixed_base(base_proj, exps):
     op, oa = np.zeros((n, 96), np.uint8), np.zeros((n, 64), np.uint8)
     assert lib().oracle_fixed_base(_p(base_proj), _p(exps), n, _p(op), _p(oa)) == 0
     return op, oa
+
+
+# ---- vectors of points as byte arrays: what lets oracle/ac20_ref.py run Protocol 5 at N = 2^20 ---------------
+
+def scalars_to_array(vals):
+    """ints (any sign / size) -> (n,32) u8 canonical residues mod l"""
+    ell = 2**252 + 27742317777372353535851937790883648493
+    return np.frombuffer(b"".join(int(v % ell).to_bytes(32, "little") for v in vals), np.uint8).reshape(-1, 32)
+
+
+class PointArray:
+    """A vector of projective points as an (n,96) u8 array X|Y|Z (representatives kept), standing where
+    oracle/ac20_ref.py otherwise holds a list of (X, Y, Z) int tuples: len(), slicing (views), indexing and
+    iteration (tuples), appending one point.  ac20_ref.vector_commitment / fold_generators hand such vectors to
+    the C restatement instead of looping in Python - same algorithm, same representatives
+    (tests/test_oracle_c.py::test_ac20_ref_over_point_arrays)."""
+
+    def __init__(self, arr):
+        self.a = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1, 96)
+
+    @classmethod
+    def from_points(cls, pts):
+        return cls(np.frombuffer(b"".join(int(c).to_bytes(32, "little") for p in pts for c in p), np.uint8))
+
+    def __len__(self):
+        return len(self.a)
+
+    @staticmethod
+    def _tuple(row):
+        b = row.tobytes()
+        return tuple(int.from_bytes(b[o:o + 32], "little") for o in (0, 32, 64))
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return PointArray(self.a[i])
+        return self._tuple(self.a[i])
+
+    def __iter__(self):
+        b = self.a.tobytes()
+        fb = int.from_bytes
+        for o in range(0, len(b), 96):
+            yield (fb(b[o:o + 32], "little"), fb(b[o + 32:o + 64], "little"), fb(b[o + 64:o + 96], "little"))
+
+    def appended(self, pt):
+        row = np.frombuffer(b"".join(int(c).to_bytes(32, "little") for c in pt), np.uint8).reshape(1, 96)
+        return PointArray(np.concatenate([self.a, row]))
+
+    def affine(self):
+        """(n,64) canonical x|y of every element (through a fold by the exponent 0: (g ** 0) * g = identity * g,
+        normalised by the C side) - for comparisons as group elements"""
+        zero = np.zeros(32, np.uint8)
+        return fold(self.a, self.a, zero, proj_in=True)[1]
+
+    # -- the two group operations ac20_ref makes on whole vectors --------------------------------------------
+    def commit(self, x, gamma, h, signed_exponents):
+        """ac20_ref.vector_commitment over this vector (pivot.py:139-145): x, gamma Python ints as ac20_ref holds
+        them (residues; gamma possibly negative after pivot._int)"""
+        assert len(self) >= len(x), "Not enough generators."
+        hb = np.frombuffer(b"".join(int(c).to_bytes(32, "little") for c in h), np.uint8)
+        g_abs = np.frombuffer(int(abs(gamma)).to_bytes(32, "little"), np.uint8)
+        if signed_exponents:        # field elements: residues, read as signed by the C side like pivot._int
+            xs = scalars_to_array(x)
+        else:                       # plain Python ints are used as they are (pivot.py:119-128)
+            assert all(0 <= v < 1 << 256 for v in x)
+            xs = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in x), np.uint8).reshape(-1, 32)
+        op, _ = vector_commitment(xs, g_abs, self.a[:len(x)], hb, proj_in=True,
+                                  signed_exp=signed_exponents, gamma_neg=gamma < 0)
+        return self._tuple(op)
+
+    def fold(self, other, c):
+        """ac20_ref.fold_generators(self, other, c) (compressed_pivot.py:64)"""
+        cb = np.frombuffer(int(c).to_bytes(32, "little"), np.uint8)
+        return PointArray(fold(self.a, other.a, cb, proj_in=True)[0])
 
 
 # ---- "strong CPU" baseline: Pippenger on all cores (oracle/cpu_pippenger.c) ---------------------------------

@@ -13,8 +13,9 @@
  * oracle/ed25519_ref.py (exact X:Y:Z representatives) and RFC 8032 by
  * tests/test_oracle_c.py.
  *
- * Field: GF(2^255-19), 5 x 51-bit limbs, unsigned __int128 products.  Single thread,
- * as the reference is.
+ * Field: GF(2^255-19), 5 x 51-bit limbs, unsigned __int128 products.  Single thread by default,
+ * as the reference is (that is what `cpu_baseline` times); oracle_set_threads() spreads the independent
+ * pieces of the SAME algorithm over cores for the parity tests at N = 2^20 / 2^24 (see below).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  */
@@ -234,68 +235,147 @@ static void l_minus(uint8_t out[32], const uint8_t s[32]) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* out_proj (96 B) = h**gamma * reduce_tree([g_i ** x_i] + [identity]); points are projective
- * 96-byte inputs when proj_in != 0, else affine 64-byte.  signed_exp: treat residues > l/2 as
- * negative exponents (field-element inputs), as the reference does. */
-int oracle_vector_commitment(const uint8_t *x, const uint8_t *gamma, const uint8_t *g, const uint8_t *h,
-                             size_t n, int proj_in, int signed_exp, uint8_t *out_proj, uint8_t *out_affine) {
-    size_t len = n + 1;
-    pt *terms = (pt *)malloc(len * sizeof(pt));
-    if (!terms) return -12;
-    for (size_t i = 0; i < n; i++) {
+/* Threads (round 6).  The reference is single-threaded Python and `cpu_baseline` times this file with ONE
+ * thread (the default).  The parity tests at BASELINE's own sizes (N = 2^20 proofs, the 2^24-term
+ * commitment) spread the INDEPENDENT pieces of the same algorithm over the box's cores: the per-term ladders
+ * of pivot.py:143, the element-wise fold of compressed_pivot.py:64, and the pair-products of one level of
+ * the mpctools.reduce tree (pivot.py:26-28).  Operation order inside every piece, the tree's shape and hence
+ * every (X:Y:Z) representative are those of the single-threaded run (tests/test_oracle_c.py compares the two
+ * and oracle/ed25519_ref.py). */
+#include <pthread.h>
+static int g_threads = 1;
+void oracle_set_threads(int n) { g_threads = n < 1 ? 1 : (n > 1024 ? 1024 : n); }
+int oracle_get_threads(void) { return g_threads; }
+
+typedef void (*range_fn)(size_t lo, size_t hi, void *arg);
+typedef struct { range_fn fn; void *arg; size_t n, chunk, next; pthread_mutex_t mu; } pf_job;
+static void *pf_worker(void *p) {
+    pf_job *j = (pf_job *)p;
+    for (;;) {
+        pthread_mutex_lock(&j->mu);
+        size_t lo = j->next;
+        j->next = lo + j->chunk;
+        pthread_mutex_unlock(&j->mu);
+        if (lo >= j->n) return NULL;
+        j->fn(lo, lo + j->chunk < j->n ? lo + j->chunk : j->n, j->arg);
+    }
+}
+/* fn over [0, n) in chunks handed out first come first served; the calling thread works too */
+static void parallel_for(size_t n, size_t chunk, range_fn fn, void *arg) {
+    size_t chunks = (n + chunk - 1) / chunk;
+    size_t t = (size_t)g_threads < chunks ? (size_t)g_threads : chunks;
+    if (t <= 1) { if (n) fn(0, n, arg); return; }
+    pf_job job = { fn, arg, n, chunk, 0, PTHREAD_MUTEX_INITIALIZER };
+    pthread_t *th = (pthread_t *)malloc(t * sizeof(pthread_t));
+    size_t started = 0;
+    if (th)
+        for (size_t i = 0; i + 1 < t; i++)
+            if (pthread_create(&th[started], NULL, pf_worker, &job) == 0) started++;
+    pf_worker(&job);
+    for (size_t i = 0; i < started; i++) pthread_join(th[i], NULL);
+    free(th);
+}
+
+/* g_i ** x_i for i in [lo, hi): the ladders of pivot.py:143 */
+typedef struct { const uint8_t *x, *g; int proj_in, signed_exp; pt *terms; } vc_job;
+static void vc_ladders(size_t lo, size_t hi, void *arg) {
+    vc_job *j = (vc_job *)arg;
+    for (size_t i = lo; i < hi; i++) {
         pt b;
-        if (proj_in) pt_load_proj(&b, g + 96 * i); else pt_load_affine(&b, g + 64 * i);
-        const uint8_t *s = x + 32 * i;
+        if (j->proj_in) pt_load_proj(&b, j->g + 96 * i); else pt_load_affine(&b, j->g + 64 * i);
+        const uint8_t *s = j->x + 32 * i;
         uint8_t mag[32];
-        if (signed_exp && gt_half_l(s)) {
+        if (j->signed_exp && gt_half_l(s)) {
             l_minus(mag, s);
             fe zero; memset(&zero, 0, sizeof zero);
             fe_sub(&b.X, &zero, &b.X);
             s = mag;
         }
-        pt_repeat(&terms[i], &b, s);
+        pt_repeat(&j->terms[i], &b, s);
     }
+}
+/* one level of the tree, out of place: dst[odd + p] = src[odd + 2p] * src[odd + 2p + 1] */
+typedef struct { const pt *src; pt *dst; size_t odd; } lvl_job;
+static void vc_level(size_t lo, size_t hi, void *arg) {
+    lvl_job *j = (lvl_job *)arg;
+    for (size_t p = lo; p < hi; p++)
+        pt_add(&j->dst[j->odd + p], &j->src[j->odd + 2 * p], &j->src[j->odd + 2 * p + 1]);
+}
+
+/* out_proj (96 B) = h**gamma * reduce_tree([g_i ** x_i] + [identity]); points are projective
+ * 96-byte inputs when proj_in != 0, else affine 64-byte.  signed_exp: treat residues > l/2 as
+ * negative exponents (field-element inputs), as the reference does.  gamma_neg: `gamma` holds |gamma| of a
+ * negative exponent (`a ** -n` inverts the base first, oracle/ed25519_ref.py pt_repeat). */
+int oracle_vector_commitment_ex(const uint8_t *x, const uint8_t *gamma, int gamma_neg, const uint8_t *g,
+                                const uint8_t *h, size_t n, int proj_in, int signed_exp, uint8_t *out_proj,
+                                uint8_t *out_affine) {
+    size_t len = n + 1;
+    pt *terms = (pt *)malloc(len * sizeof(pt));
+    pt *spare = (pt *)malloc(len * sizeof(pt));
+    if (!terms || !spare) { free(terms); free(spare); return -12; }
+    vc_job vj = { x, g, proj_in, signed_exp, terms };
+    parallel_for(n, 64, vc_ladders, &vj);
     pt_identity(&terms[n]);
     while (len > 1) {           /* mpctools.reduce tree, initial appended at the end */
-        size_t odd = len & 1, o = odd;
-        for (size_t i = odd; i < len; i += 2) { pt t; pt_add(&t, &terms[i], &terms[i + 1]); terms[o++] = t; }
-        len = o;
+        size_t odd = len & 1, pairs = (len - odd) / 2;
+        if (odd) spare[0] = terms[0];   /* an odd level keeps its first element in front */
+        lvl_job lj = { terms, spare, odd };
+        parallel_for(pairs, 256, vc_level, &lj);
+        pt *sw = terms; terms = spare; spare = sw;
+        len = odd + pairs;
     }
     pt hb, hg, res;
     if (proj_in) pt_load_proj(&hb, h); else pt_load_affine(&hb, h);
+    if (gamma_neg) { fe zero; memset(&zero, 0, sizeof zero); fe_sub(&hb.X, &zero, &hb.X); }
     pt_repeat(&hg, &hb, gamma);
     pt_add(&res, &hg, &terms[0]);
-    free(terms);
+    free(terms); free(spare);
     if (out_proj) pt_store_proj(out_proj, &res);
     if (out_affine) pt_store_affine(out_affine, &res);
     return 0;
 }
+int oracle_vector_commitment(const uint8_t *x, const uint8_t *gamma, const uint8_t *g, const uint8_t *h,
+                             size_t n, int proj_in, int signed_exp, uint8_t *out_proj, uint8_t *out_affine) {
+    return oracle_vector_commitment_ex(x, gamma, 0, g, h, n, proj_in, signed_exp, out_proj, out_affine);
+}
 
-/* g'_i = (g_l[i] ** c) * g_r[i] */
+/* g'_i = (g_l[i] ** c) * g_r[i]   (compressed_pivot.py:64,178) */
+typedef struct { const uint8_t *gl, *gr, *c; int proj_in; uint8_t *out_proj, *out_affine; } fold_job;
+static void fold_range(size_t lo, size_t hi, void *arg) {
+    fold_job *j = (fold_job *)arg;
+    for (size_t i = lo; i < hi; i++) {
+        pt a, b, t, r;
+        if (j->proj_in) { pt_load_proj(&a, j->gl + 96 * i); pt_load_proj(&b, j->gr + 96 * i); }
+        else { pt_load_affine(&a, j->gl + 64 * i); pt_load_affine(&b, j->gr + 64 * i); }
+        pt_repeat(&t, &a, j->c);
+        pt_add(&r, &t, &b);
+        if (j->out_proj) pt_store_proj(j->out_proj + 96 * i, &r);
+        if (j->out_affine) pt_store_affine(j->out_affine + 64 * i, &r);
+    }
+}
 int oracle_fold(const uint8_t *gl, const uint8_t *gr, const uint8_t *c, size_t half, int proj_in,
                 uint8_t *out_proj, uint8_t *out_affine) {
-    for (size_t i = 0; i < half; i++) {
-        pt a, b, t, r;
-        if (proj_in) { pt_load_proj(&a, gl + 96 * i); pt_load_proj(&b, gr + 96 * i); }
-        else { pt_load_affine(&a, gl + 64 * i); pt_load_affine(&b, gr + 64 * i); }
-        pt_repeat(&t, &a, c);
-        pt_add(&r, &t, &b);
-        if (out_proj) pt_store_proj(out_proj + 96 * i, &r);
-        if (out_affine) pt_store_affine(out_affine + 64 * i, &r);
-    }
+    fold_job j = { gl, gr, c, proj_in, out_proj, out_affine };
+    parallel_for(half, 64, fold_range, &j);
     return 0;
 }
 
-/* out_i = base ** r_i */
+/* out_i = base ** r_i   (circuit_sat_r1cs.py:64-70) */
+typedef struct { pt b; const uint8_t *exps; uint8_t *out_proj, *out_affine; } fb_job;
+static void fb_range(size_t lo, size_t hi, void *arg) {
+    fb_job *j = (fb_job *)arg;
+    for (size_t i = lo; i < hi; i++) {
+        pt r;
+        pt_repeat(&r, &j->b, j->exps + 32 * i);
+        if (j->out_proj) pt_store_proj(j->out_proj + 96 * i, &r);
+        if (j->out_affine) pt_store_affine(j->out_affine + 64 * i, &r);
+    }
+}
 int oracle_fixed_base(const uint8_t *base_proj, const uint8_t *exps, size_t n, uint8_t *out_proj,
                       uint8_t *out_affine) {
-    pt b;
-    pt_load_proj(&b, base_proj);
-    for (size_t i = 0; i < n; i++) {
-        pt r;
-        pt_repeat(&r, &b, exps + 32 * i);
-        if (out_proj) pt_store_proj(out_proj + 96 * i, &r);
-        if (out_affine) pt_store_affine(out_affine + 64 * i, &r);
-    }
+    fb_job j;
+    pt_load_proj(&j.b, base_proj);
+    j.exps = exps; j.out_proj = out_proj; j.out_affine = out_affine;
+    parallel_for(n, 64, fb_range, &j);
     return 0;
 }

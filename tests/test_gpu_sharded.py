@@ -62,3 +62,26 @@ def test_sharded_prover_equals_unsharded(vm, N, world):
         c = crs.commit([(v, gk)])[0]
         ref = vm.pivot.vector_commitment(v, gk or 0, g + [h], k)
         assert tuple(c.normalize().coords) == tuple(ref.normalize().coords)
+
+
+def test_sharded_commitment_with_scalars_the_short_path_cannot_hold(vm):
+    """per-rank 16-row tables of <= 2^17 columns are what the fused short path (csrc/msm_short.hip) takes,
+    and a vector of small values overflows its bins - an answer (VMPC_E_AGAIN at a later sync, the partial all zeros)
+    that the exchange after the partial sums cannot act on.  The sharded commitments take the general path: the
+    result is right and no E_AGAIN is left behind on the context."""
+    from verifiable_mpc_amd import _native, sharded
+    N, world = 1 << 16, 2
+    rng = np.random.default_rng(16)
+    exps = rng.integers(0, 256, size=(N - 1, 32), dtype=np.uint8)
+    exps[:, 31] &= 0x0F
+    group = vm.EllipticCurve("Ed25519", "projective")
+    h, k = group.generator, vm.Ed25519Point.repeat(group.generator, 777)
+    crs = sharded.ShardedCrs.from_exponents(h, k, exps, world, range(world))
+    assert crs.shards[0].points._table.rows == 16
+    ones = vm.ScalarVector.from_ints([1] * N)                    # every non-zero digit in bin 0
+    tot = (sum(_native.array_to_ints(exps)) + 1) % ELL           # ... + 1 * h
+    for gk in (None, 5):
+        c = crs.commit([(ones, gk)])[0]
+        assert c == vm.Ed25519Point.repeat(group.generator, (tot + 777 * (gk or 0)) % ELL)
+    crs.ctx.sync()                                               # would raise VMPC_E_AGAIN had a short pass overflowed
+    assert crs.ctx.get_short_path() is True

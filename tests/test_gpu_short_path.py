@@ -211,11 +211,24 @@ def test_vector_commitment_repeats_an_overflowing_call_on_the_general_path():
     dot = sum(int.from_bytes(bytes(e), "little") ** 2 for e in exps) % ELL
     assert first.result() == vm.Ed25519Point.repeat(group.generator, (dot + 7) % ELL)
     assert second.result() == vm.Ed25519Point.repeat(group.generator, (tot + 9) % ELL)
-    # and the context is back on the short path afterwards
+    # the path is still switched on (a user's own setting is restored, not forced), but after an overflow the context
+    # sends its next eligible commitments straight to the general path (scalars like these tend to come again) ...
     ctx = g.ctx
-    ctx.profile(True)
-    ctx.profile_read(reset=True)
-    vm.pivot.vector_commitment(uni, 0, g, h)
-    stages = {k for k, (_, launches) in ctx.profile_read(reset=True).items() if launches}
-    ctx.profile(False)
-    assert "short_bins" in stages
+    assert ctx.get_short_path() is True
+
+    def stages_of_one_commitment():
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        assert vm.pivot.vector_commitment(uni, 7, g, h) == vm.Ed25519Point.repeat(group.generator, (dot + 7) % ELL)
+        st = {k for k, (_, launches) in ctx.profile_read(reset=True).items() if launches}
+        ctx.profile(False)
+        return st
+    assert "short_bins" not in stages_of_one_commitment()
+    # ... until the back-off is over or cleared
+    ctx.set_short_path(True, forget_overflow=True)
+    assert "short_bins" in stages_of_one_commitment()
+    # a caller's "off" survives on_general_path
+    ctx.set_short_path(False)
+    ctx.on_general_path(lambda: None)
+    assert ctx.get_short_path() is False
+    ctx.set_short_path(True, forget_overflow=True)

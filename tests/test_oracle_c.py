@@ -65,3 +65,63 @@ def test_rfc8032_through_c():
     _, oa = c_oracle.fixed_base(proj([ed.BASE])[0], sc([a % ELL]))
     pt = ed.affine_from_bytes(oa[0].tobytes())
     assert ed.encode_rfc8032(pt).hex() == "d75a980182b10ab7d54bfed3c964073a0ee172f3daa62325af021a68f707511a"
+
+
+def test_threads_change_nothing():
+    """the threaded run (ladders, fold elements, tree levels spread over cores) gives the single-threaded run's
+    exact (X:Y:Z) - every tree shape from 1 to a few thousand leaves, odd levels included"""
+    rng = random.Random(3)
+    base = proj([ed.BASE])[0]
+    n = 3000
+    exps = sc([rng.randrange(1, ELL) for _ in range(n)])
+    x = sc([rng.randrange(ELL) for _ in range(n)])
+    gamma = sc([rng.randrange(ELL)])[0]
+    prev = c_oracle.set_threads(1)
+    try:
+        g1, a1 = c_oracle.fixed_base(base, exps)
+        f1 = c_oracle.fold(g1[:n // 2], g1[n // 2:], gamma, proj_in=True)[0]
+        want = {m: c_oracle.vector_commitment(x[:m], gamma, g1[:m], base, proj_in=True, signed_exp=True)[0].tobytes()
+                for m in (1, 2, 3, 1023, 1024, 1025, 2047, 2999, 3000)}
+        c_oracle.set_threads(5)
+        g5, a5 = c_oracle.fixed_base(base, exps)
+        assert (g1 == g5).all() and (a1 == a5).all()
+        assert (c_oracle.fold(g1[:n // 2], g1[n // 2:], gamma, proj_in=True)[0] == f1).all()
+        for m, w in want.items():
+            assert c_oracle.vector_commitment(x[:m], gamma, g1[:m], base, proj_in=True,
+                                              signed_exp=True)[0].tobytes() == w, m
+    finally:
+        c_oracle.set_threads(prev)
+
+
+def test_ac20_ref_over_point_arrays():
+    """oracle/ac20_ref.py run with the generator vector held as a c_oracle.PointArray (group work in C, what makes
+    N = 2^20 reachable) returns what it returns over lists of int tuples: both transcripts, every challenge,
+    prover and verifier"""
+    rng = random.Random(4)
+    n = 31
+    exps = [rng.randrange(1, ELL) for _ in range(n)]
+    ek = rng.randrange(1, ELL)
+    gens = ac.create_generators(exps, ek)
+    agens = dict(gens, g=c_oracle.PointArray.from_points(gens["g"]))
+    assert list(agens["g"]) == gens["g"] and agens["g"][5] == gens["g"][5] and len(agens["g"][3:9]) == 6
+    x = [rng.randrange(ELL) for _ in range(n)]
+    coeffs = [rng.randrange(ELL) for _ in range(n)]
+    gamma, rho = rng.randrange(1, ELL), rng.randrange(ELL)
+    r = [rng.randrange(ELL) for _ in range(n)]
+    P = ac.vector_commitment(x, gamma, gens["g"], gens["h"])
+    assert ac.vector_commitment(x, gamma, agens["g"], gens["h"]) == P
+    assert ac.vector_commitment(x, -5, agens["g"], gens["h"]) == ac.vector_commitment(x, -5, gens["g"], gens["h"])
+    y = ac.form_eval(coeffs, 0, x)
+    prev = c_oracle.set_threads(3)
+    try:
+        for mode in ("reference", "compact"):
+            t1, t2 = {}, {}
+            want = ac.protocol_5_prover(gens, P, coeffs, 0, y, x, gamma, r, rho, mode, trace=t1)
+            got = ac.protocol_5_prover(agens, P, coeffs, 0, y, x, gamma, r, rho, mode, trace=t2)
+            assert got == want
+            assert t1["c"] == t2["c"] and (t1["c0"], t1["c1"]) == (t2["c0"], t2["c1"])
+            assert [list(v) for v in t2["g_hat"]] == t1["g_hat"]
+            assert ac.protocol_5_verifier(agens, P, coeffs, 0, y, got, mode) is True
+            assert ac.protocol_5_verifier(agens, P, coeffs, 0, (y + 1) % ELL, got, mode) is False
+    finally:
+        c_oracle.set_threads(prev)

@@ -26,7 +26,7 @@ SCALAR_BYTES, AFFINE_BYTES, PROJ_BYTES, EXT_BYTES = 32, 64, 96, 128
 # against the header and against the built library)
 SYMBOLS = [
     "vmpc_backend_info", "vmpc_last_error", "vmpc_ctx_create", "vmpc_ctx_destroy",
-    "vmpc_ctx_set_stream", "vmpc_ctx_sync", "vmpc_ctx_set_short_path", "vmpc_ctx_debug_hold_wait", "vmpc_ctx_query", "vmpc_ctx_wait_for", "vmpc_malloc", "vmpc_free", "vmpc_memcpy_h2d",
+    "vmpc_ctx_set_stream", "vmpc_ctx_sync", "vmpc_ctx_set_short_path", "vmpc_ctx_get_short_path", "vmpc_ctx_debug_hold_wait", "vmpc_ctx_query", "vmpc_ctx_wait_for", "vmpc_malloc", "vmpc_free", "vmpc_memcpy_h2d",
     "vmpc_memcpy_d2h", "vmpc_memcpy_d2d", "vmpc_ctx_profile", "vmpc_ctx_profile_read",
     "vmpc_ctx_set_window", "vmpc_ed25519_msm_plan", "vmpc_ed25519_madd_rate", "vmpc_ed25519_msm", "vmpc_ed25519_fold",
     "vmpc_ed25519_fixed_base_batch", "vmpc_fr_axpy", "vmpc_fr_dot", "vmpc_points_validate_dev",
@@ -77,6 +77,7 @@ def load_library():
         "vmpc_ctx_set_stream": (i32, [vp, vp]),
         "vmpc_ctx_sync": (i32, [vp]),
         "vmpc_ctx_set_short_path": (i32, [vp, i32]),
+        "vmpc_ctx_get_short_path": (i32, [vp, ctypes.POINTER(ctypes.c_int)]),
         "vmpc_ctx_debug_hold_wait": (i32, [vp, i32]),
         "vmpc_ctx_query": (i32, [vp, ctypes.POINTER(i32)]),
         "vmpc_ctx_wait_for": (i32, [vp, vp]),
@@ -497,18 +498,30 @@ class Context:
     def sync(self):
         _check(self.lib.vmpc_ctx_sync(self.handle), "vmpc_ctx_sync")
 
-    def set_short_path(self, on):
-        """commitments over short 16-row tables: the fused three-launch path (csrc/msm_short.hip) on / off"""
-        _check(self.lib.vmpc_ctx_set_short_path(self.handle, 1 if on else 0), "vmpc_ctx_set_short_path")
+    def set_short_path(self, on, forget_overflow=False):
+        """commitments over short 16-row tables: the fused three-launch path (csrc/msm_short.hip) on / off;
+        forget_overflow: also end the back-off (64 eligible calls on the general path) that follows an overflow"""
+        _check(self.lib.vmpc_ctx_set_short_path(self.handle, (2 if forget_overflow else 1) if on else 0),
+               "vmpc_ctx_set_short_path")
+
+    def get_short_path(self):
+        on = ctypes.c_int(0)
+        _check(self.lib.vmpc_ctx_get_short_path(self.handle, ctypes.byref(on)), "vmpc_ctx_get_short_path")
+        return bool(on.value)
 
     def on_general_path(self, fn):
-        """fn() once more with the short path off: what a caller does after sync() raised VMPC_E_AGAIN (a commitment's
-        scalars were skewed beyond the short path's fixed capacities; its result is void)"""
-        self.set_short_path(False)
+        """fn() with the short path off, the PREVIOUS setting restored afterwards (a user who switched the path off
+        keeps it off): what a caller does after sync() raised VMPC_E_AGAIN (a commitment's scalars were skewed beyond
+        the short path's fixed capacities; its result is void), and what callers do whose consumer cannot act on
+        that answer (a collective that has already summed the partial)"""
+        prev = self.get_short_path()
+        if prev:
+            self.set_short_path(False)
         try:
             return fn()
         finally:
-            self.set_short_path(True)
+            if prev:
+                self.set_short_path(True)
 
     def done(self):
         """True when all work enqueued on this context's stream has completed (does not block)"""

@@ -47,7 +47,10 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
     vmpc_ctx *c = new vmpc_ctx();
     c->device = device;
     hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, device) == hipSuccess) c->cu_count = p.multiProcessorCount;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess) {
+        c->cu_count = p.multiProcessorCount;
+        c->lds_optin = p.sharedMemPerBlockOptin ? p.sharedMemPerBlockOptin : p.sharedMemPerBlock;
+    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -156,6 +159,9 @@ extern "C" int vmpc_ctx_sync(vmpc_ctx *ctx) {
                  "(vmpc_ctx_set_short_path(ctx, 0))");
         VMPC_HIP_CHECK(hipMemsetAsync(ctx->d_status, 0, VMPC_ST_WORDS * sizeof(uint32_t), ctx->stream));
         VMPC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        // scalars like these tend to come again (a witness with many small wires puts every non-zero digit into one
+        // bin): the next eligible commitments of this context go straight to the general path
+        ctx->short_backoff = 64;
         return VMPC_E_AGAIN;
     }
     return VMPC_OK;
@@ -174,6 +180,13 @@ extern "C" int vmpc_ctx_debug_hold_wait(vmpc_ctx *ctx, int on) {
 extern "C" int vmpc_ctx_set_short_path(vmpc_ctx *ctx, int on) {
     if (!ctx) return VMPC_E_INVAL;
     ctx->short_path = on ? 1 : 0;
+    if (on == 2) ctx->short_backoff = 0;       // 2: on, and forget a recent overflow
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_ctx_get_short_path(vmpc_ctx *ctx, int *on) {
+    if (!ctx || !on) return VMPC_E_INVAL;
+    *on = ctx->short_path;
     return VMPC_OK;
 }
 

@@ -57,6 +57,8 @@ struct vmpc_ctx {
     int reduce_max_chunks = 32768; // most chunk-lanes per bucket set in the bucket reduction (msm_sort.hip)
     int reduce_chunks_override = 0; // > 0: chunk-lanes per bucket set, fixed (power of two)
     int short_path = 1;            // commitments over a 16-row table of <= 2^17 columns: the fused path (msm_short.hip)
+    int short_backoff = 0;         // eligible calls still to take the general path after an overflow (vmpc_ctx_sync sets it)
+    size_t lds_optin = 0;          // the device's largest dynamic LDS per workgroup (sharedMemPerBlockOptin)
     bool short_ready = false;      // its kernels' dynamic-LDS limits are set on this context's device
     uint32_t *short_cursors = nullptr;   // [2][128] bin fill counts, zero between calls (the path's last kernel re-arms them)
     int reduce_tree = 1;           // short chunks: weights from the quad tree (msm_reduce_tree.hip), not per-lane ladders

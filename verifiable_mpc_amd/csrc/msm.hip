@@ -642,8 +642,10 @@ static int msm_table_batch(vmpc_ctx *ctx, const void *table, size_t table_n, siz
     for (int k = 0; k < K; k++)
         if (m && !scalars[k]) return VMPC_E_INVAL;
     // one bucket set per commitment over a short table: three launches instead of seventeen (msm_short.hip)
-    if (msm_short_fits(ctx, table_n, table_extra, m, rows, msm_table_window(ctx), K, out_ext, out_affine))
-        return msm_short_batch(ctx, table, table_n, table_extra, scalars, m, extra_scalars, K, out_ext, ED25519_L);
+    if (msm_short_fits(ctx, table_n, table_extra, m, rows, msm_table_window(ctx), K, out_ext, out_affine)) {
+        if (ctx->short_backoff > 0) ctx->short_backoff--;      // an overflow a few calls ago: general path for now
+        else return msm_short_batch(ctx, table, table_n, table_extra, scalars, m, extra_scalars, K, out_ext, ED25519_L);
+    }
     const size_t stride = msm_table_stride(table_n + table_extra);
     // each of the 16 / rows bucket sets of a commitment is one row of rows * stride entries
     msm_plan p;

@@ -19,7 +19,8 @@
 //
 // One commitment is shared out among 2 x 128 workgroups (parts = entries of even / odd list position), a pair among
 // 2 x 128: the chip's 256 CUs each get one.  Capacities are fixed (SH_T entries per workgroup, SH_MAX_HEAVY whole-
-// workgroup buckets); an input beyond them - only possible for adversarially skewed scalars - raises
+// workgroup buckets); an input beyond them - NOT only an adversarial one: a witness whose non-zero digits are mostly
+// small values (many 0/1/2 wires) fills bin 0 alone, > ~24 K such wires in a vector of 2^14.6 .. 2^17 - raises
 // VMPC_ST_SHORT_OVERFLOW, vmpc_ctx_sync answers VMPC_E_AGAIN and the caller repeats the call on the general path
 // (verifiable_mpc_amd/pivot.py, compressed_pivot.py); the void result itself goes out as all zeros (Z = 0 is no point),
 // so that with several commitments pending on one context each can tell whether it was the one.  The group element is the same as the general path's; its
@@ -283,7 +284,8 @@ bool msm_short_fits(const vmpc_ctx *ctx, size_t table_n, size_t table_extra, siz
     // uniform scalars put 16 (m + extras) / 128 entries into a bin; a workgroup (half a bin for one commitment, a
     // whole one for a pair) must expect at most two thirds of its SH_T: one commitment up to 2^17 terms, a pair 2^16
     const size_t per_wg = 16 * (m + table_extra) / SH_BINS / (K == 1 ? 2 : 1);
-    return ctx->short_path && !ctx->bucket_stream && rows == 16 && c == 16 && K >= 1 && K <= 2 && out_ext && !out_affine &&
+    const size_t lds_bytes = ((size_t)SH_T + SH_STAGE_WORDS + 3 * SH_FINE + 16) * 4;     // k_short_bins' dynamic LDS
+    return ctx->short_path && ctx->lds_optin >= lds_bytes && !ctx->bucket_stream && rows == 16 && c == 16 && K >= 1 && K <= 2 && out_ext && !out_affine &&
            (size_t)16 * stride <= ((size_t)1 << SH_POS_BITS) && per_wg <= (size_t)SH_T * 2 / 3 + 16;
 }
 
@@ -322,16 +324,25 @@ int msm_short_batch(vmpc_ctx *ctx, const void *table, size_t table_n, size_t tab
             a, m, table_n, table_extra, stride, modulus, cap, ctx->short_cursors, bins, ctx->d_status, poison);
         VMPC_KERNEL_CHECK();
     }
+    // from here on the bin cursors hold this call's counts and only the LAST kernel re-arms them: a launch that fails
+    // in between must not leave them to the next call
+    int rc = VMPC_OK;
     {
         vmpc_stage_scope s(ctx, "short_bins");
         k_short_bins<<<dim3(SH_BINS, K * spl), SH_THREADS, lds_bytes, st>>>((const uint32_t *)table, bins, ctx->short_cursors,
                                                                           cap, spl, triples, ctx->d_status, poison);
-        VMPC_KERNEL_CHECK();
+        if (hipGetLastError() != hipSuccess) rc = VMPC_E_HIP;
     }
-    {
+    if (rc == VMPC_OK) {
         vmpc_stage_scope s(ctx, "short_combine");
-        VMPC_CHECK(msm_reduce_combine_launch(ctx, triples, K, SH_BINS, spl, scratch, out_ext, ctx->short_cursors, SH_BINS,
-                                             poison));
+        rc = msm_reduce_combine_launch(ctx, triples, K, SH_BINS, spl, scratch, out_ext, ctx->short_cursors, SH_BINS,
+                                       poison);
+    }
+    if (rc != VMPC_OK) {
+        VMPC_IGNORE(hipMemsetAsync(ctx->short_cursors, 0, 2 * SH_BINS * sizeof(uint32_t), st));
+        ctx->short_path = 0;       // this context's device cannot run the path: general path from now on
+        snprintf(vmpc_err_buf, sizeof vmpc_err_buf, "short-commitment path: launch failed; path switched off for this context");
+        return rc;
     }
     ctx->short_ready = true;      // (the combine launcher sets its kernel's LDS limit while this is still false)
     return VMPC_OK;

@@ -135,11 +135,7 @@ class HipBackend:
         # next synchronisation - an answer a pipeline of launches in flight, let alone one followed by a collective
         # that has already summed the void partial on every rank, cannot act on: this backend's commitments always
         # take the general path.
-        ctx.set_short_path(False)
-        try:
-            self._launch_partial_general(ctx, scalars, points, slot)
-        finally:
-            ctx.set_short_path(True)
+        ctx.on_general_path(lambda: self._launch_partial_general(ctx, scalars, points, slot))
 
     def _launch_partial_general(self, ctx, scalars, points, slot):
         table = getattr(points, "_table", None)

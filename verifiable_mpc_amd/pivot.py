@@ -388,9 +388,12 @@ class _PendingCommitment:
             raw = self.ctx.download(self.out.ptr, 96).tobytes()
             again = _void_point(raw)        # this commitment overflowed, another caller collected the status word
         except _native.VmpcError as e:
-            if e.code != _native.E_AGAIN or self.relaunch is None:
+            if e.code != _native.E_AGAIN:
                 raise
-            again = True
+            # the status word is one per context: the overflow may be another pending commitment's.  The sync has
+            # completed; this one's own marker decides
+            raw = self.ctx.download(self.out.ptr, 96).tobytes()
+            again = _void_point(raw)
         if again:
             if self.relaunch is None:
                 raise _native.VmpcError(_native.E_AGAIN, "vector_commitment")
@@ -458,7 +461,17 @@ def _auto_tabulate(gv, h):
     if _auto_table_bytes[0] + nbytes > AUTO_TABLE_TOTAL:
         return
     import weakref
-    gv.precompute([h], rows=rows)
+    try:
+        gv.precompute([h], rows=rows)
+    except _native.VmpcError as e:
+        # precompute synchronises the context: a short-path overflow of an EARLIER, not yet collected commitment
+        # surfaces here (one status word per context).  That commitment finds its own void marker in result(); the
+        # table build itself never takes the short path and has completed with the sync
+        if e.code != _native.E_AGAIN:
+            raise
+        gv.ctx.sync()
+        if gv._table is None:
+            gv.precompute([h], rows=rows)
     _auto_table_bytes[0] += nbytes
     weakref.finalize(gv._table, _auto_table_released, nbytes)
 

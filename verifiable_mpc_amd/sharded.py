@@ -111,7 +111,10 @@ class DeviceOps:
         elif gamma is not None:
             ctx.upload_into(esc.ptr, np.frombuffer(reduce_scalar(gamma).to_bytes(32, "little"), np.uint8))
         t = block._table
-        ctx.msm_table(t.ptr, len(block), 1, v_block.ptr, len(block), esc.ptr, out_ptr, None, rows=t.rows)
+        # general path only: the fused short path's "repeat this call" (VMPC_E_AGAIN at a later synchronisation) is
+        # an answer the exchange that follows - it has summed the void partial on every rank by then - cannot act on
+        ctx.on_general_path(lambda: ctx.msm_table(t.ptr, len(block), 1, v_block.ptr, len(block), esc.ptr, out_ptr, None,
+                                                  rows=t.rows))
         return ctx, (esc, v_block)          # stream to wait for, buffers to keep alive until then
 
     # -- exchange buffers and the ordered combine ----------------------------------------------------------------
@@ -250,7 +253,8 @@ class ShardedCrs:
                 ctx.copy(esc.ptr, gamma.ptr, 32)
             elif s.index == 0 and gamma is not None:
                 ctx.upload_into(esc.ptr, np.frombuffer(reduce_scalar(gamma).to_bytes(32, "little"), np.uint8))
-            ctx.msm_table(t.ptr, s.n, 1, per_shard[s.index].ptr, s.n, esc.ptr, mine.ptr + 128 * j, None, rows=t.rows)
+            ctx.on_general_path(lambda: ctx.msm_table(t.ptr, s.n, 1, per_shard[s.index].ptr, s.n, esc.ptr,      # (as in
+                                                      mine.ptr + 128 * j, None, rows=t.rows))                  # partial)
             keep.append(esc)
         self.comm.points_allsum(ctx, mine.ptr, K, scratch.ptr, res.ptr)
         raw = ctx.download(res.ptr, 128 * K).tobytes()
