@@ -102,7 +102,7 @@ def cpu_baseline(log2_sample, seed):
     c_oracle.vector_commitment(sc, np.zeros(32, np.uint8), pts, pts[0])
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "scalar-mults/s", "cores": 1, "kind": "port",
-            "host_cores_available": os.cpu_count(),
+            "host_cores_available": os.cpu_count(), "host_cores_granted": c_oracle.host_threads(),
             "sample": f"oracle/ed25519_oracle.c vector_commitment (reference algorithm: per-term "
                       f"253-bit double-and-add + product tree), n=2^{log2_sample} uniform scalars, "
                       f"{dt:.1f} s on 1 core"}

@@ -61,11 +61,25 @@ def set_threads(n):
 
 
 def host_threads():
-    """the cores this process may run on"""
+    """the cores this process may USE: the affinity mask capped by the cgroup's CPU quota (the GPU box shows 256
+    cores and grants 16: more threads than that only get throttled - scripts/oracle_threads_probe.py)"""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        return max(1, os.cpu_count() or 1)
+        n = max(1, os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def vector_commitment(x, gamma, g, h, proj_in=False, signed_exp=False, gamma_neg=False):
