@@ -241,6 +241,7 @@ class _Transcript:
 
 
 # ---- Protocol 4 --------------------------------------------------------------------------------------
+WIDE_TABLE_ROWS = 13      # device.PointVector.precompute(rows=13): csrc/msm.hip msm_table_batch_wide
 
 def _tabulated(g_hat, k, whole=False):
     """g_hat and k live in one fixed-base table: commitments over the UNFOLDED g_hat are then cheaper
@@ -248,7 +249,9 @@ def _tabulated(g_hat, k, whole=False):
     whole: g_hat must be ALL of the table's generators (+ its leading extras), not a strict prefix - the
     round context (vmpc_p4_create) derives N from the table, a prefix has to take the round-by-round path."""
     t = getattr(g_hat, "_table", None)
-    if t is None:
+    if t is None or t.rows == WIDE_TABLE_ROWS:
+        # (a wide-window table serves commitments only: the fold jump and the bucket-free short rounds read rows spaced
+        # 256 / rows bits)
         return False
     if whole and len(g_hat) - g_hat._table_tail != t.n:
         return False

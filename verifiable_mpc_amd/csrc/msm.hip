@@ -544,8 +544,16 @@ static int msm_table_window(const vmpc_ctx *ctx) {
     const int o = ctx->window_override;      // vmpc_ctx_set_window / VMPC_MSM_WINDOW: honoured when it divides 16
     return (o == 4 || o == 8 || o == 16) ? o : 16;
 }
-static size_t msm_table_stride(size_t n_points) { return (n_points + 7) & ~(size_t)7; }
-static bool msm_table_rows_ok(int rows) { return rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16; }
+// rows = MSM_WIDE_ROWS (13) is the WIDE-WINDOW table (round 6): rows spaced 20 bits, T[r][i] = 2^(20 r) * P_i, one set
+// of 2^19 buckets per commitment, 13 mixed additions per term instead of 16 and no recombination; its row stride is a
+// whole number of 8192-position sort chunks (msm_sort.h).  The other row counts are spaced 256 / rows bits.
+static size_t msm_table_stride(size_t n_points, int rows = 16) {
+    return rows == MSM_WIDE_ROWS ? (n_points + 8191) & ~(size_t)8191 : (n_points + 7) & ~(size_t)7;
+}
+static bool msm_table_rows_ok(int rows) {
+    return rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16 || rows == MSM_WIDE_ROWS;
+}
+static int msm_table_row_bits(int rows) { return rows == MSM_WIDE_ROWS ? MSM_WIDE_C : 256 / rows; }
 
 __global__ void __launch_bounds__(MSM_BLOCK, 2)
 k_msm_table_build(const uint32_t *__restrict__ aff, size_t n_main, const uint32_t *__restrict__ aff_extra,
@@ -566,7 +574,7 @@ k_msm_table_build(const uint32_t *__restrict__ aff, size_t n_main, const uint32_
     a.y = fe_ld8(src + 8);
     niels_st_line(table + NIELS_WORDS * i, ge_niels_from_affine(a));
     ge_ext q = ge_ext_from_affine(a);
-    const int dbl_per_row = 256 / rows;
+    const int dbl_per_row = rows == MSM_WIDE_ROWS ? MSM_WIDE_C : 256 / rows;
     // Rows 1 .. rows-1 need the AFFINE form of 2^(k rho) P: one inversion for all of them (Montgomery's
     // trick).  Pass 1 parks (X, Y, Z, Z_1 ... Z_rho) of row rho in the row's own 128-byte slot; pass 2 walks
     // back with the running inverse and overwrites the slot with the niels entry.
@@ -598,7 +606,7 @@ k_msm_table_build(const uint32_t *__restrict__ aff, size_t n_main, const uint32_
 
 extern "C" int vmpc_msm_table_bytes(size_t n, size_t n_extra, int rows, size_t *bytes) {
     if (!bytes || n + n_extra == 0 || n + n_extra > ((size_t)1 << 26) || !msm_table_rows_ok(rows)) return VMPC_E_INVAL;
-    *bytes = (size_t)rows * msm_table_stride(n + n_extra) * NIELS_WORDS * 4;
+    *bytes = (size_t)rows * msm_table_stride(n + n_extra, rows) * NIELS_WORDS * 4;
     return VMPC_OK;
 }
 
@@ -608,7 +616,7 @@ extern "C" int vmpc_msm_table_build_dev(vmpc_ctx *ctx, const void *affine_points
         n + n_extra > ((size_t)1 << 26) || !msm_table_rows_ok(rows))
         return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t stride = msm_table_stride(n + n_extra);
+    const size_t stride = msm_table_stride(n + n_extra, rows);
     vmpc_stage_scope s(ctx, "msm_table_build");
     k_msm_table_build<<<(unsigned)((stride + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
         (const uint32_t *)affine_points, n, (const uint32_t *)extra_affine_points, n + n_extra, stride, rows, 0,
@@ -620,11 +628,44 @@ extern "C" int vmpc_msm_table_build_dev(vmpc_ctx *ctx, const void *affine_points
 // the extras' columns (and the padding) of a table whose generator columns another kernel fills (fold_jump.hip)
 int vmpc_msm_table_build_extras(vmpc_ctx *ctx, size_t n, const void *extra_affine_points, size_t n_extra, int rows,
                                 void *table) {
-    const size_t stride = msm_table_stride(n + n_extra);
+    const size_t stride = msm_table_stride(n + n_extra, rows);
     k_msm_table_build<<<(unsigned)((stride - n + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, ctx->stream>>>(
         nullptr, n, (const uint32_t *)extra_affine_points, n + n_extra, stride, rows, n, (uint32_t *)table);
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
+}
+
+// The wide-window table: K commitments = K digit rows of 13 * stride positions, each its own set of 2^19 buckets
+// (plan: c = 20, period = 1).  Sorted by the same two-level LDS sort (1024 coarse bins x 512 buckets), accumulated,
+// finished and reduced by the same kernels; no recombination (k_msm_final only adds the reduction's partial sums).
+static int msm_table_batch_wide(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra,
+                                const void *const *scalars, size_t m, const void *const *extra_scalars, int K,
+                                void *out_ext, void *out_affine) {
+    const size_t stride = msm_table_stride(table_n + table_extra, MSM_WIDE_ROWS);
+    if (stride > ((size_t)1 << 22)) return VMPC_E_INVAL;          // column + 9 fine bits + sign in a 32-bit entry
+    msm_plan p;
+    p.n_main = p.n_total = (size_t)MSM_WIDE_ROWS * stride;
+    p.n_extra = 0;
+    p.scalar_bits = 253;
+    p.c = MSM_WIDE_C;
+    p.period = 1;
+    p.W = K;
+    p.top_row = -1;
+    p.top_max_b = 0;
+    p.wide = 1;
+    p.row_stride = stride;
+    p.chunks_per_row = (int)(stride / 8192);
+    p.col_bits = 1;
+    while (((size_t)1 << p.col_bits) < stride) p.col_bits++;
+    msm_plan_geometry(ctx, p);
+    msm_ws w;
+    msm_layout(p, w, nullptr, 0, EXT_WORDS * 4);
+    VMPC_CHECK(vmpc_ws_reserve(ctx, w.total));
+    msm_layout(p, w, (char *)ctx->ws, 0, EXT_WORDS * 4);
+    VMPC_CHECK(msm_recode_wide_batch(ctx, scalars, m, extra_scalars, K, table_n, table_extra, stride, (int32_t *)w.digits,
+                                     p.n_pad, ED25519_L));
+    VMPC_CHECK(msm_sort_digits(ctx, p, w));
+    return msm_accumulate(ctx, p, w, (const uint32_t *)table, out_ext, out_affine);
 }
 
 // K commitments over the same tabulated generators in ONE pass: the K scalar vectors are recoded into K * (16 / rows)
@@ -646,6 +687,8 @@ static int msm_table_batch(vmpc_ctx *ctx, const void *table, size_t table_n, siz
         if (ctx->short_backoff > 0) ctx->short_backoff--;      // an overflow a few calls ago: general path for now
         else return msm_short_batch(ctx, table, table_n, table_extra, scalars, m, extra_scalars, K, out_ext, ED25519_L);
     }
+    if (rows == MSM_WIDE_ROWS)
+        return msm_table_batch_wide(ctx, table, table_n, table_extra, scalars, m, extra_scalars, K, out_ext, out_affine);
     const size_t stride = msm_table_stride(table_n + table_extra);
     // each of the 16 / rows bucket sets of a commitment is one row of rows * stride entries
     msm_plan p;

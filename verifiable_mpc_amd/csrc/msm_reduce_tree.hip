@@ -151,7 +151,9 @@ k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_
 bool msm_reduce_tree_fits(const msm_plan &p) {
     if (p.chunks % RT_LEAVES != 0 || p.chunks * p.chunk_len != p.nb) return false;
     const int G = p.chunks / RT_LEAVES;
-    return G >= 1 && G <= 128 && (G & (G - 1)) == 0 && p.chunk_len <= 8 && (p.chunk_len & (p.chunk_len - 1)) == 0;
+    // (chunks of 16 buckets: the one set of 2^19 buckets of a wide-window commitment, 128 workgroups of 256 chunk-lanes)
+    return G >= 1 && G <= 128 && (G & (G - 1)) == 0 && p.chunk_len <= (p.wide ? 16 : 8) &&
+           (p.chunk_len & (p.chunk_len - 1)) == 0;
 }
 
 // buckets -> W window sums at w.partials (one per window: k_msm_final's red_blocks = 1); the triples sit behind them.

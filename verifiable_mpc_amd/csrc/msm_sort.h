@@ -7,6 +7,8 @@
 #include "common.h"
 
 #define MSM_MAX_C 16
+#define MSM_WIDE_C 20       // the wide window of a 13-row fixed-base table (msm.hip): int32 digit rows, one set of 2^19 buckets
+#define MSM_WIDE_ROWS 13
 #define MSM_BLOCK 256
 #define MSM_SORT_BLOCK 1024
 #define MSM_SEG 64          // length bins of the task table; a segment holds MSM_SEG << seg_shift entries
@@ -35,6 +37,15 @@ struct msm_plan {
     int chunks;         // chunk-threads per window in the reduce kernel
     int chunk_len;      // buckets per chunk (power of two)
     int red_blocks;     // blocks per window in the reduce kernel
+    // wide window (c = MSM_WIDE_C over a MSM_WIDE_ROWS-row table): digits are int32; a digit row is the flattened
+    // [table row][column] and every sort chunk lies inside ONE table row (row_stride = chunks_per_row * 8192), so the
+    // entries between the sort passes carry the COLUMN (col_bits) beside the fine bucket and the table row is read
+    // off the entry's place in its coarse bin (runs are laid out chunk by chunk, i.e. row by row)
+    int wide = 0;
+    int chunks_per_row = 0; // 0: entries carry the flattened index (every other plan)
+    int col_bits = 0;
+    size_t row_stride = 0;
+    int fine_cap = 12288;   // entries of a coarse bin that k_sort_fine stages in LDS (16384 for the wide window)
 };
 inline size_t msm_seg_len(const msm_plan &p) { return (size_t)1 << (MSM_SEG_LOG2 + p.seg_shift); }
 
@@ -50,7 +61,7 @@ struct msm_ws {
     uint32_t *nseg, *seg_starts, *block_hist, *block_base, *heavy_list, *ctrl;
     uint32_t *seg_partial;  // per-segment partial sums, acc_bytes each
     uint2 *tasks;
-    int16_t *digits;
+    int16_t *digits;        // int32 rows when the plan is `wide`
     void *scan_ws;
     size_t total;
     uint32_t plan_blocks;
@@ -74,6 +85,11 @@ int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st,
 int msm_sort_stage(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const void *scalars, size_t n,
                    const void *extra_scalars, const msm_modulus &modulus);
 int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w);   // the same minus the recoding
+// wide window: the MSM_WIDE_ROWS signed 20-bit digits of the K commitments' scalars (main || extra) as int32 rows,
+// digit r of column i of commitment k at digits32[k * digits_per_commitment + r * row_stride + i]
+int msm_recode_wide_batch(vmpc_ctx *ctx, const void *const *scalars, size_t n_main, const void *const *extra_scalars,
+                          int K, size_t extra_pos, size_t n_extra, size_t row_stride, int32_t *digits32,
+                          size_t digits_per_commitment, const msm_modulus &modulus);
 // signed c-bit digits of (main || extra) scalars for a fixed-base table of `rows` rows (msm.hip): digit
 // w of term i goes to digits[(w % (W/rows)) * rows * n_pad + (w / (W/rows)) * n_pad + i]; positions
 // outside [0, n_main) and [extra_pos, extra_pos + n_extra) are zeroed

@@ -122,38 +122,141 @@ k_msm_recode_batch(msm_recode_batch b, size_t n_main, size_t extra_pos, size_t n
                     digits + (size_t)blockIdx.y * digits_per_commitment, c, W, wpr, set_stride, mod, status);
 }
 
+// ---- wide window: 13 signed 20-bit digits per scalar, int32 rows --------------------------------
+// Signed recoding without a carry chain: with h = 2^19 and H = h * sum_r 2^(20 r), digit r of s is
+// ((s + H) >> 20 r & (2^20 - 1)) - h, in [-h, h) - the very digits the carry loop of msm_recode_term produces
+// (raw + carry >= h  <=>  the addition of h at position r carries out).  s < l < 2^253 and H < 2^260: thirteen digits,
+// the top one in [0, 2^13].
+__global__ void __launch_bounds__(MSM_BLOCK)
+k_msm_recode_wide(msm_recode_batch b, size_t n_main, size_t extra_pos, size_t n_extra, size_t row_stride,
+                  int32_t *__restrict__ digits, size_t digits_per_commitment, msm_modulus mod,
+                  uint32_t *__restrict__ status) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row_stride) return;
+    const uint32_t *sc = b.sc[blockIdx.y], *sc_extra = b.sc_extra[blockIdx.y];
+    int32_t *out = digits + (size_t)blockIdx.y * digits_per_commitment + i;
+    const uint32_t *src = nullptr;
+    if (i < n_main) src = sc + 8 * i;
+    else if (sc_extra && i >= extra_pos && i < extra_pos + n_extra) src = sc_extra + 8 * (i - extra_pos);
+    if (!src) {
+#pragma unroll
+        for (int r = 0; r < MSM_WIDE_ROWS; r++) out[(size_t)r * row_stride] = 0;
+        return;
+    }
+    uint32_t s[9];
+    load_u32x8(s, src);
+    s[8] = 0;
+    {
+        bool ge = true;          // canonical residue?  (as msm_recode_term)
+#pragma unroll
+        for (int k = 7; k >= 0; k--) {
+            if (s[k] != mod.v[k]) {
+                ge = s[k] > mod.v[k];
+                break;
+            }
+        }
+        if (ge) {
+            atomicAdd(&status[VMPC_ST_NONCANON], 1u);
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = 0;
+        }
+    }
+    // The top digit of a canonical scalar has 13 bits: 2^20 entries of table row 12 would crowd into the lowest 2^13 of
+    // the 2^19 buckets (16 of the 1024 coarse bins six times as full as the rest: 227 us of sorting instead of ~50).
+    // l * P = O for every generator, so s may be replaced by s + k l: with k in [0, 120] (s + k l < 2^259: the top
+    // digit stays below 2^19) chosen by a hash of the column, the top digit 4096 k + (s >> 240) is spread over 94 %
+    // of the buckets like the other twelve.  Scalars below 2^240 (zeros and the small wire values of a witness, whose
+    // few digits are what makes them cheap) are left as they are.
+    if (mod.v[7] == 0x10000000u && (s[7] >> 16) != 0) {
+        const uint32_t k = ((((uint32_t)i * 2654435761u) >> 16) * 121u) >> 16;
+        uint64_t c2 = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            c2 += (uint64_t)s[w] + (uint64_t)k * mod.v[w];
+            s[w] = (uint32_t)c2;
+            c2 >>= 32;
+        }
+        s[8] = (uint32_t)c2;
+    }
+    // H = 2^19 * (1 + 2^20 + ... + 2^240): bit 19 + 20 r set
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        uint32_t hk = 0;
+#pragma unroll
+        for (int r = 0; r < MSM_WIDE_ROWS; r++)
+            if ((19 + 20 * r) / 32 == k) hk |= 1u << ((19 + 20 * r) % 32);
+        const uint64_t v = (uint64_t)s[k] + hk + carry;
+        s[k] = (uint32_t)v;
+        carry = v >> 32;
+    }
+#pragma unroll
+    for (int r = 0; r < MSM_WIDE_ROWS; r++) {
+        const int bit = 20 * r, k = bit / 32, sh = bit % 32;
+        uint32_t f = s[k] >> sh;
+        if (sh > 12) f |= s[k + 1] << (32 - sh);
+        out[(size_t)r * row_stride] = (int32_t)(f & 0xfffffu) - (int32_t)(1u << 19);
+    }
+}
+
+// eight consecutive digits of a row: one 16-byte vector of int16, or two of int32 (wide window)
+template <bool WIDE>
+__device__ __forceinline__ void sort_load8(const int16_t *__restrict__ digits, size_t at, int d[8]) {
+    if (WIDE) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const int32_t *>(digits) + at);
+        const uint4 a = p[0], b = p[1];
+        d[0] = (int)a.x; d[1] = (int)a.y; d[2] = (int)a.z; d[3] = (int)a.w;
+        d[4] = (int)b.x; d[5] = (int)b.y; d[6] = (int)b.z; d[7] = (int)b.w;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4 *>(digits + at);
+        const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = (int)(int16_t)(word[k >> 1] >> (16 * (k & 1)));
+    }
+}
+
+// Wide window: which chunk a workgroup takes.  A (chunk, coarse bin) run is only 8 entries there (8192 positions into
+// 1024 bins), so a bin's region is written in 32-byte pieces, chunk after chunk.  Workgroups are dealt to the XCDs
+// round robin; handing XCD x the chunks [x J/8, (x+1) J/8) in order makes neighbouring pieces come from the SAME
+// L2 at about the same time, where they merge into whole lines before they leave for HBM.
+__device__ __forceinline__ int sort_xcd_chunk(int x, int J) {
+    const int per = (J + 7) / 8;
+    return (x & 7) * per + (x >> 3);
+}
+
 // ---- coarse histogram per (chunk, window) ---------------------------------------------------
 // digit d != 0 lands in bucket b = |d| - 1 in [0, nb); coarse bin = b >> LB, fine bucket = b & (2^LB - 1)
+template <bool WIDE>
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_sort_hist1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, int top_row, int period, int LB_top,
              int J, uint32_t *__restrict__ hist1, uint32_t *__restrict__ ctrl) {
     extern __shared__ uint32_t lds[];
-    const int j = blockIdx.x, w = blockIdx.y;
+    const int j = WIDE ? sort_xcd_chunk(blockIdx.x, J) : (int)blockIdx.x, w = blockIdx.y;
     if (w % period == top_row) LB = LB_top;      // rows of a batch repeat with period = windows per commitment
     // ctrl[0] = #split buckets, [1] = #tasks, [2] = #partial sums, [3] = #big bins, [4] = #buckets split into more
     // than MSM_FINISH_SERIAL segments, [16 ..) = tasks per (length class, window)
-    if (j == 0 && w == 0)
+    if (blockIdx.x == 0 && w == 0)
         for (int i = threadIdx.x; i < 16 + MSM_SEG * (int)gridDim.y; i += SORT_BLOCK) ctrl[i] = 0;
+    if (WIDE && j >= J) return;                  // (the grid is 8 * ceil(J / 8) wide)
     for (int b = threadIdx.x; b < NC; b += SORT_BLOCK) lds[b] = 0;
     __syncthreads();
     const size_t i0 = (size_t)j * SORT_T + 8 * (size_t)threadIdx.x;
     if (i0 < n_pad) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(digits + (size_t)w * n_pad + i0);
-        const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+        int d[8];
+        sort_load8<WIDE>(digits, (size_t)w * n_pad + i0, d);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int d = (int)(int16_t)(word[k >> 1] >> (16 * (k & 1)));
-            if (d != 0) atomicAdd(&lds[((uint32_t)(d < 0 ? -d : d) - 1u) >> LB], 1u);
-        }
+        for (int k = 0; k < 8; k++)
+            if (d[k] != 0) atomicAdd(&lds[((uint32_t)(d[k] < 0 ? -d[k] : d[k]) - 1u) >> LB], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < NC; b += SORT_BLOCK) hist1[((size_t)w * NC + b) * J + j] = lds[b];
 }
 
 // ---- partition a chunk by coarse bin in LDS; every bin's run leaves contiguous -----------------
+template <bool WIDE>
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_sort_part1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, int top_row, int period, int LB_top,
-             int J, int idx_bits, const uint32_t *__restrict__ gbase, uint32_t *__restrict__ out) {
+             int J, int idx_bits, int chunks_per_row, const uint32_t *__restrict__ gbase, uint32_t *__restrict__ out) {
     extern __shared__ uint32_t lds[];
     uint32_t *cnt = lds;                 // [NC]  run lengths
     uint32_t *lbase = lds + NC;          // [NC]  run starts inside the stage
@@ -161,7 +264,8 @@ k_sort_part1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, i
     uint32_t *scratch = lds + 3 * NC;    // [16]
     uint32_t *stage = lds + 3 * NC + 16; // [SORT_T]
     // (a persistent form - two workgroups per CU walking the items - measured slower: 52 vs 38 us)
-    const int j = blockIdx.x, w = blockIdx.y;
+    const int j = WIDE ? sort_xcd_chunk(blockIdx.x, J) : (int)blockIdx.x, w = blockIdx.y;
+    if (WIDE && j >= J) return;
     if (w % period == top_row) LB = LB_top;
     for (int b = threadIdx.x; b < NC; b += SORT_BLOCK) {
         cnt[b] = 0;
@@ -169,18 +273,17 @@ k_sort_part1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, i
     }
     __syncthreads();
     const size_t i0 = (size_t)j * SORT_T + 8 * (size_t)threadIdx.x;
+    // wide window: the chunk lies inside one table row; its entries carry the COLUMN (k_sort_fine reads the row off the
+    // entry's place)
+    const size_t e0 = chunks_per_row ? i0 - (size_t)(j / chunks_per_row) * chunks_per_row * SORT_T : i0;
     uint32_t tag[8];     // coarse bin << 16 | rank inside the bin's run; 0xffffffff = no entry
-    uint32_t word[4] = {0, 0, 0, 0};
-    if (i0 < n_pad) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(digits + (size_t)w * n_pad + i0);
-        word[0] = v.x; word[1] = v.y; word[2] = v.z; word[3] = v.w;
-    }
+    int d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i0 < n_pad) sort_load8<WIDE>(digits, (size_t)w * n_pad + i0, d);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const int d = (int)(int16_t)(word[k >> 1] >> (16 * (k & 1)));
         tag[k] = 0xffffffffu;
-        if (d != 0) {
-            const uint32_t cb = ((uint32_t)(d < 0 ? -d : d) - 1u) >> LB;
+        if (d[k] != 0) {
+            const uint32_t cb = ((uint32_t)(d[k] < 0 ? -d[k] : d[k]) - 1u) >> LB;
             tag[k] = (cb << 16) | atomicAdd(&cnt[cb], 1u);
         }
     }
@@ -202,10 +305,9 @@ k_sort_part1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, i
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         if (tag[k] != 0xffffffffu) {
-            const int d = (int)(int16_t)(word[k >> 1] >> (16 * (k & 1)));
-            const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+            const uint32_t b = (uint32_t)(d[k] < 0 ? -d[k] : d[k]) - 1u;
             stage[lbase[tag[k] >> 16] + (tag[k] & 0xffffu)] =
-                (uint32_t)(i0 + k) | ((b & fmask) << (idx_bits & 31)) | (d < 0 ? 0x80000000u : 0u);
+                (uint32_t)(e0 + k) | ((b & fmask) << (idx_bits & 31)) | (d[k] < 0 ? 0x80000000u : 0u);
         }
     }
     __syncthreads();
@@ -225,7 +327,14 @@ __device__ __forceinline__ uint32_t sort_fine_of(uint32_t e, int idx_bits, uint3
     return ((uint32_t)(d < 0 ? -d : d) - 1u) & fmask;   // per fine bit): one 2-byte gather per entry instead
 }
 
-#define SORT_FINE_REG (SORT_FINE_CAP / SORT_BLOCK)     // entries per thread of a staged bin
+// wide window: the table row an entry belongs to, read off its place `at` in the coarse bin's region (the runs of a
+// bin are laid out chunk by chunk and a chunk lies inside one row: rb[r] = where row r's runs begin), times the row
+// stride: what turns the entry's column into the table position.  n_rows == 0 (every other plan): nothing to add.
+__device__ __forceinline__ uint32_t sort_row_offset(const uint32_t *rb, int n_rows, uint32_t at, uint32_t row_stride) {
+    uint32_t row = 0;
+    for (int r = 1; r < n_rows; r++) row += rb[r] <= at ? 1u : 0u;
+    return row * row_stride;
+}
 
 // LB of a row, and (top row only) the buckets no digit of a canonical scalar reaches are marked empty
 __device__ __forceinline__ int sort_row_lb(int w, int cb, int NC, int LB, int top_row, int period, int LB_top,
@@ -249,17 +358,27 @@ __device__ __forceinline__ int sort_row_lb(int w, int cb, int NC, int LB, int to
 // under-full top window of some plans) are only counted here and sorted by k_sort_fine_big.
 // The tail is pass 1 of the segment planning: segments per bucket, the block's histogram of segment lengths,
 // and partial-sum slots for buckets that need several segments.
-template <bool FINE_IN_ENTRY>
+template <bool FINE_IN_ENTRY, int CAP>
 __global__ void __launch_bounds__(SORT_BLOCK, 8)      // 8 waves per SIMD = two workgroups per CU (<= 64 VGPRs)
 k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase, int NC, int W, int LB, int top_row,
-            int period, int LB_top, int J, int idx_bits, int nb1, const int16_t *__restrict__ digits, size_t n_pad,
+            int period, int LB_top, int J, int idx_bits, int chunks_per_row, uint32_t row_stride, int nb1,
+            const int16_t *__restrict__ digits, size_t n_pad,
             uint32_t *__restrict__ counts, uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
             int seg_shift, int balanced, uint32_t *__restrict__ nseg, uint32_t *__restrict__ block_hist,
             uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ seg_starts,
             uint32_t *__restrict__ ctrl /*[0] = #split buckets, [2] = #partial sums, [3] = #big bins*/) {
     __shared__ uint32_t cnt[512], cur[512], scratch[16];
     __shared__ uint32_t lh[MSM_SEG + 1], heavy_n, heavy_segs, heavy_base, heavy_seg_base;
-    __shared__ uint32_t stage[SORT_FINE_CAP];
+    __shared__ uint32_t rb[MSM_WIDE_ROWS + 3];         // wide window: where each table row's entries start in this bin
+    constexpr int REG = CAP / SORT_BLOCK;              // entries per thread of a staged bin
+    uint32_t *stage;
+    if constexpr (CAP > SORT_FINE_CAP) {               // (the wide window's 64 KB stage: dynamic LDS)
+        extern __shared__ uint32_t fine_stage_dyn[];
+        stage = fine_stage_dyn;
+    } else {
+        __shared__ uint32_t fine_stage[SORT_FINE_CAP];
+        stage = fine_stage;
+    }
     // top window first: under-full, so its bins are the fullest
     const int cb = blockIdx.x % NC, w = W - 1 - blockIdx.x / NC;
     LB = sort_row_lb(w, cb, NC, LB, top_row, period, LB_top, nb1, counts, nseg);
@@ -269,20 +388,22 @@ k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase,
     const uint32_t fmask = (uint32_t)NF - 1u, imask = FINE_IN_ENTRY ? (1u << idx_bits) - 1u : 0x7fffffffu;
     const int16_t *drow = digits + (size_t)w * n_pad;
     const int lane = threadIdx.x & 63;
-    const bool staged = hi - lo <= SORT_FINE_CAP;
+    const bool staged = hi - lo <= (uint32_t)CAP;
+    const int n_rows = chunks_per_row ? J / chunks_per_row : 0;
     for (int f = threadIdx.x; f < NF; f += SORT_BLOCK) cnt[f] = 0;
     if (threadIdx.x <= MSM_SEG) lh[threadIdx.x] = 0;
     if (threadIdx.x == 0) heavy_n = heavy_segs = 0;
+    if ((int)threadIdx.x < n_rows) rb[threadIdx.x] = gbase[slot * J + (size_t)threadIdx.x * chunks_per_row];
     __syncthreads();
-    uint32_t ev[SORT_FINE_REG], rk2[SORT_FINE_REG / 2];      // ranks < 2^16, two per register
+    uint32_t ev[REG], rk2[REG / 2];      // ranks < 2^16, two per register
     if (staged) {
 #pragma unroll
-        for (int k = 0; k < SORT_FINE_REG; k++) {
+        for (int k = 0; k < REG; k++) {
             const uint32_t i = lo + k * SORT_BLOCK + threadIdx.x;
             ev[k] = i < hi ? in[i] : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < SORT_FINE_REG; k++) {
+        for (int k = 0; k < REG; k++) {
             uint32_t r = 0;
             if (lo + k * SORT_BLOCK + threadIdx.x < hi)
                 r = atomicAdd(&cnt[sort_fine_of<FINE_IN_ENTRY>(ev[k], idx_bits, fmask, drow)], 1u);
@@ -352,11 +473,13 @@ k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase,
     }
     if (!staged) return;
 #pragma unroll
-    for (int k = 0; k < SORT_FINE_REG; k++) {
-        if (lo + k * SORT_BLOCK + threadIdx.x < hi) {
+    for (int k = 0; k < REG; k++) {
+        const uint32_t at = lo + k * SORT_BLOCK + threadIdx.x;
+        if (at < hi) {
             const uint32_t e = ev[k];
             const uint32_t f = sort_fine_of<FINE_IN_ENTRY>(e, idx_bits, fmask, drow);
-            stage[cur[f] + ((rk2[k >> 1] >> (16 * (k & 1))) & 0xffffu)] = (e & imask) | (e & 0x80000000u);
+            stage[cur[f] + ((rk2[k >> 1] >> (16 * (k & 1))) & 0xffffu)] =
+                ((e & imask) + sort_row_offset(rb, n_rows, at, row_stride)) | (e & 0x80000000u);
         }
     }
     __syncthreads();
@@ -367,40 +490,51 @@ k_sort_fine(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase,
 // ranks; a bucket's run of the tile then leaves as one contiguous piece (one wave per bucket; the whole
 // workgroup for a run that dominates the tile), appended at the bucket's cursor.  Launched over all bins;
 // a workgroup whose bin was staged (or when no bin was big: ctrl[3] == 0) exits at once.
-template <bool FINE_IN_ENTRY>
+template <bool FINE_IN_ENTRY, int CAP>
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_sort_fine_big(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gbase, int NC, int W, int LB,
-                int top_row, int period, int LB_top, int J, int idx_bits, int nb1, const int16_t *__restrict__ digits,
-                size_t n_pad, const uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
-                const uint32_t *__restrict__ ctrl) {
+                int top_row, int period, int LB_top, int J, int idx_bits, int chunks_per_row, uint32_t row_stride, int nb1,
+                const int16_t *__restrict__ digits, size_t n_pad, const uint32_t *__restrict__ starts,
+                uint32_t *__restrict__ sorted, const uint32_t *__restrict__ ctrl) {
     // (a small grid walking the slots instead of one workgroup per slot was tried in round 4 to make the empty case
     // cheaper: 15 against 13 us - the cost of this launch is not its workgroup count)
     if (ctrl[3] == 0) return;
     const int cb = blockIdx.x % NC, w = W - 1 - blockIdx.x / NC;
     const size_t slot = (size_t)w * NC + cb;
     const uint32_t lo = gbase[slot * J], hi = gbase[(slot + 1) * J];
-    if (hi - lo <= SORT_FINE_CAP) return;
-    __shared__ uint32_t tcnt[512], tex[512], cur[512], scratch[16], long_runs[SORT_FINE_CAP / 512 + 1], n_long;
-    __shared__ uint32_t stage[SORT_FINE_CAP];
+    if (hi - lo <= (uint32_t)CAP) return;
+    __shared__ uint32_t tcnt[512], tex[512], cur[512], scratch[16], long_runs[CAP / 512 + 1], n_long;
+    __shared__ uint32_t rb[MSM_WIDE_ROWS + 3];
+    constexpr int REG = CAP / SORT_BLOCK;
+    uint32_t *stage;
+    if constexpr (CAP > SORT_FINE_CAP) {
+        extern __shared__ uint32_t fine_stage_dyn[];
+        stage = fine_stage_dyn;
+    } else {
+        __shared__ uint32_t fine_stage[SORT_FINE_CAP];
+        stage = fine_stage;
+    }
+    const int n_rows = chunks_per_row ? J / chunks_per_row : 0;
+    if ((int)threadIdx.x < n_rows) rb[threadIdx.x] = gbase[slot * J + (size_t)threadIdx.x * chunks_per_row];
     LB = sort_row_lb(w, cb, NC, LB, top_row, period, LB_top, nb1, nullptr, nullptr);
     const int NF = 1 << LB;
     const uint32_t fmask = (uint32_t)NF - 1u, imask = FINE_IN_ENTRY ? (1u << idx_bits) - 1u : 0x7fffffffu;
     const int16_t *drow = digits + (size_t)w * n_pad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < (unsigned)NF) cur[threadIdx.x] = starts[(size_t)w * nb1 + 1 + (size_t)cb * NF + threadIdx.x];
-    uint32_t ev[SORT_FINE_REG], rk2[SORT_FINE_REG / 2];
-    for (uint32_t t0 = lo; t0 < hi; t0 += SORT_FINE_CAP) {
-        const uint32_t t1 = t0 + SORT_FINE_CAP < hi ? t0 + SORT_FINE_CAP : hi;
+    uint32_t ev[REG], rk2[REG / 2];
+    for (uint32_t t0 = lo; t0 < hi; t0 += CAP) {
+        const uint32_t t1 = t0 + CAP < hi ? t0 + CAP : hi;
         for (int f = threadIdx.x; f < NF; f += SORT_BLOCK) tcnt[f] = 0;
         if (threadIdx.x == 0) n_long = 0;
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < SORT_FINE_REG; k++) {
+        for (int k = 0; k < REG; k++) {
             const uint32_t i = t0 + k * SORT_BLOCK + threadIdx.x;
             ev[k] = i < t1 ? in[i] : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < SORT_FINE_REG; k++) {
+        for (int k = 0; k < REG; k++) {
             uint32_t r = 0;
             if (t0 + k * SORT_BLOCK + threadIdx.x < t1) {
                 const uint32_t f = sort_fine_of<FINE_IN_ENTRY>(ev[k], idx_bits, fmask, drow);
@@ -426,11 +560,13 @@ k_sort_fine_big(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gb
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < SORT_FINE_REG; k++) {
-            if (t0 + k * SORT_BLOCK + threadIdx.x < t1) {
+        for (int k = 0; k < REG; k++) {
+            const uint32_t at = t0 + k * SORT_BLOCK + threadIdx.x;
+            if (at < t1) {
                 const uint32_t e = ev[k];
                 const uint32_t f = sort_fine_of<FINE_IN_ENTRY>(e, idx_bits, fmask, drow);
-                stage[tex[f] + ((rk2[k >> 1] >> (16 * (k & 1))) & 0xffffu)] = (e & imask) | (e & 0x80000000u);
+                stage[tex[f] + ((rk2[k >> 1] >> (16 * (k & 1))) & 0xffffu)] =
+                    ((e & imask) + sort_row_offset(rb, n_rows, at, row_stride)) | (e & 0x80000000u);
             }
         }
         __syncthreads();
@@ -657,6 +793,15 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
     if (ctx->sort_fine_bits >= 0 && ctx->sort_fine_bits <= 9 && ctx->sort_fine_bits <= p.c - 1 &&
         (p.nb >> ctx->sort_fine_bits) <= 4096)
         lb = ctx->sort_fine_bits;                                                          // tuning knob
+    p.fine_cap = SORT_FINE_CAP;
+    if (p.wide) {
+        // one set of 2^19 buckets fed by 13 table rows: 1024 coarse bins of 512 buckets; at 2^20 columns a bin holds
+        // ~13.3 K entries (sigma 115), staged whole in a 16 K-entry LDS stage.  The entry between the passes carries the
+        // column and the fine bucket; the table row comes from the entry's place (k_sort_fine, sort_row_offset)
+        lb = 9;
+        p.idx_bits = p.col_bits;
+        p.fine_cap = 16384;
+    }
     p.LB = lb;
     p.NC = p.nb >> lb;                                       // <= 4096 (c <= 16, lb >= 3 whenever nb > 4096)
     p.fine_in_entry = p.idx_bits + lb <= 31;
@@ -712,7 +857,7 @@ void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, si
     };
     size_t nbk = (size_t)p.W * p.nb1;
     w.entries = (uint32_t *)take(p.n_total * entry_bytes);
-    w.digits = (int16_t *)take((size_t)p.W * p.n_pad * 2);
+    w.digits = (int16_t *)take((size_t)p.W * p.n_pad * (p.wide ? 4 : 2));
     w.hist1_n = (size_t)p.W * p.NC * p.J;
     w.hist1 = (uint32_t *)take((w.hist1_n + 1) * 4);
     w.counts = (uint32_t *)take(nbk * 4);
@@ -786,14 +931,61 @@ int msm_recode_rows_batch(vmpc_ctx *ctx, const void *const *scalars, size_t n_ma
     return VMPC_OK;
 }
 
+int msm_recode_wide_batch(vmpc_ctx *ctx, const void *const *scalars, size_t n_main, const void *const *extra_scalars,
+                          int K, size_t extra_pos, size_t n_extra, size_t row_stride, int32_t *digits32,
+                          size_t digits_per_commitment, const msm_modulus &modulus) {
+    vmpc_stage_scope s(ctx, "msm_recode");
+    msm_recode_batch b;
+    memset(&b, 0, sizeof b);
+    for (int k = 0; k < K; k++) {
+        b.sc[k] = (const uint32_t *)scalars[k];
+        b.sc_extra[k] = extra_scalars ? (const uint32_t *)extra_scalars[k] : nullptr;
+    }
+    k_msm_recode_wide<<<dim3((unsigned)((row_stride + MSM_BLOCK - 1) / MSM_BLOCK), K), MSM_BLOCK, 0, ctx->stream>>>(
+        b, n_main, extra_pos, n_extra, row_stride, digits32, digits_per_commitment, modulus, ctx->d_status);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
 // hist1 -> scan -> part1 -> fine -> plan over digits already in w.digits
+template <bool FINE_IN_ENTRY, int CAP>
+static int msm_launch_fine(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
+    hipStream_t st = ctx->stream;
+    const unsigned grid = (unsigned)p.NC * (unsigned)p.W;
+    const size_t dyn = CAP > SORT_FINE_CAP ? (size_t)CAP * 4 : 0;
+    if (dyn && !ctx->sort_wide_ready) {
+        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_sort_fine<FINE_IN_ENTRY, CAP>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_sort_fine_big<FINE_IN_ENTRY, CAP>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        ctx->sort_wide_ready = true;
+    }
+    k_sort_fine<FINE_IN_ENTRY, CAP><<<grid, SORT_BLOCK, dyn, st>>>(
+        w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period, p.LB_top, p.J, p.idx_bits, p.chunks_per_row,
+        (uint32_t)p.row_stride, p.nb1, w.digits, p.n_pad, w.counts, w.starts, w.sorted, p.seg_shift, p.balanced, w.nseg,
+        w.block_hist, w.heavy_list, w.seg_starts, w.ctrl);
+    k_sort_fine_big<FINE_IN_ENTRY, CAP><<<grid, SORT_BLOCK, dyn, st>>>(
+        w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period, p.LB_top, p.J, p.idx_bits, p.chunks_per_row,
+        (uint32_t)p.row_stride, p.nb1, w.digits, p.n_pad, w.starts, w.sorted, w.ctrl);
+    VMPC_KERNEL_CHECK();
+    return VMPC_OK;
+}
+
 int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
     hipStream_t st = ctx->stream;
-    const dim3 chunk_grid(p.J, p.W);
+    if (p.wide && (!p.fine_in_entry || p.chunks_per_row <= 0 || p.J != p.chunks_per_row * MSM_WIDE_ROWS ||
+                   p.n_pad != (size_t)p.J * SORT_T || p.row_stride != (size_t)p.chunks_per_row * SORT_T))
+        return VMPC_E_INVAL;
+    // wide window: chunks are dealt to the XCDs in contiguous ranges (sort_xcd_chunk): 8 * ceil(J / 8) workgroups
+    const dim3 chunk_grid(p.wide ? 8 * ((p.J + 7) / 8) : p.J, p.W);
     {
         vmpc_stage_scope s(ctx, "msm_hist");
-        k_sort_hist1<<<chunk_grid, SORT_BLOCK, (size_t)p.NC * 4, st>>>(w.digits, p.n_pad, p.NC, p.LB, p.top_row,
-                                                                      p.period, p.LB_top, p.J, w.hist1, w.ctrl);
+        if (p.wide)
+            k_sort_hist1<true><<<chunk_grid, SORT_BLOCK, (size_t)p.NC * 4, st>>>(w.digits, p.n_pad, p.NC, p.LB, p.top_row,
+                                                                                p.period, p.LB_top, p.J, w.hist1, w.ctrl);
+        else
+            k_sort_hist1<false><<<chunk_grid, SORT_BLOCK, (size_t)p.NC * 4, st>>>(w.digits, p.n_pad, p.NC, p.LB, p.top_row,
+                                                                                 p.period, p.LB_top, p.J, w.hist1, w.ctrl);
         VMPC_KERNEL_CHECK();
         VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint32_t>(st, w.hist1, w.hist1, w.hist1_n, w.scan_ws,
                                                             w.hist1 + w.hist1_n)));    // [H] = #entries
@@ -801,35 +993,28 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
     {
         vmpc_stage_scope s(ctx, "msm_part");
         const size_t lds_bytes = ((size_t)3 * p.NC + 16 + SORT_T) * 4;
-        if (lds_bytes > 48 * 1024)
-            VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_sort_part1,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        k_sort_part1<<<chunk_grid, SORT_BLOCK, lds_bytes, st>>>(
-            w.digits, p.n_pad, p.NC, p.LB, p.top_row, p.period, p.LB_top, p.J, p.fine_in_entry ? p.idx_bits : 31, w.hist1,
-            w.stage1);
+        if (p.wide) {
+            if (lds_bytes > 48 * 1024)
+                VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_sort_part1<true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            k_sort_part1<true><<<chunk_grid, SORT_BLOCK, lds_bytes, st>>>(
+                w.digits, p.n_pad, p.NC, p.LB, p.top_row, p.period, p.LB_top, p.J, p.idx_bits, p.chunks_per_row, w.hist1,
+                w.stage1);
+        } else {
+            if (lds_bytes > 48 * 1024)
+                VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_sort_part1<false>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            k_sort_part1<false><<<chunk_grid, SORT_BLOCK, lds_bytes, st>>>(
+                w.digits, p.n_pad, p.NC, p.LB, p.top_row, p.period, p.LB_top, p.J, p.fine_in_entry ? p.idx_bits : 31, 0,
+                w.hist1, w.stage1);
+        }
         VMPC_KERNEL_CHECK();
     }
     {
         vmpc_stage_scope s(ctx, "msm_sort");
-        const unsigned grid = (unsigned)p.NC * (unsigned)p.W;
-        if (p.fine_in_entry) {
-            k_sort_fine<true><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period, p.LB_top,
-                                                          p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.counts, w.starts,
-                                                          w.sorted, p.seg_shift, p.balanced, w.nseg, w.block_hist, w.heavy_list,
-                                                          w.seg_starts, w.ctrl);
-            k_sort_fine_big<true><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period,
-                                                              p.LB_top, p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.starts,
-                                                              w.sorted, w.ctrl);
-        } else {
-            k_sort_fine<false><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period, p.LB_top,
-                                                           p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.counts, w.starts,
-                                                           w.sorted, p.seg_shift, p.balanced, w.nseg, w.block_hist, w.heavy_list,
-                                                           w.seg_starts, w.ctrl);
-            k_sort_fine_big<false><<<grid, SORT_BLOCK, 0, st>>>(w.stage1, w.hist1, p.NC, p.W, p.LB, p.top_row, p.period,
-                                                               p.LB_top, p.J, p.idx_bits, p.nb1, w.digits, p.n_pad, w.starts,
-                                                               w.sorted, w.ctrl);
-        }
-        VMPC_KERNEL_CHECK();
+        if (p.wide) VMPC_CHECK((msm_launch_fine<true, 16384>(ctx, p, w)));
+        else if (p.fine_in_entry) VMPC_CHECK((msm_launch_fine<true, SORT_FINE_CAP>(ctx, p, w)));
+        else VMPC_CHECK((msm_launch_fine<false, SORT_FINE_CAP>(ctx, p, w)));
     }
     {
         vmpc_stage_scope s(ctx, "msm_plan");

@@ -311,8 +311,8 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
                      int h_slots, int k_slot, const uint8_t k_affine[64], const void *z_hat, const void *L_tilde,
                      vmpc_p4 **out) {
     if (!ctx || !table || !z_hat || !L_tilde || !out || !k_affine || h_slots < 0 || k_slot < h_slots ||
-        (size_t)k_slot >= table_extra)
-        return VMPC_E_INVAL;
+        (size_t)k_slot >= table_extra || !(rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16))
+        return VMPC_E_INVAL;       // (rows = 13, the wide-window table, serves commitments only)
     int world = 1, rank = 0;
     if (comm) VMPC_CHECK(vmpc_comm_info(comm, &world, &rank, nullptr));
     // the tail slots (h) belong to the last block only; a sharded CRS keeps h as that block's last generator

@@ -423,7 +423,11 @@ class PointVector:
         of HBM per generator and row); by default the largest with a table of at most 1 GiB: the
         bucket stage gathers table entries at random, and far past the Infinity Cache that costs what
         the shorter recombination saves (at 2^20 generators every choice is within 3 % for one
-        commitment; 8 rows is the best for the prover, see TABLE_BUDGET_BYTES)."""
+        commitment; 8 rows is the best for the prover, see TABLE_BUDGET_BYTES).
+        rows = 13 is the WIDE-WINDOW table (round 6): rows spaced 20 bits, a commitment is 13 mixed additions per
+        term into one set of 2^19 buckets (instead of 16 into 16 / rows sets of 2^15) and needs no recombination -
+        the fastest form for plain commitments over a large CRS (1.7 GB at 2^20 generators); the prover's round
+        context and fold jump do not read it (compressed_pivot._tabulated)."""
         extras = [as_point(p) for p in extras]
         if rows is None and os.environ.get("VMPC_TABLE_ROWS"):
             rows = int(os.environ["VMPC_TABLE_ROWS"])          # tuning knob
