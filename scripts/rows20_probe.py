@@ -64,11 +64,18 @@ def measure(label, t, rows, scs):
         ctx.msm_table_batch(t.ptr, t.n, 0, ptrs, n, None, out.ptr, None, rows)
     ctx.sync()
     per = (time.perf_counter() - t0) / reps / 3 * 1e3
-    print(f"{label:34s} table {rows * n * 128 >> 20:5d} MiB  alone {alone:6.3f} ms  3-per-pass {per:6.3f} ms/commitment  {st}",
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    for _ in range(4):
+        ctx.msm_table_batch(t.ptr, t.n, 0, ptrs, n, None, out.ptr, None, rows)
+        ctx.sync()
+    st3 = {k: round(ms / max(c, 1) * 1e3) for k, (ms, c) in ctx.profile_read(reset=True).items() if ms > 0}
+    ctx.profile(False)
+    print(f"{label:34s} table {rows * n * 128 >> 20:5d} MiB  alone {alone:6.3f} ms  3-per-pass {per:6.3f} ms/commitment  {st}\n{'':34s} stages of a pass of three: {st3} = {sum(st3.values())} us",
           flush=True)
 
 
-for rows in (1, 4, 8, 16, 13):
+for rows in [int(r) for r in os.environ.get('ROWS', '1,4,8,16,13').split(',')]:
     prep = vm.PointVector(pts.a, None, ctx).precompute([], rows=rows)
     measure(f"rows={rows:2d} 253-bit scalars ({13 if rows == 13 else 16} digits)", prep._table, rows, full)
     if rows == 16:

@@ -460,7 +460,8 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
     // short chunks (latency path: one commitment alone, the prover's rounds): weights from the quad tree
     const bool tree = ctx->reduce_tree && msm_reduce_tree_fits(p);
     // ... and with one bucket set per commitment (a 16-row table) its second kernel writes the results itself
-    const bool tree_is_final = tree && p.period == 1 && out_ext && !out_affine;
+    const int tree_parts = tree ? msm_reduce_tree_split(p) : 1;
+    const bool tree_is_final = tree && p.period == 1 && out_ext && !out_affine && tree_parts == 1;
     {
         vmpc_stage_scope s(ctx, "msm_reduce");
         if (tree) {
@@ -473,7 +474,7 @@ static int msm_accumulate(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, const uin
     }
     if (!tree_is_final) {
         vmpc_stage_scope s(ctx, "msm_final");
-        k_msm_final<<<batch, 64, 0, st>>>(w.partials, p.period, tree ? 1 : p.red_blocks, p.c, (uint32_t *)out_ext,
+        k_msm_final<<<batch, 64, 0, st>>>(w.partials, p.period, tree ? tree_parts : p.red_blocks, p.c, (uint32_t *)out_ext,
                                           (uint32_t *)out_affine, ctx->d_status + VMPC_ST_WORDS, ctx->done_flag_dev,
                                           ctx->done_seq);
         ctx->done_flag_dev = nullptr;

@@ -94,10 +94,14 @@ k_msm_reduce_tree(const uint32_t *__restrict__ buckets, const uint32_t *__restri
 // spl > 1 (msm_short.hip): every group's triple arrives as spl PARTIAL triples (the group's entries were shared out
 // among spl workgroups); a triple is linear in the bucket sums, so the parts are added on the way in.
 // reset: words this workgroup zeroes for the next call (the short path's bin cursors), or NULL.
+// sub > 1 (one set of 2^19 buckets: 256 groups of a window, more than one workgroup's LDS holds): workgroup w * sub + h
+// takes the groups [h G, (h + 1) G) of window w and adds their offset h G sum_g D_g = h * DD[0] to Z; the `sub` partial
+// results of a window are consecutive in `out` and k_msm_final (red_blocks = sub) adds them.
 __global__ void __launch_bounds__(RT_THREADS)
 k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_t *__restrict__ out,
                      uint32_t *__restrict__ out_packed, uint32_t *done_counter, uint32_t *done_flag, uint32_t done_seq,
-                     int spl, uint32_t *__restrict__ reset, int reset_words, const uint32_t *__restrict__ poison) {
+                     int spl, uint32_t *__restrict__ reset, int reset_words, const uint32_t *__restrict__ poison,
+                     int sub) {
     extern __shared__ __align__(16) uint32_t rt_lds[];
     uint32_t *TA = rt_lds;
     uint32_t *US = TA + (size_t)G * EXT_WORDS;
@@ -130,6 +134,10 @@ k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_
     const int q = threadIdx.x & 3;
     fe R = rt_ld(EX, 0, q);
     if (G > 1) R = rt_add(R, rt_ld(RR, 0, q), q);
+    if (sub > 1 && G > 1) {
+        const fe D = rt_ld(DD, 0, q);                         // G * sum of this part's leaves
+        for (int h = w % sub; h > 0; h--) R = rt_add(R, D, q);
+    }
     for (int k = 0; k < log2L; k++) R = quadD_dbl(R, q);
     R = rt_add(R, rt_ld(US, 0, q), q);
     // poison[w] != 0 (msm_short.hip: THIS commitment's scalars were beyond the fused path's capacities): the result is
@@ -151,9 +159,17 @@ k_msm_reduce_combine(const uint32_t *__restrict__ in3, int G, int log2L, uint32_
 bool msm_reduce_tree_fits(const msm_plan &p) {
     if (p.chunks % RT_LEAVES != 0 || p.chunks * p.chunk_len != p.nb) return false;
     const int G = p.chunks / RT_LEAVES;
-    // (chunks of 16 buckets: the one set of 2^19 buckets of a wide-window commitment, 128 workgroups of 256 chunk-lanes)
-    return G >= 1 && G <= 128 && (G & (G - 1)) == 0 && p.chunk_len <= (p.wide ? 16 : 8) &&
+    // (the one set of 2^19 buckets of a wide-window commitment: chunks of 16 buckets, or 256 groups combined in two
+    // halves - msm_reduce_tree_split)
+    return G >= 1 && (G <= 128 || (p.wide && G == 256)) && (G & (G - 1)) == 0 && p.chunk_len <= (p.wide ? 16 : 8) &&
            (p.chunk_len & (p.chunk_len - 1)) == 0;
+}
+
+// parts a window's groups are combined in (k_msm_reduce_combine `sub`): the window's result is the sum of that many
+// partial results
+int msm_reduce_tree_split(const msm_plan &p) {
+    const int G = p.chunks / RT_LEAVES;
+    return G > 128 ? G / 128 : 1;
 }
 
 // buckets -> W window sums at w.partials (one per window: k_msm_final's red_blocks = 1); the triples sit behind them.
@@ -162,7 +178,6 @@ bool msm_reduce_tree_fits(const msm_plan &p) {
 int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st, void *out_packed) {
     const int G = p.chunks / RT_LEAVES, L = p.chunk_len;
     const size_t lds_a1 = (size_t)(RT_LEAVES * 2) * EXT_WORDS * 4, lds_aU = (size_t)(RT_LEAVES * 3) * EXT_WORDS * 4;
-    const size_t lds_b = (size_t)(4 * G + 1) * EXT_WORDS * 4;
     if (!ctx->reduce_tree_ready) {
         VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_msm_reduce_tree<false, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a1));
@@ -174,7 +189,8 @@ int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 * 128 + 1) * EXT_WORDS * 4)));
         ctx->reduce_tree_ready = true;
     }
-    uint32_t *triples = w.partials + (size_t)EXT_WORDS * p.W;
+    const int sub = msm_reduce_tree_split(p);
+    uint32_t *triples = w.partials + (size_t)EXT_WORDS * p.W * sub;
     if (L > 2)
         k_msm_reduce_tree<true, true><<<dim3(G, p.W), RT_THREADS / 2, lds_aU, st>>>(w.buckets, w.counts, p.nb, G, L, triples);
     else if (L > 1)
@@ -182,9 +198,10 @@ int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st,
     else
         k_msm_reduce_tree<false, false><<<dim3(G, p.W), RT_THREADS, lds_a1, st>>>(w.buckets, w.counts, p.nb, G, L, triples);
     VMPC_KERNEL_CHECK();
-    k_msm_reduce_combine<<<p.W, RT_THREADS, lds_b, st>>>(triples, G, msm_ilog2(L), w.partials, (uint32_t *)out_packed,
-                                                         ctx->d_status + VMPC_ST_WORDS, out_packed ? ctx->done_flag_dev : nullptr,
-                                                         ctx->done_seq, 1, nullptr, 0, nullptr);
+    if (sub > 1 && out_packed) return VMPC_E_INVAL;            // (the caller lets k_msm_final add the parts)
+    k_msm_reduce_combine<<<p.W * sub, RT_THREADS, (size_t)(4 * (G / sub) + 1) * EXT_WORDS * 4, st>>>(
+        triples, G / sub, msm_ilog2(L), w.partials, (uint32_t *)out_packed, ctx->d_status + VMPC_ST_WORDS,
+        out_packed ? ctx->done_flag_dev : nullptr, ctx->done_seq, 1, nullptr, 0, nullptr, sub);
     if (out_packed) ctx->done_flag_dev = nullptr;
     VMPC_KERNEL_CHECK();
     return VMPC_OK;
@@ -200,7 +217,7 @@ int msm_reduce_combine_launch(vmpc_ctx *ctx, const uint32_t *triples, int W, int
     const size_t lds_b = (size_t)(4 * G + 1) * EXT_WORDS * 4;
     k_msm_reduce_combine<<<W, RT_THREADS, lds_b, st>>>(triples, G, 0, scratch_out, (uint32_t *)out_packed,
                                                        ctx->d_status + VMPC_ST_WORDS, out_packed ? ctx->done_flag_dev : nullptr,
-                                                       ctx->done_seq, spl, reset, reset_words, poison);
+                                                       ctx->done_seq, spl, reset, reset_words, poison, 1);
     if (out_packed) ctx->done_flag_dev = nullptr;
     VMPC_KERNEL_CHECK();
     return VMPC_OK;

@@ -79,6 +79,7 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p);   // from (n_total, c, W) al
 void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, size_t acc_bytes);
 // Ed25519 bucket reduction through the quad tree (msm_reduce_tree.hip): W window sums at w.partials
 bool msm_reduce_tree_fits(const msm_plan &p);
+int msm_reduce_tree_split(const msm_plan &p);      // partial results per window that k_msm_final adds (1: none)
 int msm_reduce_tree(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w, hipStream_t st, void *out_packed);
 // recode -> hist1 -> scan -> part1 -> fine -> plan: fills digits, sorted, starts, counts, nseg,
 // seg_starts, heavy_list, tasks, ctrl[0] = #split buckets, ctrl[1] = #tasks

@@ -219,7 +219,8 @@ __device__ __forceinline__ void sort_load8(const int16_t *__restrict__ digits, s
 // 1024 bins), so a bin's region is written in 32-byte pieces, chunk after chunk.  Workgroups are dealt to the XCDs
 // round robin; handing XCD x the chunks [x J/8, (x+1) J/8) in order makes neighbouring pieces come from the SAME
 // L2 at about the same time, where they merge into whole lines before they leave for HBM.
-__device__ __forceinline__ int sort_xcd_chunk(int x, int J) {
+__device__ __forceinline__ int sort_xcd_chunk(int x, int J, int xcd) {
+    if (!xcd) return x;
     const int per = (J + 7) / 8;
     return (x & 7) * per + (x >> 3);
 }
@@ -229,9 +230,9 @@ __device__ __forceinline__ int sort_xcd_chunk(int x, int J) {
 template <bool WIDE>
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_sort_hist1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, int top_row, int period, int LB_top,
-             int J, uint32_t *__restrict__ hist1, uint32_t *__restrict__ ctrl) {
+             int J, int xcd, uint32_t *__restrict__ hist1, uint32_t *__restrict__ ctrl) {
     extern __shared__ uint32_t lds[];
-    const int j = WIDE ? sort_xcd_chunk(blockIdx.x, J) : (int)blockIdx.x, w = blockIdx.y;
+    const int j = WIDE ? sort_xcd_chunk(blockIdx.x, J, xcd) : (int)blockIdx.x, w = blockIdx.y;
     if (w % period == top_row) LB = LB_top;      // rows of a batch repeat with period = windows per commitment
     // ctrl[0] = #split buckets, [1] = #tasks, [2] = #partial sums, [3] = #big bins, [4] = #buckets split into more
     // than MSM_FINISH_SERIAL segments, [16 ..) = tasks per (length class, window)
@@ -256,7 +257,8 @@ k_sort_hist1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, i
 template <bool WIDE>
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_sort_part1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, int top_row, int period, int LB_top,
-             int J, int idx_bits, int chunks_per_row, const uint32_t *__restrict__ gbase, uint32_t *__restrict__ out) {
+             int J, int idx_bits, int chunks_per_row, int xcd, const uint32_t *__restrict__ gbase,
+             uint32_t *__restrict__ out) {
     extern __shared__ uint32_t lds[];
     uint32_t *cnt = lds;                 // [NC]  run lengths
     uint32_t *lbase = lds + NC;          // [NC]  run starts inside the stage
@@ -264,7 +266,7 @@ k_sort_part1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, i
     uint32_t *scratch = lds + 3 * NC;    // [16]
     uint32_t *stage = lds + 3 * NC + 16; // [SORT_T]
     // (a persistent form - two workgroups per CU walking the items - measured slower: 52 vs 38 us)
-    const int j = WIDE ? sort_xcd_chunk(blockIdx.x, J) : (int)blockIdx.x, w = blockIdx.y;
+    const int j = WIDE ? sort_xcd_chunk(blockIdx.x, J, xcd) : (int)blockIdx.x, w = blockIdx.y;
     if (WIDE && j >= J) return;
     if (w % period == top_row) LB = LB_top;
     for (int b = threadIdx.x; b < NC; b += SORT_BLOCK) {
@@ -306,11 +308,20 @@ k_sort_part1(const int16_t *__restrict__ digits, size_t n_pad, int NC, int LB, i
     for (int k = 0; k < 8; k++) {
         if (tag[k] != 0xffffffffu) {
             const uint32_t b = (uint32_t)(d[k] < 0 ? -d[k] : d[k]) - 1u;
-            stage[lbase[tag[k] >> 16] + (tag[k] & 0xffffu)] =
-                (uint32_t)(e0 + k) | ((b & fmask) << (idx_bits & 31)) | (d[k] < 0 ? 0x80000000u : 0u);
+            const uint32_t cb = tag[k] >> 16, pos = lbase[cb] + (tag[k] & 0xffffu);
+            stage[pos] = (uint32_t)(e0 + k) | ((b & fmask) << (idx_bits & 31)) | (d[k] < 0 ? 0x80000000u : 0u);
+            // wide window: a bin's run of the chunk is ~8 entries; a wave walking 64 such runs one after the other
+            // (below) keeps 8 of its lanes busy for 64 LDS round trips - every staged entry gets its destination
+            // instead and the stage leaves in one sweep
+            if (WIDE) stage[SORT_T + pos] = gb[cb] + (tag[k] & 0xffffu);
         }
     }
     __syncthreads();
+    if (WIDE) {
+        const uint32_t total = lbase[NC - 1] + cnt[NC - 1];
+        for (uint32_t s = threadIdx.x; s < total; s += SORT_BLOCK) out[stage[SORT_T + s]] = stage[s];
+        return;
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int b = wave; b < NC; b += SORT_WAVES) {
         const uint32_t len = cnt[b], lb = lbase[b], g = gb[b];
@@ -835,7 +846,10 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
     // dependency chain, so shorter chunks on more lanes cut the latency
     // (with few windows - fixed-base tables - more chunk-lanes per window keep the same ~64 K lanes busy)
     int chunks = MSM_REDUCE_CHUNKS;
-    while (chunks * 2 * p.W <= MSM_REDUCE_CHUNKS * 16 && chunks * 2 <= ctx->reduce_max_chunks) chunks *= 2;
+    // (one wide-window commitment: 2^16 chunk-lanes of 8 buckets, 256 workgroups - the whole chip - instead of 128)
+    while (chunks * 2 * p.W <= MSM_REDUCE_CHUNKS * 16 &&
+           chunks * 2 <= (p.wide && ctx->reduce_max_chunks == 32768 ? 65536 : ctx->reduce_max_chunks))
+        chunks *= 2;
     // ... and FEWER for many windows (several commitments in one pass): the reduction kernel holds 256 VGPRs, so
     // the chip keeps 2^17 of its lanes resident; beyond 2^16 chunk-lanes a pass runs in rounds, and every lane
     // repeats the offset ladder - at three commitments per pass 1024 chunk-lanes per window do half the work of
@@ -865,7 +879,7 @@ void msm_layout(const msm_plan &p, msm_ws &w, char *base, size_t entry_bytes, si
     w.stage1 = (uint32_t *)take((size_t)p.W * p.n_total * 4);
     w.sorted = (uint32_t *)take((size_t)p.W * p.n_total * 4);
     w.buckets = (uint32_t *)take((size_t)p.W * p.nb * acc_bytes);
-    w.partials = (uint32_t *)take((size_t)p.W * (3 * p.red_blocks + 1) * acc_bytes);     // msm_sort.h
+    w.partials = (uint32_t *)take((size_t)p.W * (3 * p.red_blocks + 4) * acc_bytes);     // msm_sort.h
     // segment planning: at most M/SEG full segments plus one remainder per non-empty bucket
     size_t m_max = (size_t)p.W * p.n_total;
     size_t nonempty_max = m_max < (size_t)p.W * p.nb ? m_max : (size_t)p.W * p.nb;
@@ -977,35 +991,36 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
                    p.n_pad != (size_t)p.J * SORT_T || p.row_stride != (size_t)p.chunks_per_row * SORT_T))
         return VMPC_E_INVAL;
     // wide window: chunks are dealt to the XCDs in contiguous ranges (sort_xcd_chunk): 8 * ceil(J / 8) workgroups
+    static const int xcd = getenv("VMPC_WIDE_XCD") ? atoi(getenv("VMPC_WIDE_XCD")) : 1;      // (A/B knob)
     const dim3 chunk_grid(p.wide ? 8 * ((p.J + 7) / 8) : p.J, p.W);
     {
         vmpc_stage_scope s(ctx, "msm_hist");
         if (p.wide)
             k_sort_hist1<true><<<chunk_grid, SORT_BLOCK, (size_t)p.NC * 4, st>>>(w.digits, p.n_pad, p.NC, p.LB, p.top_row,
-                                                                                p.period, p.LB_top, p.J, w.hist1, w.ctrl);
+                                                                                p.period, p.LB_top, p.J, xcd, w.hist1, w.ctrl);
         else
             k_sort_hist1<false><<<chunk_grid, SORT_BLOCK, (size_t)p.NC * 4, st>>>(w.digits, p.n_pad, p.NC, p.LB, p.top_row,
-                                                                                 p.period, p.LB_top, p.J, w.hist1, w.ctrl);
+                                                                                 p.period, p.LB_top, p.J, 0, w.hist1, w.ctrl);
         VMPC_KERNEL_CHECK();
         VMPC_CHECK((vmpc_exclusive_scan<uint32_t, uint32_t>(st, w.hist1, w.hist1, w.hist1_n, w.scan_ws,
                                                             w.hist1 + w.hist1_n)));    // [H] = #entries
     }
     {
         vmpc_stage_scope s(ctx, "msm_part");
-        const size_t lds_bytes = ((size_t)3 * p.NC + 16 + SORT_T) * 4;
+        const size_t lds_bytes = ((size_t)3 * p.NC + 16 + (p.wide ? 2 : 1) * SORT_T) * 4;
         if (p.wide) {
             if (lds_bytes > 48 * 1024)
                 VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_sort_part1<true>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             k_sort_part1<true><<<chunk_grid, SORT_BLOCK, lds_bytes, st>>>(
-                w.digits, p.n_pad, p.NC, p.LB, p.top_row, p.period, p.LB_top, p.J, p.idx_bits, p.chunks_per_row, w.hist1,
-                w.stage1);
+                w.digits, p.n_pad, p.NC, p.LB, p.top_row, p.period, p.LB_top, p.J, p.idx_bits, p.chunks_per_row, xcd,
+                w.hist1, w.stage1);
         } else {
             if (lds_bytes > 48 * 1024)
                 VMPC_HIP_CHECK(hipFuncSetAttribute((const void *)k_sort_part1<false>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             k_sort_part1<false><<<chunk_grid, SORT_BLOCK, lds_bytes, st>>>(
-                w.digits, p.n_pad, p.NC, p.LB, p.top_row, p.period, p.LB_top, p.J, p.fine_in_entry ? p.idx_bits : 31, 0,
+                w.digits, p.n_pad, p.NC, p.LB, p.top_row, p.period, p.LB_top, p.J, p.fine_in_entry ? p.idx_bits : 31, 0, 0,
                 w.hist1, w.stage1);
         }
         VMPC_KERNEL_CHECK();
@@ -1018,7 +1033,9 @@ int msm_sort_digits(vmpc_ctx *ctx, const msm_plan &p, msm_ws &w) {
     }
     {
         vmpc_stage_scope s(ctx, "msm_plan");
-        if (p.W <= 8) {
+        if (p.W <= 8 && (size_t)p.W * p.NC <= 1024) {
+            // (the windows one after the other in ONE workgroup: only when that is short - three wide-window
+            // commitments of 1024 bins each took 81 us this way, 27 us side by side)
             k_msm_ranks_classes<<<1, 1024, 0, st>>>(w.block_hist, p.NC, p.W, w.ctrl, w.block_base);
             VMPC_KERNEL_CHECK();
         } else {
