@@ -902,9 +902,11 @@ def main():
                          "reduction and recombination chains are paid once per batch; 1 = one commitment per launch")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one commitment in flight (default: 3 launches, on three streams of the same GPU)")
-    ap.add_argument("--table-rows", type=int, default=int(os.environ.get("VMPC_BENCH_TABLE_ROWS", "1")),
-                    help="rows of the resident generator table (1 = prepared form only, no multiples; 2/4/8/16 = "
-                         "fixed-base table with rows - 1 extra multiples per generator, PointVector.precompute)")
+    ap.add_argument("--table-rows", type=int, default=int(os.environ.get("VMPC_BENCH_TABLE_ROWS", "13")),
+                    help="rows of the resident generator table: 13 = the wide-window table (rows spaced 20 bits, 13 mixed "
+                         "additions per term, what pivot._auto_tabulate builds for a CRS of >= 2^19 generators; default "
+                         "since round 6), 1 = prepared form only (no multiples; the headline of rounds 2-5, still timed "
+                         "and reported beside it), 2/4/8/16 = 16-bit-window table with rows - 1 extra multiples")
     ap.add_argument("--depth", type=int, default=int(os.environ.get("VMPC_BENCH_DEPTH", "0")),
                     help="launches in flight (streams of the same GPU); 0 = the measured optimum")
     ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("VMPC_BENCH_WATCHDOG_S", "1500")),
@@ -1164,6 +1166,25 @@ def main():
         steps(args.warmup, other_pts)
     other_runs, (other_results, other_idx) = timed(other_pts, args.repeats)
     other_elapsed = sorted(other_runs)[len(other_runs) // 2]
+    # ... and, when the headline runs over a table of multiples, the prepared form WITHOUT multiples (one 128-byte line
+    # per generator: the headline of rounds 2-5)
+    prepared1 = None
+    if not args.variable_base and args.table_rows != 1:
+        enter("prepared form without multiples")
+        p1 = vm.PointVector(points_plain.a, None, ctx).precompute([], rows=1)
+        grow_workspaces(p1)
+        if args.warmup:
+            steps(args.warmup, p1)
+        p1_runs, (p1_results, p1_idx) = timed(p1, max(1, args.repeats - 2))
+        p1_elapsed = sorted(p1_runs)[len(p1_runs) // 2]
+        prepared1 = {"value": world * n * args.steps / p1_elapsed, "ms_per_step": p1_elapsed / args.steps * 1e3,
+                     "table_MiB": (n * 128) >> 20,
+                     "note": "same K steps and brackets; generators as one prepared 128-byte line each, 16 mixed "
+                             "additions per term (16-bit windows) + recombination"}
+        if not shard.collective:
+            same = {i: pt for pt, i in zip(results, result_idx)}
+            prepared1["same_points_as_headline"] = all(pt == same[i] for pt, i in zip(p1_results, p1_idx) if i in same)
+        del p1
     no_check = bool(os.environ.get("BENCH_NO_CHECK"))          # (developer A/B builds that break the result)
 
     # size-independent correctness property at full size, for every commitment of the last launch:
@@ -1201,6 +1222,8 @@ def main():
         bucket_ms, bucket_n = prof.get("msm_bucket", (0.0, 0))
         t_bucket_timed = bucket_ms / max(bucket_n, 1) / 1e3          # in the timed region: three launches in flight
         c_bits, windows = ctx.msm_plan(n)
+        if args.table_rows == 13 and not args.variable_base:
+            c_bits, windows = 20, 13            # the wide-window table: thirteen 20-bit digits per scalar
         madds = n * windows                     # one mixed addition per non-zero digit (upper bound)
         iso_bucket_s = iso.get("msm_bucket", 0.0) / 1e3
         # The roofline figure uses the kernel ALONE on the GPU (one commitment in flight, same inputs, same
@@ -1242,18 +1265,25 @@ def main():
                                   # the DEFAULT path of a generator vector that is committed to more than once
                                   # (pivot._auto_tabulate: a 4-row table at 2^20); the prepared form beside it
                                   "latency_ms_one_commitment_alone":
+                                      round(iso_ms, 4) if args.table_rows == 13 else
                                       (alone_table or {}).get("ms_per_commitment") or round(iso_ms, 4),
                                   "latency_ms_one_commitment_alone_form":
-                                      (f"{alone_table['rows']}-row fixed-base table (what a PointVector becomes at its "
-                                       "second commitment)" if (alone_table or {}).get("ms_per_commitment")
+                                      ("13-row wide-window table (what a PointVector of >= 2^19 generators becomes at its "
+                                       "second commitment)" if args.table_rows == 13 else
+                                       f"{alone_table['rows']}-row fixed-base table" if (alone_table or {}).get("ms_per_commitment")
                                        else "prepared generators"),
-                                  "latency_ms_one_commitment_alone_prepared_generators": round(iso_ms, 4),
+                                  "latency_ms_one_commitment_alone_4_row_table": (alone_table or {}).get("ms_per_commitment"),
+                                  "latency_ms_one_commitment_alone_headline_form": round(iso_ms, 4),
                                   "what": "value = pipelined throughput (launches_in_flight x commitments_per_launch "
                                           "commitments in flight); a prover's commitments are sequential and cost "
                                           "the latency figure"},
                        "generators": ("plain affine points, prepared inside every call" if args.variable_base else
                                       "resident in prepared form (128-byte niels image of each point, made once "
                                       "at CRS load, untimed)" if args.table_rows == 1 else
+                                      f"resident as the 13-row WIDE-WINDOW fixed-base table (rows spaced 20 bits: 12 extra "
+                                      f"multiples per generator, {(13 * n * 128) >> 20} MiB, made once at CRS load, untimed; "
+                                      f"what pivot._auto_tabulate builds for a CRS committed to more than once)"
+                                      if args.table_rows == 13 else
                                       f"resident as a {args.table_rows}-row fixed-base table ({args.table_rows - 1} extra "
                                       f"multiples per generator, made once at CRS load, untimed)"),
                        "variable_base_scalar_mults_per_s": round(var_value, 1),
@@ -1291,9 +1321,10 @@ def main():
             ("prepared_generators" if args.variable_base else "variable_base"): {
                 "value": other_value, "ms_per_step": other_elapsed / args.steps * 1e3,
                 "note": "same K steps and brackets with the generators in the other form"},
+            "prepared_generators_no_multiples": prepared1,
             "stages_us": {k: round(ms / max(c, 1) * 1e3, 1) for k, (ms, c) in prof.items()},
             "alone": {"over_fixed_base_table": alone_table,
-                      "over_prepared_generators": {"ms_per_commitment": round(iso_ms, 4),
+                      "over_headline_form": {"ms_per_commitment": round(iso_ms, 4),
                                                    "stages_us": {k: round(v * 1e3, 1) for k, v in iso.items()}}},
         }
         if comm_note:

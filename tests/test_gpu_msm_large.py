@@ -132,12 +132,12 @@ def test_config3_tabulated_crs_2_20(vm):
     def flat(proof):
         return {key: (v.to_affine_bytes() if hasattr(v, "to_affine_bytes") else [int(e) for e in v]
                       if isinstance(v, list) else int(v)) for key, v in proof.items()}
-    for rows in (None, 16, 1):
+    for rows in (None, 16, 1, 13):           # (13: the wide-window table, commitments only)
         g.precompute([h, k], rows=rows)
         assert vm.pivot.vector_commitment(x, gamma, g, h) == P
         assert vm.pivot.vector_commitment(x[:12345], 5, g, k) == vm.pivot.vector_commitment(
             x[:12345], 5, vm.PointVector(g.a, None, g.ctx), k)
-        if rows != 16:
+        if rows not in (16, 13):
             tab = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, gamma, gf, transcript="compact",
                                                         r=vm.ScalarVector.from_array(r), rho=7)
             assert flat(tab) == flat(plain)

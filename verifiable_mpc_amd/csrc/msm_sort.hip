@@ -809,7 +809,10 @@ void msm_plan_geometry(vmpc_ctx *ctx, msm_plan &p) {
         // one set of 2^19 buckets fed by 13 table rows: 1024 coarse bins of 512 buckets; at 2^20 columns a bin holds
         // ~13.3 K entries (sigma 115), staged whole in a 16 K-entry LDS stage.  The entry between the passes carries the
         // column and the fine bucket; the table row comes from the entry's place (k_sort_fine, sort_row_offset)
+        // (beyond 2^20 columns - a 2^21-generator CRS, one GPU's share of BASELINE config 4 - narrower bins keep them
+        // inside the stage: 2048 bins of 256 buckets)
         lb = 9;
+        while (lb > 6 && (p.n_total >> (p.c - 1 - lb)) > 14336) lb--;
         p.idx_bits = p.col_bits;
         p.fine_cap = 16384;
     }

@@ -439,13 +439,29 @@ def _table_args(xs, gamma, gv, h, ctx):
 
 # A generator vector somebody commits to a SECOND time is a CRS (pivot.py:139-145 is called with the same g, h for every
 # proof): it is tabulated then, without being asked (PointVector.precompute), and every later commitment over it skips
-# the point preparation and most of the window recombination.  Rows by a budget of 512 MiB per table - the form with
-# the shortest latency for one commitment alone (bench.py `alone`: 4 rows at 2^20, 16 up to 2^18) - and at most
-# AUTO_TABLE_TOTAL bytes of such tables alive per process.
+# the point preparation and most or all of the window recombination.  The form with the shortest latency for one
+# commitment alone (scripts/rows20_probe.py, round 6): 16 rows below 2^19 generators (<= 1 GiB; up to 2^17 columns the
+# fused short path), the 13-row wide-window table from 2^19 up (0.66 / 0.98 / 1.69 ms at 2^19 / 2^20 / 2^21 against
+# 0.71 / 1.04 / 2.06 for the best 16-bit-window table) while it fits AUTO_TABLE_BUDGET; at most AUTO_TABLE_TOTAL bytes
+# of such tables alive per process (288 GB of HBM: these caps are politeness, not necessity).
 AUTO_TABLE_MIN = 1 << 10
-AUTO_TABLE_BUDGET = 512 << 20
-AUTO_TABLE_TOTAL = 8 << 30
+AUTO_TABLE_BUDGET = 8 << 30
+AUTO_TABLE_TOTAL = 32 << 30
+AUTO_TABLE_WIDE_MIN = 1 << 19
 _auto_table_bytes = [0]
+
+
+def _auto_table_rows(n_points):
+    """(rows, bytes) of the table _auto_tabulate builds over n_points generators + one extra"""
+    cols = n_points + 1
+    if n_points >= AUTO_TABLE_WIDE_MIN:
+        stride = (cols + 8191) & ~8191
+        if stride <= 1 << 22 and 13 * 128 * stride <= AUTO_TABLE_BUDGET:
+            return 13, 13 * 128 * stride
+    rows = 16
+    while rows > 1 and rows * 128 * cols > 1 << 30:
+        rows //= 2
+    return rows, rows * 128 * cols
 
 
 def _auto_tabulate(gv, h):
@@ -454,10 +470,7 @@ def _auto_tabulate(gv, h):
     gv._commit_uses = getattr(gv, "_commit_uses", 0) + 1
     if gv._commit_uses != 2:
         return
-    rows = 16
-    while rows > 1 and rows * 128 * (len(gv) + 1) > AUTO_TABLE_BUDGET:
-        rows //= 2
-    nbytes = rows * 128 * (len(gv) + 1)
+    rows, nbytes = _auto_table_rows(len(gv))
     if _auto_table_bytes[0] + nbytes > AUTO_TABLE_TOTAL:
         return
     import weakref
