@@ -380,9 +380,9 @@ def other_sizes_timing(vm, ctx, pows):
         dt = (time.perf_counter() - t0) / reps
         out[f"n2^{lg}"] = {"ms": round(dt * 1e3, 3), "M_scalar_mults_per_s": round(n / dt / 1e6, 1)}
         # the same commitment over the generators as circuit_sat.create_generators hands them to vector_commitment:
-        # a fixed-base table, rows by PointVector.precompute's budget (16 rows up to 2^19 generators, 8 at 2^20, the
-        # prepared form alone beyond) - the latency a prover's commitment actually pays
-        tab = vm.PointVector(pts.a, None, ctx).precompute([])
+        # a fixed-base table, rows as pivot._auto_tabulate picks them (16 rows below 2^19 generators, the 13-row
+        # wide-window table from there up to 2^22, then whatever fits 1 GiB) - the latency a commitment actually pays
+        tab = vm.PointVector(pts.a, None, ctx).precompute([], rows=vm.pivot._auto_table_rows(n)[0])
         t_ = tab._table
         for _ in range(2):
             ctx.msm_table(t_.ptr, t_.n, 0, sc.ptr, n, None, res.ptr, None, rows=t_.rows)
@@ -425,7 +425,7 @@ def distribution_timing(vm, ctx, pows):
         n = 1 << lg
         exps = rand_scalars(rng, n)
         pts = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(exps), keep_proj=False)
-        tab = vm.PointVector(pts.a, None, ctx).precompute([])
+        tab = vm.PointVector(pts.a, None, ctx).precompute([], rows=vm.pivot._auto_table_rows(n)[0])   # (as _auto_tabulate)
         t_ = tab._table
         res = ctx.alloc(128)
         entry = {"crs_table_rows": t_.rows}
@@ -515,6 +515,82 @@ def clocks_sample():
     except Exception as e:
         out["error"] = f"{type(e).__name__}: {e}"
     return out
+
+
+_SAMPLER_CODE = r"""
+import glob, json, sys, time
+# runs as a CHILD started before the parent touches the GPU; reads sysfs only (no HIP, no rocm-smi library)
+cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+want = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+path = cards[want] if want < len(cards) else (cards[0] if cards else None)
+dev = path.rsplit("/", 1)[0] if path else None
+power = (sorted(glob.glob(dev + "/hwmon/hwmon*/power1_average")) + sorted(glob.glob(dev + "/hwmon/hwmon*/power1_input"))) if dev else []
+def cur_mhz(p):
+    try:
+        for line in open(p):
+            if "*" in line:
+                return float(line.split(":")[1].strip().split("M")[0].split("m")[0])
+    except Exception:
+        return None
+while True:
+    rec = {"t": time.time(), "sclk": cur_mhz(path) if path else None}
+    if dev:
+        rec["mclk"] = cur_mhz(dev + "/pp_dpm_mclk")
+    if power:
+        try:
+            rec["w"] = int(open(power[0]).read()) / 1e6
+        except Exception:
+            pass
+    sys.stdout.write(json.dumps(rec) + "\n")
+    sys.stdout.flush()
+    time.sleep(0.004)
+"""
+
+
+class ClockSampler:
+    """sclk / mclk / socket power read from sysfs every few ms by a child process that is started BEFORE this process
+    initialises the GPU (a child started later would be an exec from a GPU-initialised process, which the pool's boxes
+    refuse); window(t0, t1) summarises the samples taken while a measured loop ran - the clocks the kernels actually
+    saw, next to the idle reading of clocks_sample()."""
+
+    def __init__(self, card_index=0):
+        import subprocess
+        import threading
+        self.samples, self.proc = [], None
+        if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+            return                                   # (a profiler's preload initialises the GPU in every child)
+        try:
+            self.proc = subprocess.Popen([sys.executable, "-c", _SAMPLER_CODE, str(card_index)], stdout=subprocess.PIPE,
+                                         stderr=subprocess.DEVNULL, text=True)
+        except Exception:
+            self.proc = None
+            return
+
+        def pump():
+            for line in self.proc.stdout:
+                try:
+                    self.samples.append(json.loads(line))
+                except Exception:
+                    pass
+        threading.Thread(target=pump, daemon=True).start()
+
+    def window(self, t0, t1):
+        inside = [r for r in self.samples if t0 <= r["t"] <= t1]
+        out = {"samples": len(inside), "window_ms": round((t1 - t0) * 1e3, 1)}
+        for key, name in (("sclk", "sclk_mhz"), ("mclk", "mclk_mhz"), ("w", "socket_power_w")):
+            vals = sorted(r[key] for r in inside if r.get(key) is not None)
+            if vals:
+                out[name] = {"min": vals[0], "median": vals[len(vals) // 2], "max": vals[-1]}
+        return out
+
+    def stop(self):
+        if self.proc is not None:
+            try:
+                self.proc.kill()                     # the exact child started above
+                self.proc.wait(timeout=5)
+            except Exception:
+                pass
+            self.proc = None
 
 
 def pinocchio_timing(vm, ctx, n_pow):
@@ -920,6 +996,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     gpu_clocks = clocks_sample() if rank == 0 else None          # before anything below initialises the GPU
+    sampler = ClockSampler(local_rank) if rank == 0 else None    # (likewise: its child starts before GPU init)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import torch
     ndev = torch.cuda.device_count()
@@ -1091,7 +1168,9 @@ def main():
     enter("timed region")
     # the headline: median of `--repeats` back-to-back repetitions of the K-step region (one 20-60 ms window used to
     # decide it; boxes and windows differ by several per cent), min / max reported beside it
+    t_region0 = time.time()
     elapsed_runs, (results, result_idx) = timed(points, args.repeats)
+    t_region1 = time.time()
     elapsed = sorted(elapsed_runs)[len(elapsed_runs) // 2]
     # once more with the per-stage HIP events on every stream the kernels are launched on: the in-region kernel
     # durations of the roofline entry (not part of the headline: the events themselves cost time)
@@ -1131,10 +1210,25 @@ def main():
         c0.profile_read(reset=True)
     for _ in range(iso_steps):             # the same again with the per-stage HIP events: the roofline's kernel time
         shard.finish(shard.launch(scalar_vectors[0], points, 0))
+    busy_clocks = None
     if rank == 0:
         iso = {k: ms / max(c, 1) for k, (ms, c) in c0.profile_read(reset=True).items()}
         c0.profile(False)
         alu_peak = max(c0.madd_rate(400) for _ in range(3))
+    if rank == 0 and sampler is not None and not shard.collective:
+        # the clocks the alone-kernel figures were taken at: the same commitment back to back for ~0.25 s while the
+        # child samples sclk / power (the 5-launch loops above are over before two samples are in)
+        t_a0 = time.time()
+        while time.time() - t_a0 < 0.25:
+            shard.finish(shard.launch(scalar_vectors[0], points, 0))
+        t_a1 = time.time()
+        time.sleep(0.02)
+        busy_clocks = {"one_commitment_alone_loop": sampler.window(t_a0, t_a1),
+                       "timed_region": sampler.window(t_region0, t_region1),
+                       "source": "sysfs pp_dpm_sclk / pp_dpm_mclk / hwmon power1_average, read every ~5 ms by a child "
+                                 "process started before GPU initialisation"}
+    if sampler is not None:
+        sampler.stop()
     # one commitment alone over a 4-row fixed-base table of the same generators (PointVector.precompute: what a CRS
     # that serves many commitments holds; 3 extra multiples per generator): the recombination chain is 48 doublings
     # instead of 240 and the reduction covers 4 bucket sets instead of 16
@@ -1291,7 +1385,7 @@ def main():
                                       if shard.collective else "none"),
                        "dist_backend": args.dist_backend if dist else None,
                        "comm": comm_info,
-                       "gpu_clocks": gpu_clocks,
+                       "gpu_clocks": {"idle_before_gpu_init": gpu_clocks, "busy": busy_clocks},
                        "launched_by": ("bench.py itself (child processes)" if os.environ.get("VMPC_BENCH_SELF_LAUNCHED")
                                        else "external launcher" if "WORLD_SIZE" in os.environ else "plain process")},
             "roofline": {"bound": "hbm", "kernel": "k_msm_bucket", "achieved": achieved,

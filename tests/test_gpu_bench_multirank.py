@@ -134,6 +134,11 @@ def test_one_rank_over_rccl_force_collective():
     assert d["n_gpus"] == 1 and d["checked"] is True and "error" not in d
     assert "rccl" in d["config"]["collective"], d["config"]
     assert d["config"]["comm"]["kind"] == "rccl" and d["config"]["comm"]["world"] == 1      # RCCL's own count
+    # the slot-per-communicator pattern of the multi-GPU run under REAL RCCL: three communicators,
+    # one per commitment slot = one per stream, and the pipelined step loop (three launches in flight, each a pass of
+    # three commitments followed by ncclAllGather + ordered add on ITS stream) running through all of them
+    assert d["config"]["comm"]["communicators"] == 3 and d["config"]["launches_in_flight"] == 3
+    assert d["config"]["commitments_per_launch"] == 3 and "all_gather" in d["config"]["collective"]
     sp = d["ac20_n2^14_sharded"]
     assert "error" not in sp, sp
     assert sp["transport"] == "rccl" and sp["verified"] is True and sp["rounds_in"].startswith("libvmpc_hip")

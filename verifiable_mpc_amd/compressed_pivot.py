@@ -52,6 +52,7 @@ TAIL_BASE = 1 << 16
 # ALUs the fold needs, the text arrives later and the hash waits longer than before.  VMPC_EXPERIMENTAL=1
 # VMPC_EARLY_PAIR_MIN=16384 turns it on; parity is the same either way (tests/test_gpu_protocol.py runs both).
 EARLY_PAIR_MIN = int(os.environ.get("VMPC_EARLY_PAIR_MIN", "0")) if os.environ.get("VMPC_EXPERIMENTAL", "0") != "0" else 0
+EARLY_PAIR_FIRST = os.environ.get("VMPC_EARLY_PAIR_FIRST", "1") != "0"     # the pair ahead of the fold, not beside it
 
 
 # ---- group glue on single elements (independent of the is_additive/is_multiplicative flags) ----
@@ -452,8 +453,13 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
             prep = _early_pair_prepare(g_hat.ctx, L_next, z_next, c, half, gf) if ahead else None
             # reference transcript: the folded vector's text is the bulk of the next pre-image - folded, formatted
             # and copied slice by slice (PointVector.fold), hashed while the rest is still on its way
+            if ahead and EARLY_PAIR_FIRST:
+                # the pair FIRST, the fold ordered behind it (round 6): beside a fold that fills the vector ALUs for
+                # 8.6 ms the four commitments took ~40 ms to come back (EXPERIMENTS R5.9); ahead of it they take ~2 ms,
+                # and the fold's first slice of text follows ~1 ms later
+                early = _early_pair_launch(unfolded, k, half, prep, then=g_hat.ctx)
             g_hat = g_l.fold(g_r, c, stream_text=transcript.mode == "reference")
-            if ahead:
+            if ahead and not EARLY_PAIR_FIRST:
                 early = _early_pair_launch(unfolded, k, half, prep)
         if transcript.mode == "reference":
             # only the reference pre-image contains Q (compressed_pivot.py:52); the compact
@@ -493,13 +499,16 @@ def _early_pair_prepare(main, L_next, z_next, c, half, gf):
     return q, (z_l, z_r, cz_l, cz_r, gamma_a, gamma_b), (sa, sb)
 
 
-def _early_pair_launch(g_hat, k, half, prep):
+def _early_pair_launch(g_hat, k, half, prep, then=None):
     """... and this half: the four commitments over the unfolded vector on the side streams -> a callable that
-    collects (A', B')"""
+    collects (A', B').  then: a context whose LATER work (the fold) is ordered behind the four commitments."""
     q, (z_l, z_r, cz_l, cz_r, gamma_a, gamma_b), (sa, sb) = prep
     g_l, g_r = g_hat[:half], g_hat[half:]
     parts = [pivot._commit_launch(cz_l, 0, g_l[q:], k, sa), pivot._commit_launch(z_l, gamma_a, g_r[q:], k, sa),
              pivot._commit_launch(cz_r, 0, g_l[:q], k, sb), pivot._commit_launch(z_r, gamma_b, g_r[:q], k, sb)]
+    if then is not None:
+        then.wait_for(sa)
+        then.wait_for(sb)
 
     def collect():
         pts = [p.result() for p in parts]
