@@ -518,32 +518,34 @@ def clocks_sample():
 
 
 _SAMPLER_CODE = r"""
-import glob, json, sys, time
-# runs as a CHILD started before the parent touches the GPU; reads sysfs only (no HIP, no rocm-smi library)
-cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-want = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-path = cards[want] if want < len(cards) else (cards[0] if cards else None)
-dev = path.rsplit("/", 1)[0] if path else None
-power = (sorted(glob.glob(dev + "/hwmon/hwmon*/power1_average")) + sorted(glob.glob(dev + "/hwmon/hwmon*/power1_input"))) if dev else []
+import glob, json, os, sys, time
+# runs as a CHILD started before the parent touches the GPU; reads sysfs only (no HIP, no rocm-smi library).  Every card
+# is sampled, keyed by its PCI address: which one the parent computes on is only known after it has initialised the GPU.
+cards = {}
+for p in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+    dev = os.path.realpath(p.rsplit("/", 1)[0])
+    power = sorted(glob.glob(dev + "/hwmon/hwmon*/power1_average")) + sorted(glob.glob(dev + "/hwmon/hwmon*/power1_input"))
+    cards[os.path.basename(dev)] = (dev, power[0] if power else None)
 def cur_mhz(p):
     try:
         for line in open(p):
             if "*" in line:
-                return float(line.split(":")[1].strip().split("M")[0].split("m")[0])
+                return float(line.split(":")[1].strip().lower().split("m")[0])
     except Exception:
         return None
 while True:
-    rec = {"t": time.time(), "sclk": cur_mhz(path) if path else None}
-    if dev:
-        rec["mclk"] = cur_mhz(dev + "/pp_dpm_mclk")
-    if power:
-        try:
-            rec["w"] = int(open(power[0]).read()) / 1e6
-        except Exception:
-            pass
+    rec = {"t": time.time(), "cards": {}}
+    for pci, (dev, power) in cards.items():
+        c = {"sclk": cur_mhz(dev + "/pp_dpm_sclk"), "mclk": cur_mhz(dev + "/pp_dpm_mclk")}
+        if power:
+            try:
+                c["w"] = int(open(power).read()) / 1e6
+            except Exception:
+                pass
+        rec["cards"][pci] = c
     sys.stdout.write(json.dumps(rec) + "\n")
     sys.stdout.flush()
-    time.sleep(0.004)
+    time.sleep(0.003)
 """
 
 
@@ -553,14 +555,14 @@ class ClockSampler:
     refuse); window(t0, t1) summarises the samples taken while a measured loop ran - the clocks the kernels actually
     saw, next to the idle reading of clocks_sample()."""
 
-    def __init__(self, card_index=0):
+    def __init__(self):
         import subprocess
         import threading
         self.samples, self.proc = [], None
         if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
             return                                   # (a profiler's preload initialises the GPU in every child)
         try:
-            self.proc = subprocess.Popen([sys.executable, "-c", _SAMPLER_CODE, str(card_index)], stdout=subprocess.PIPE,
+            self.proc = subprocess.Popen([sys.executable, "-c", _SAMPLER_CODE], stdout=subprocess.PIPE,
                                          stderr=subprocess.DEVNULL, text=True)
         except Exception:
             self.proc = None
@@ -574,11 +576,19 @@ class ClockSampler:
                     pass
         threading.Thread(target=pump, daemon=True).start()
 
-    def window(self, t0, t1):
+    def window(self, t0, t1, pci=None):
+        """min / median / max over the samples of card `pci` (its PCI address, e.g. "0000:05:00.0"; None: the only
+        card, else nothing) taken between the two time.time() stamps"""
         inside = [r for r in self.samples if t0 <= r["t"] <= t1]
-        out = {"samples": len(inside), "window_ms": round((t1 - t0) * 1e3, 1)}
+        out = {"samples": len(inside), "window_ms": round((t1 - t0) * 1e3, 1), "card": pci}
+        names = sorted({k for r in inside for k in r.get("cards", {})})
+        if pci is None and len(names) == 1:
+            pci = out["card"] = names[0]
+        if pci not in names:
+            out["cards_seen"] = names
+            return out
         for key, name in (("sclk", "sclk_mhz"), ("mclk", "mclk_mhz"), ("w", "socket_power_w")):
-            vals = sorted(r[key] for r in inside if r.get(key) is not None)
+            vals = sorted(r["cards"][pci][key] for r in inside if r.get("cards", {}).get(pci, {}).get(key) is not None)
             if vals:
                 out[name] = {"min": vals[0], "median": vals[len(vals) // 2], "max": vals[-1]}
         return out
@@ -996,7 +1006,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     gpu_clocks = clocks_sample() if rank == 0 else None          # before anything below initialises the GPU
-    sampler = ClockSampler(local_rank) if rank == 0 else None    # (likewise: its child starts before GPU init)
+    sampler = ClockSampler() if rank == 0 else None              # (likewise: its child starts before GPU init)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import torch
     ndev = torch.cuda.device_count()
@@ -1223,8 +1233,13 @@ def main():
             shard.finish(shard.launch(scalar_vectors[0], points, 0))
         t_a1 = time.time()
         time.sleep(0.02)
-        busy_clocks = {"one_commitment_alone_loop": sampler.window(t_a0, t_a1),
-                       "timed_region": sampler.window(t_region0, t_region1),
+        try:        # the card this process computes on, by PCI address (the box's sysfs shows every GPU of the node)
+            pr = torch.cuda.get_device_properties(device_index)
+            pci = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            pci = None
+        busy_clocks = {"one_commitment_alone_loop": sampler.window(t_a0, t_a1, pci),
+                       "timed_region": sampler.window(t_region0, t_region1, pci),
                        "source": "sysfs pp_dpm_sclk / pp_dpm_mclk / hwmon power1_average, read every ~5 ms by a child "
                                  "process started before GPU initialisation"}
     if sampler is not None:
