@@ -183,7 +183,7 @@ def prove_timing(vm, ctx, n_pow, rng):
     out["create_generators_ms"] = (time.perf_counter() - t0) * 1e3
     gens = {"g": g, "h": group.generator, "k": vm.Ed25519Point.repeat(group.generator, 0x1234567)}
     t0 = time.perf_counter()
-    g.precompute([gens["h"], gens["k"]])     # CRS setup, as circuit_sat.create_generators does
+    g.precompute([gens["h"], gens["k"]], wide=True)     # CRS setup, as circuit_sat.create_generators does
     ctx.sync()
     out["crs_table_ms"] = (time.perf_counter() - t0) * 1e3
     x = vm.ScalarVector.from_array(rand_scalars(rng, n))

@@ -391,6 +391,11 @@ int vmpc_msm_table_fold_table_dev(vmpc_ctx *ctx, const void *table, size_t table
 typedef struct vmpc_p4 vmpc_p4;
 int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows, int h_slots,
                    int k_slot, const uint8_t k_affine[64], const void *z_hat, const void *L_tilde, vmpc_p4 **out);
+/* A second table over the SAME generators and extras (same n, same extras in the same order) for the A_i, B_i
+ * commitments of the rounds BEFORE the generators are folded - the 13-row wide-window table (vmpc_msm_table_build_dev
+ * with rows = 13): 13 mixed additions per term instead of 16.  The fold itself reads the table given to
+ * vmpc_p4_create (rows spaced 256 / rows bits).  NULL: none.  The caller keeps it alive as long as the context. */
+int vmpc_p4_set_commit_table(vmpc_p4 *p4, const void *table, int rows);
 /* The same rounds with g_hat cut into `world` CONTIGUOUS blocks, one per rank of `comm` (one process
  * per GPU): block_table = vmpc_msm_table_build_dev over THIS rank's block_n = N / world generators (h is the last
  * generator of the last block) with k among its extras (k_slot); z_hat / L_tilde: all N scalars, the same on every

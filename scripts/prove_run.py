@@ -29,7 +29,7 @@ def main():
     gf = vm.GF(group.order)
     g = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(rand_scalars(rng, n)))
     gens = {"g": g, "h": group.generator, "k": vm.Ed25519Point.repeat(group.generator, 12345)}
-    g.precompute([gens["h"], gens["k"]])
+    g.precompute([gens["h"], gens["k"]], wide=os.environ.get("VMPC_CRS_WIDE", "1") != "0")
     x = vm.ScalarVector.from_array(rand_scalars(rng, n))
     L = vm.pivot.LinearForm(vm.ScalarVector.from_array(rand_scalars(rng, n)))
     y = gf(L(x))

@@ -14,7 +14,7 @@ group = vm.EllipticCurve("Ed25519", "projective")
 gf = vm.GF(group.order)
 g = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(rs(rng, n)), keep_proj=False)
 gens = {"g": g, "h": group.generator, "k": vm.Ed25519Point.repeat(group.generator, 12345)}
-g.precompute([gens["h"], gens["k"]])
+g.precompute([gens["h"], gens["k"]], wide=os.environ.get("VMPC_CRS_WIDE", "1") != "0")
 x = vm.ScalarVector.from_array(rs(rng, n))
 L = vm.pivot.LinearForm(vm.ScalarVector.from_array(rs(rng, n)))
 y = gf(L(x))

@@ -226,3 +226,45 @@ def test_the_prover_does_not_take_a_wide_table(nat):
         ctx = vm.get_context()
         t = g._table
         nat.P4Rounds(ctx, t, 0, t.extra_index(k), ctx.alloc(32 * 256).ptr, ctx.alloc(32 * 256).ptr)
+
+
+@pytest.mark.parametrize("log_n", [12, 13])
+def test_round_context_commits_over_the_wide_table(nat, monkeypatch, log_n):
+    """vmpc_p4_set_commit_table: a CRS that holds the wide-window table BESIDE its 16-bit-window one
+    (PointVector.precompute(wide=True), what circuit_sat.create_generators builds from 2^19 generators) gives the very
+    proof of a CRS without it - A (Protocol 5), every A_i / B_i of the round context, z' - and the commitments really
+    run over the 13-row table"""
+    import verifiable_mpc_amd as vm
+    monkeypatch.setenv("VMPC_P4_COMMIT_TABLE_MIN_LOG2", "0")      # (default: only tables beyond the short path's 2^17 columns)
+    rng = random.Random(log_n)
+    n = (1 << log_n) - 1
+    group = vm.EllipticCurve("Ed25519", "projective")
+    gf = vm.GF(group.order)
+    h, k = group.generator, vm.Ed25519Point.repeat(group.generator, rng.randrange(1, ELL))
+    exps = [rng.randrange(1, ELL) for _ in range(n)]
+    x = [rng.randrange(ELL) for _ in range(n)]
+    coeffs = [rng.randrange(ELL) for _ in range(n)]
+    r = [rng.randrange(ELL) for _ in range(n)]
+    proofs = []
+    for wide in (False, True):
+        g = vm.PointVector.fixed_base(h, exps, keep_proj=False)
+        g.precompute([h, k], wide=wide)
+        assert (g._wide is not None) == wide and (not wide or g._wide.rows == WIDE)
+        gens = {"g": g, "h": h, "k": k}
+        xs, L = vm.ScalarVector.from_ints(x), vm.pivot.LinearForm(vm.ScalarVector.from_ints(coeffs))
+        Pc = vm.pivot.vector_commitment(xs, 99, g, h)
+        y = gf(L(xs))
+        ctx = g.ctx
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        proof = vm.compressed_pivot.protocol_5_prover(gens, Pc, L, y, xs, 99, gf, transcript="compact", r=list(r), rho=7)
+        st = {k_: c for k_, (_, c) in ctx.profile_read(reset=True).items() if c}
+        ctx.profile(False)
+        if wide:        # A (Protocol 5) + the pairs of the rounds down to 2^11 generators (then k_p4_direct) over the
+            assert "short_bins" not in st and st.get("msm_bucket", 0) >= 1 + (log_n - 11), st    # general pipeline
+        else:
+            assert "short_bins" in st, st
+        assert vm.compressed_pivot.protocol_5_verifier(gens, Pc, L, y, proof, gf, transcript="compact") is True
+        proofs.append({key: (v.to_affine_bytes() if hasattr(v, "to_affine_bytes") else [int(e) for e in v]
+                             if isinstance(v, list) else int(v)) for key, v in proof.items()})
+    assert proofs[0] == proofs[1]

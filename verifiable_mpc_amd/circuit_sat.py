@@ -38,6 +38,9 @@ def choice_name(pivot_choice):
 PRECOMPUTE_MAX = 1 << 20
 
 
+WIDE_TABLE_MIN = (1 << 19) - 1
+
+
 def create_generators(g_length, pivot_choice, group=None, progress_bar=False):
     """Create generators g, h, k with g_i = h ** r_i on the GPU (one lane per generator,
     csrc/exact.hip k_repeat).  Exponents are drawn from `prng` in the reference's order:
@@ -59,11 +62,13 @@ def create_generators(g_length, pivot_choice, group=None, progress_bar=False):
     g = PointVector.fixed_base(h, random_exponents)
     if choice == "pivot":
         if g_length <= PRECOMPUTE_MAX:
-            g.precompute([h])
+            g.precompute([h], wide=g_length >= WIDE_TABLE_MIN)
         return {"g": g, "h": h}
     k = Ed25519Point.repeat(h, prng.randrange(1, group.order))
     if g_length <= PRECOMPUTE_MAX:
-        g.precompute([h, k])
+        # from 2^19 generators the wide-window table beside the prover's (commitments and the rounds before the fold
+        # jump read it: 13 mixed additions per term; + 13 x 128 bytes per generator of HBM)
+        g.precompute([h, k], wide=g_length >= WIDE_TABLE_MIN)
     return {"g": g, "h": h, "k": k}
 
 

@@ -349,6 +349,8 @@ def _unfold_commitment(Q0, rounds, order, ctx=None):
 
 NATIVE_ROUNDS = os.environ.get("VMPC_NATIVE_ROUNDS", "1") != "0"
 NATIVE_CHAIN = os.environ.get("VMPC_NATIVE_CHAIN", "1") != "0"      # the compact challenge chain inside the C call
+# the pairs of the rounds before the fold jump over the CRS's wide-window table when it holds one (A/B knob)
+USE_WIDE_COMMIT_TABLE = os.environ.get("VMPC_P4_WIDE_TABLE", "1") != "0"
 
 
 def _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, transcript):
@@ -360,7 +362,7 @@ def _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, tran
     Lc = _coeffs_dev(L_tilde)
     def run():
         rounds = P4Rounds(g_hat.ctx, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, Lc.ptr,
-                          n_total=len(z_hat))
+                          n_total=len(z_hat), commit_table=USE_WIDE_COMMIT_TABLE and getattr(g_hat, "_wide", None) or None)
         try:
             n_rounds = len(z_hat).bit_length() - 2
             if NATIVE_CHAIN:

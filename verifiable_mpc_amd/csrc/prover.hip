@@ -255,6 +255,12 @@ struct vmpc_p4 {
     char *mine, *gathered;            // 2 partial points of this rank; world x 2 gathered ones
     bool poisoned;                    // a call failed after the fold state advanced: only destroy is valid
     const void *table0;               // the caller's table (the unfolded CRS / block)
+    // a second table over the SAME generators and extras for the pair commitments of the rounds before the fold
+    // (vmpc_p4_set_commit_table: the 13-row wide-window table - 13 mixed additions per term instead of 16); the fold
+    // itself keeps reading `table0`, whose rows are spaced 256 / rows bits
+    const void *commit_table;
+    int commit_rows;
+    size_t commit_min_cols;
 };
 
 // All device buffers of a context are carved from one arena that stays with the vmpc_ctx between proofs
@@ -325,6 +331,9 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     p->z[0] = p->z[1] = p->L[0] = p->L[1] = p->products = p->va = p->vb = p->ex_a = p->ex_b = p->out = nullptr;
     p->k_aff = p->partials = p->mine = p->gathered = nullptr;
     p->arena = nullptr;
+    p->commit_table = nullptr;
+    p->commit_rows = 0;
+    p->commit_min_cols = 0;
     p->arena_pooled = false;
     p->poisoned = false;
     p->dots_grid = 0;
@@ -428,6 +437,16 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
         return rc;
     }
     *out = p;
+    return VMPC_OK;
+}
+
+extern "C" int vmpc_p4_set_commit_table(vmpc_p4 *p, const void *table, int rows) {
+    if (!p || p->poisoned || (table && rows != 13 && !(rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16)))
+        return VMPC_E_INVAL;
+    p->commit_table = table;
+    p->commit_rows = table ? rows : 0;
+    p->commit_min_cols = (size_t)1 << 17;
+    if (const char *e = getenv("VMPC_P4_COMMIT_TABLE_MIN_LOG2")) p->commit_min_cols = atoi(e) > 0 ? (size_t)1 << atoi(e) : 0;   // (tests)
     return VMPC_OK;
 }
 
@@ -644,8 +663,12 @@ static int p4_round_enqueue(vmpc_p4 *p, const uint32_t *c_mem) {
         // have to be agreed between the ranks)
         const int keep_short = ctx->short_path;
         if (p->comm) ctx->short_path = 0;
-        const int rc = vmpc_msm_table_batch_dev(ctx, p->table, p->table_n, p->table_extra, p->rows, sc, p->table_n, ex, 2,
-                                                pair_out, nullptr);
+        // (only where the fused short path would not run anyway: tables of more than 2^17 columns)
+        const bool over_commit_table = p->commit_table && p->table == p->table0 && !p->comm &&
+                                       p->table_n + p->table_extra > p->commit_min_cols;
+        const int rc = vmpc_msm_table_batch_dev(ctx, over_commit_table ? p->commit_table : p->table, p->table_n,
+                                                p->table_extra, over_commit_table ? p->commit_rows : p->rows, sc,
+                                                p->table_n, ex, 2, pair_out, nullptr);
         ctx->short_path = keep_short;
         ctx->plan_fill_shift = 0;
         VMPC_CHECK(rc);

@@ -251,6 +251,7 @@ class PointVector:
         self._digest = None
         self._table = None       # FixedBaseTable over this vector (precompute)
         self._table_tail = 0     # trailing elements that are the table's extras 0.._table_tail-1
+        self._wide = None        # the 13-row wide-window table over the same vector and extras (precompute(wide=True))
 
     # ---- construction ----------------------------------------------------------------------
     @classmethod
@@ -349,6 +350,7 @@ class PointVector:
                               self.ctx)
             if a == 0 and self._table is not None:
                 sub._table = self._table       # a prefix addresses the same table rows
+                sub._wide = self._wide
                 sub._table_tail = max(0, b - (len(self) - self._table_tail))
             return sub
         if key < 0:
@@ -406,6 +408,7 @@ class PointVector:
             out = PointVector(affine(), proj() if self.has_proj else None, self.ctx)
         if tabulated:
             out._table, out._table_tail = t, m      # g + [h]: h is extra 0 of g's table
+            out._wide = self._wide
         out._text_parent = (src, list(points))      # its transcript text = the source's text + these points' (text_chunks)
         return out
 
@@ -415,7 +418,7 @@ class PointVector:
         return NotImplemented
 
     # ---- kernels -------------------------------------------------------------------------------
-    def precompute(self, extras=(), rows=None):
+    def precompute(self, extras=(), rows=None, wide=False):
         """Build the fixed-base table (include/vmpc.h: vmpc_msm_table_build_dev) for this vector and
         the `extras` (the commitment bases h, k of the CRS).  Commitments over this vector or a
         prefix of it, with one of `extras` as base point, then need no point preparation and only
@@ -440,6 +443,14 @@ class PointVector:
         buf = self.ctx.msm_table_build(self.a.ptr, len(self), eb.ptr if eb else None, len(extras), rows)
         self.ctx.sync()
         self._table = FixedBaseTable(buf, len(self), [raw[64 * i:64 * i + 64] for i in range(len(extras))], rows)
+        self._wide = None
+        if wide and rows != 13 and len(self) + len(extras) <= (1 << 22) - 8192:
+            # BESIDE it, the 13-row wide-window table over the same columns: commitments (pivot.vector_commitment, the
+            # prover's A and the A_i, B_i of its rounds before the fold) read this one - 13 mixed additions per term -
+            # while the fold jump keeps the table above, whose rows are spaced 256 / rows bits
+            wbuf = self.ctx.msm_table_build(self.a.ptr, len(self), eb.ptr if eb else None, len(extras), 13)
+            self.ctx.sync()
+            self._wide = FixedBaseTable(wbuf, len(self), list(self._table.extra_bytes), 13)
         return self
 
     TEXT_SLICE = 1 << 16     # fold(stream_text=True): elements folded, formatted and sent to the host at a time

@@ -416,7 +416,9 @@ def _table_args(xs, gamma, gv, h, ctx):
     table: gv is (a prefix of) a tabulated vector, possibly followed by the first `tail` extras of the table
     (g + [h]), and h is one of the remaining extras.  None otherwise."""
     import numpy as np
-    table = getattr(gv, "_table", None)
+    # (a vector that holds the wide-window table beside its 16-bit-window one - PointVector.precompute(wide=True) -
+    # is committed to over the former)
+    table = getattr(gv, "_wide", None) or getattr(gv, "_table", None)
     if table is None:
         return None
     n = len(xs)
