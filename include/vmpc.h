@@ -314,6 +314,11 @@ int vmpc_host_free(void *p);
 int vmpc_ed25519_fold_commitment_host(const uint8_t A[64], const uint8_t Q[64], const uint8_t B[64],
                                       const uint8_t c[32], uint8_t out[64]);
 
+/* out = sum_i scalars[i] * points[i] on the HOST (n <= 8; affine 64-byte points, canonical 32-byte residues): the
+ * commitment Q = A * P**c0 * k**(c1 (c0 y + t)) of compressed_pivot.py:140 / :233, whose normalised value the first
+ * round's pre-image contains (no device, no context). */
+int vmpc_ed25519_lincomb_host(const uint8_t *points, const uint8_t *scalars, size_t n, uint8_t out[64]);
+
 /* ---- BN-256 G1 / G2 (Pinocchio prover MSMs) ----------------------------------
  * The eight sums of verifiable_mpc/trinocchio/pynocchio.py:229-246
  *     apply_to_list(point_add, [int(c[i]) * evalkey[...] for i in qap.indices_mid])

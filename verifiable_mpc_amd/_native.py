@@ -33,7 +33,7 @@ SYMBOLS = [
     "vmpc_msm_dev", "vmpc_msm_table_bytes", "vmpc_msm_table_build_dev", "vmpc_msm_table_dev", "vmpc_msm_table_batch_dev", "vmpc_points_sum_dev", "vmpc_points_sum_many_dev", "vmpc_fixed_base_dev", "vmpc_repeat_dev", "vmpc_fold_dev",
     "vmpc_tree_reduce_dev", "vmpc_normalize_dev", "vmpc_affine_to_proj_dev", "vmpc_fr_axpy_dev",
     "vmpc_fr_scale_dev", "vmpc_fr_axpy_tail_dev", "vmpc_fr_dot_dev", "vmpc_fr_dot_to_dev", "vmpc_format_points_dev", "vmpc_format_scalars_dev",
-    "vmpc_format_points_chunked_dev", "vmpc_format_scalars_chunked_dev", "vmpc_ed25519_fold_commitment_host",
+    "vmpc_format_points_chunked_dev", "vmpc_format_scalars_chunked_dev", "vmpc_ed25519_fold_commitment_host", "vmpc_ed25519_lincomb_host",
     "vmpc_format_points_async_dev", "vmpc_format_scalars_async_dev", "vmpc_host_alloc", "vmpc_host_free",
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev", "vmpc_fr_tail_scalars_block_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
@@ -125,6 +125,7 @@ def load_library():
         "vmpc_format_points_async_dev": (i32, [vp, vp, sz, vp, sz, vp, vp]),
         "vmpc_format_scalars_async_dev": (i32, [vp, vp, sz, i32, vp, sz, vp, vp]),
         "vmpc_ed25519_fold_commitment_host": (i32, [vp, vp, vp, vp, vp]),
+        "vmpc_ed25519_lincomb_host": (i32, [vp, vp, sz, vp]),
         "vmpc_format_points_chunked_dev": (i32, [vp, vp, sz, vp, sz, vp, vp, sz]),
         "vmpc_format_scalars_chunked_dev": (i32, [vp, vp, sz, i32, vp, sz, vp, vp, sz]),
         "vmpc_host_alloc": (i32, [sz, ctypes.POINTER(vp)]),
@@ -1063,6 +1064,17 @@ def ed25519_fixed_base_batch(base, scalars):
     _check(lib.vmpc_ed25519_fixed_base_batch(_np_ptr(b), _np_ptr(s), len(s), _np_ptr(out)),
            "vmpc_ed25519_fixed_base_batch")
     return out
+
+
+def lincomb_host(points_affine, scalars):
+    """sum_i scalars[i] * points[i] (64-byte affine encodings, ints mod l) on the host: vmpc_ed25519_lincomb_host"""
+    lib = load_library()
+    n = len(points_affine)
+    out = ctypes.create_string_buffer(64)
+    sc = b"".join(scalar_to_bytes(v) for v in scalars)
+    _check(lib.vmpc_ed25519_lincomb_host(ctypes.c_char_p(b"".join(points_affine)), ctypes.c_char_p(sc), n, out),
+           "vmpc_ed25519_lincomb_host")
+    return out.raw
 
 
 def fold_commitment_host(a_affine, q_affine, b_affine, c):

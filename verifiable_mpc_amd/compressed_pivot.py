@@ -586,6 +586,10 @@ def protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof, round_i=0, transcript=N
         else:
             deferred.append((A, B, c))
         L_tilde = _fold_form(L_tilde, c, half, gf)
+        if transcript.mode == "reference" and isinstance(L_tilde.coeffs, ScalarVector) and len(g_prime) > 2:
+            # the next pre-image ends with L~: its text on the side stream now, not inside the next hash call (where it
+            # was 5 + 1.3 + ... ms of waiting per proof, round 6)
+            L_tilde.coeffs.text_begin()
         if len(g_prime) <= 2:
             z_prime = proof["z_prime"]
             Q_check = pivot.vector_commitment(z_prime, int(L_tilde(z_prime)), g_prime, k)
@@ -631,11 +635,10 @@ class _LazyQ:
         self.terms = [(1, A), (c0 % order, P), (e % order, k)]
 
     def point(self):
-        acc = None
-        for sc, pt in self.terms:
-            term = pt if sc == 1 else _gpow(pt, sc)
-            acc = term if acc is None else _gmul(acc, term)
-        return acc
+        # on the host in C (vmpc_ed25519_lincomb_host, ~0.15 ms; as Python big-int ladders 8 ms of the first round's
+        # hash call): only the group element matters - the transcript hashes Q normalised (compressed_pivot.py:52)
+        raw = _native.lincomb_host([pt.to_affine_bytes() for _, pt in self.terms], [sc for sc, _ in self.terms])
+        return Ed25519Point.from_affine_bytes(raw)
 
 
 def _extend_form(L, c1):
@@ -716,6 +719,11 @@ def protocol_5_prover(generators, P, L, y, x, gamma, gf, transcript=None, r=None
     if mode == "reference":
         Q = Q.point()
     L_tilde = _extend_form(L, c1)
+    if mode == "reference" and isinstance(L_tilde.coeffs, ScalarVector):
+        # round 0's pre-image ends with L~ (82 MB of text at N = 2^20): formatted and copied on the side stream while
+        # the pair is computed and the 250 MB of generator text in front of it are hashed - left to the hash call it was
+        # 8 ms of waiting inside it (round 6, scripts/ref_stall_probe.py)
+        L_tilde.coeffs.text_begin()
     if not (mode == "compact" and device_mode):
         # compressed_pivot.py:142's self-check; on the compact device path it would be two more inner products
         # with a host round trip each (0.15 ms) for an identity that tests/test_gpu_protocol.py pins
@@ -751,6 +759,8 @@ def protocol_5_verifier(generators, P, L, y, proof, gf, transcript=None):
     if mode == "reference":
         Q = Q.point()
     L_tilde = _extend_form(L, c1)
+    if mode == "reference" and isinstance(L_tilde.coeffs, ScalarVector):
+        L_tilde.coeffs.text_begin()              # (as in the prover: round 0's pre-image ends with L~)
     try:
         verdict = protocol_4_verifier(g_hat, k, Q, L_tilde, gf, proof,
                                       transcript=_p5_setup(generators, k, seed, mode, order), _checked=True)

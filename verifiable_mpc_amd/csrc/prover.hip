@@ -605,6 +605,24 @@ extern "C" int vmpc_ed25519_fold_commitment_host(const uint8_t A[64], const uint
     return VMPC_OK;
 }
 
+// out = sum_i s_i * P_i on the HOST, n <= 8 (affine in and out, canonical residues): Q_0 = A * P**c0 * k**(c1 (c0 y + t))
+// of compressed_pivot.py:140, whose normalised value leads off the first round's pre-image - as Python big-int ladders it
+// was 8 ms inside that round's hash call, for prover and verifier alike (round 6, scripts/ref_stall_probe.py)
+extern "C" int vmpc_ed25519_lincomb_host(const uint8_t *points, const uint8_t *scalars, size_t n, uint8_t out[64]) {
+    if (!points || !scalars || !out || n < 1 || n > 8) return VMPC_E_INVAL;
+    const fe51::el dd = fe51::d2();
+    fe51::pt acc;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t cw[8];
+        memcpy(cw, scalars + 32 * i, 32);
+        if (fr_geq_l(cw)) return VMPC_E_NONCANON;
+        const fe51::pt term = fe51::pt_mul(fe51::pt_from_affine(points + 64 * i), scalars + 32 * i, dd);
+        acc = i ? fe51::pt_add(acc, term, dd) : term;
+    }
+    fe51::pt_to_affine(out, acc);
+    return VMPC_OK;
+}
+
 static int p4_round_enqueue(vmpc_p4 *p, const uint32_t *c_mem) {
     vmpc_ctx *ctx = p->ctx;
     if (p4_jump_due(p)) {
