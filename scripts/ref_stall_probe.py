@@ -24,6 +24,8 @@ group = vm.EllipticCurve("Ed25519", "projective")
 gf = vm.GF(group.order)
 g = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(bench.rand_scalars(rng, n)), keep_proj=True)
 gens = {"g": g, "h": group.generator, "k": vm.Ed25519Point.repeat(group.generator, 0x1234567)}
+if os.environ.get("VMPC_CRS_TABLE", "1") != "0":       # as circuit_sat.create_generators hands a CRS over
+    g.precompute([gens["h"], gens["k"]], wide=True)
 x = vm.ScalarVector.from_array(bench.rand_scalars(rng, n))
 L = vm.pivot.LinearForm(vm.ScalarVector.from_array(bench.rand_scalars(rng, n)))
 y = gf(L(x))

@@ -89,6 +89,11 @@ def test_config3_protocol5_bit_exact_vs_oracle(vm, all_cores, record_hashes, mod
     # ---- setup: create_generators' exponentiations (circuit_sat_r1cs.py:64-70,81), both sides ---------------------
     g = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(exps), keep_proj=(mode == "reference"))
     gens = {"g": g, "h": group.generator, "k": vm.Ed25519Point.repeat(group.generator, ek)}
+    if log_n == 20:
+        # the CRS as circuit_sat.create_generators hands it over: tabulated (8 rows + the 13-row wide-window table), so
+        # that the proof runs the way bench.py times it - commitments over the wide table, the compact prover's round
+        # context, and in the reference transcript the big rounds' A_i, B_i from that context ahead of the exact folds
+        g.precompute([gens["h"], gens["k"]], wide=True)
     base = np.frombuffer(ed.proj_to_bytes(ed.BASE), np.uint8)
     oproj, oaff = c_oracle.fixed_base(base, exps)
     assert (g.affine_array() == oaff).all()

@@ -183,13 +183,27 @@ def test_hash_input_dump_is_what_gets_hashed(vm, golden_small, monkeypatch):
     assert records[n_prover + 1].startswith("Method protocol_4_verifier:")
 
 
-@pytest.mark.parametrize("early_pair", [False, True])
+@pytest.mark.parametrize("early_pair", [False, True, "table_rounds", "table_rounds_wide"])
 def test_protocol5_n1023_device_mode(vm, golden_n1023, monkeypatch, record_hashes, early_pair):
     """N = 1024 in device mode against the reference-made fixture; also with the next round's pair committed over the
-    unfolded vector beside the fold (compressed_pivot._early_pair_*, an experiment that is off by default)"""
+    unfolded vector beside the fold (compressed_pivot._early_pair_*, an experiment that is off by default), and with
+    the big rounds' pairs taken from the round context over the tabulated CRS ahead of the exact folds (round 6:
+    REF_TABLE_PAIR_MIN, what a 2^20-generator CRS from create_generators does) - every challenge of the reference's
+    own run either way"""
     case = golden_n1023
-    monkeypatch.setattr(vm.compressed_pivot, "EARLY_PAIR_MIN", 64 if early_pair else 0)
+    monkeypatch.setattr(vm.compressed_pivot, "EARLY_PAIR_MIN", 64 if early_pair is True else 0)
     group, gens = build_generators(vm, case, monkeypatch, case["seed"] + 1)
+    if isinstance(early_pair, str):
+        monkeypatch.setattr(vm.compressed_pivot, "REF_TABLE_PAIR_MIN", 16)
+        monkeypatch.setenv("VMPC_P4_COMMIT_TABLE_MIN_LOG2", "0")
+        gens["g"].precompute([gens["h"], gens["k"]], wide=early_pair.endswith("wide"))
+        made = []
+        orig = vm._native.P4Rounds.round
+
+        def spy(self, c=None):
+            made.append(c)
+            return orig(self, c)
+        monkeypatch.setattr(vm._native.P4Rounds, "round", spy)
     gf = vm.GF(group.order)
     x = vm.ScalarVector.from_ints([h2i(v) for v in case["x"]])
     L = vm.pivot.LinearForm(vm.ScalarVector.from_ints([h2i(v) for v in case["L"]]))
@@ -200,6 +214,8 @@ def test_protocol5_n1023_device_mode(vm, golden_n1023, monkeypatch, record_hashe
     proof = vm.compressed_pivot.protocol_5_prover(gens, P, L, y, x, gamma, gf)
     hashes = list(record_hashes)
     check_proof(case, proof, hashes)
+    if isinstance(early_pair, str):
+        assert len(made) == 6 and made[0] is None       # rounds 0 .. 5 (vectors of 1024 .. 32 elements) from the context
     assert vm.compressed_pivot.protocol_5_verifier(gens, P, L, y, proof, gf) is True
 
 

@@ -52,7 +52,16 @@ TAIL_BASE = 1 << 16
 # ALUs the fold needs, the text arrives later and the hash waits longer than before.  VMPC_EXPERIMENTAL=1
 # VMPC_EARLY_PAIR_MIN=16384 turns it on; parity is the same either way (tests/test_gpu_protocol.py runs both).
 EARLY_PAIR_MIN = int(os.environ.get("VMPC_EARLY_PAIR_MIN", "0")) if os.environ.get("VMPC_EXPERIMENTAL", "0") != "0" else 0
+EARLY_PAIR_MAX = int(os.environ.get("VMPC_EARLY_PAIR_MAX", str(1 << 62)))   # ... and only up to this length
 EARLY_PAIR_FIRST = os.environ.get("VMPC_EARLY_PAIR_FIRST", "1") != "0"     # the pair ahead of the fold, not beside it
+# reference transcript, device mode, tabulated CRS (round 6): while the vector is at least this long, a round's A_i, B_i
+# come from the ROUND CONTEXT (csrc/prover.hip: commitments over the UNFOLDED, tabulated generators with the challenge
+# products in the scalars - the same group elements) BEFORE the round's exact generator fold is enqueued.  The fold
+# (8.6 ms of arithmetic at 2^19 elements) is still needed - its (X:Y:Z) are the bulk of the next pre-image - but the hash
+# no longer waits for it AND the pair over the folded vector: 11.7 -> ~2.5 ms before round 1's hash, 6.8 -> 2.5 before
+# round 2's.  Below the threshold a pass over the full table (1.3 ms whatever the round) costs more than the short fold
+# + pair it replaces.  0: never.
+REF_TABLE_PAIR_MIN = int(os.environ.get("VMPC_REF_TABLE_PAIR_MIN", str(1 << 16)))
 
 
 # ---- group glue on single elements (independent of the is_additive/is_multiplicative flags) ----
@@ -409,6 +418,32 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
         Q = Q.point()
     tail_cs = None           # challenges not yet applied to g_hat (compact tail)
     early = None             # this round's A, B, launched during the previous round (_early_pair)
+    return _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, transcript, tail_cs, early)
+
+
+def _ref_table_rounds(g_hat, k, L_tilde, z_hat, transcript):
+    """the round context for the reference-transcript prover's big rounds, or None (see REF_TABLE_PAIR_MIN)"""
+    m = len(z_hat) if hasattr(z_hat, "__len__") else 0
+    if not (REF_TABLE_PAIR_MIN and NATIVE_ROUNDS and transcript.mode == "reference" and isinstance(z_hat, ScalarVector)
+            and isinstance(L_tilde.coeffs, ScalarVector) and len(g_hat) == m and m >= 2 * REF_TABLE_PAIR_MIN
+            and m & (m - 1) == 0 and L_tilde.constant == 0 and _tabulated(g_hat, k, whole=True)):
+        return None
+    from ._native import P4Rounds
+    table = g_hat._table
+    return P4Rounds(g_hat.ctx, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, _coeffs_dev(L_tilde).ptr,
+                    n_total=m, commit_table=USE_WIDE_COMMIT_TABLE and getattr(g_hat, "_wide", None) or None)
+
+
+def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, transcript, tail_cs, early):
+    if _on_device(L_tilde.coeffs, z_hat):
+        z_hat = pivot._as_device(z_hat)
+    # reference transcript: the round context that supplies the big rounds' pairs (closed below the threshold, or with
+    # this frame)
+    table_rounds = _ref_table_rounds(g_hat, k, L_tilde, z_hat, transcript)
+    if table_rounds is not None:
+        a0, b0 = table_rounds.round(None)
+        first = (Ed25519Point.from_affine_bytes(a0), Ed25519Point.from_affine_bytes(b0))
+        early = lambda: first                                                    # noqa: E731
     while True:
         if _on_device(L_tilde.coeffs, z_hat):
             z_hat = pivot._as_device(z_hat)
@@ -450,9 +485,19 @@ def protocol_4_prover(g_hat, k, Q, L_tilde, z_hat, gf, proof={}, round_i=0, tran
             g_l, g_r = g_hat[:half], g_hat[half:]
             unfolded = g_hat
             ahead = transcript.mode == "reference" and isinstance(z_next, ScalarVector) and len(g_hat) == m \
-                and isinstance(L_next.coeffs, ScalarVector) and 0 < EARLY_PAIR_MIN <= m and m & (m - 1) == 0
+                and isinstance(L_next.coeffs, ScalarVector) and 0 < EARLY_PAIR_MIN <= m <= EARLY_PAIR_MAX \
+                and m & (m - 1) == 0 and table_rounds is None
             # (its scalars on the main stream and two side streams ordered behind them BEFORE the fold is enqueued)
             prep = _early_pair_prepare(g_hat.ctx, L_next, z_next, c, half, gf) if ahead else None
+            if table_rounds is not None:
+                if half >= 2 * REF_TABLE_PAIR_MIN:
+                    # the NEXT round's pair from the round context, before this round's exact fold is enqueued
+                    an, bn = table_rounds.round(c)
+                    nxt = (Ed25519Point.from_affine_bytes(an), Ed25519Point.from_affine_bytes(bn))
+                    early = lambda nxt=nxt: nxt                                  # noqa: E731
+                else:
+                    table_rounds.close()
+                    table_rounds = None
             # reference transcript: the folded vector's text is the bulk of the next pre-image - folded, formatted
             # and copied slice by slice (PointVector.fold), hashed while the rest is still on its way
             if ahead and EARLY_PAIR_FIRST:
