@@ -1504,6 +1504,35 @@ def main():
             line[f"ac20_n2^{args.sharded_log2n + world.bit_length() - 1}_sharded_weak_scaling"] = sharded_weak
         if cfg4 is not None:
             line[f"msm_config4_n2^{args.config4_log2n}_over_{world}_gpus"] = cfg4
+        # the numbers a reader of the last 2000 characters of this line should see (a harness that keeps a tail of stdout
+        # keeps THIS; everything here is also further up, with its context) - last key of the line on purpose
+        try:
+            a20, hf = line.get("ac20_n2^20") or {}, (line.get("ac20_n2^20") or {}).get("hash_floor") or {}
+            busy = ((line["config"].get("gpu_clocks") or {}).get("busy") or {}).get("timed_region") or {}
+            sizes = line.get("msm_other_sizes") or {}
+            line["summary"] = {
+                "G_scalar_mults_per_s": round(line["value"] / 1e9, 4), "ms_per_step": round(line["ms_per_step"], 4),
+                "generators": f"{args.table_rows}-row table" if not args.variable_base else "plain points",
+                "same_run_prepared_form_ms_per_step": round((line.get("prepared_generators_no_multiples") or {}).get("ms_per_step") or 0, 4) or None,
+                "same_run_variable_base_ms_per_step": round((line.get("variable_base") or {}).get("ms_per_step") or 0, 4) or None,
+                "one_commitment_alone_ms": line["config"]["timing"].get("latency_ms_one_commitment_alone"),
+                "k_msm_bucket_alone_ms": round(line["roofline"]["avg_kernel_ms"], 4),
+                "roofline_frac_hbm": round(line["roofline"]["frac"], 5),
+                "alu_frac": round(line["roofline"]["alu"]["frac"] or 0, 4),
+                "traffic_GB_per_launch": round((line["roofline"]["traffic"] or 0) / 1e9, 3) or None,
+                "checked_against": "C oracle (reference algorithm), bit-exact" if oracle_check else "exponent identity",
+                "prove_ms_compact": a20.get("prove_ms_compact"), "verify_ms_compact": a20.get("verify_ms_compact"),
+                "prove_ms_reference": a20.get("prove_ms_reference"), "verify_ms_reference": a20.get("verify_ms_reference"),
+                "sha256_floor_ms": hf.get("hash_floor_ms"), "prove_over_floor": hf.get("prove_over_floor"),
+                "verify_over_floor": hf.get("verify_over_floor"),
+                "n2^16_ms_over_crs_table": (sizes.get("n2^16") or {}).get("ms_over_crs_table"),
+                "n2^21_ms_over_crs_table": (sizes.get("n2^21") or {}).get("ms_over_crs_table"),
+                "pinocchio_2^18_whole_proof_ms": (line.get("bn256_n2^18") or {}).get("whole_proof_ms"),
+                "busy_sclk_mhz_median": (busy.get("sclk_mhz") or {}).get("median"),
+                "busy_socket_power_w_median": (busy.get("socket_power_w") or {}).get("median"),
+                "cpu_reference_algorithm_1_core_per_s": round((line.get("cpu_baseline") or {}).get("value") or 0, 1) or None}
+        except Exception as e:
+            line["summary"] = {"error": f"{type(e).__name__}: {e}"}
         try:        # RCCL's version banner sits in the C stdio buffer: push it out first, the JSON line is the last line
             import ctypes
             ctypes.CDLL(None).fflush(None)
