@@ -62,6 +62,9 @@ EARLY_PAIR_FIRST = os.environ.get("VMPC_EARLY_PAIR_FIRST", "1") != "0"     # the
 # round 2's.  Below the threshold a pass over the full table (1.3 ms whatever the round) costs more than the short fold
 # + pair it replaces.  0: never.
 REF_TABLE_PAIR_MIN = int(os.environ.get("VMPC_REF_TABLE_PAIR_MIN", str(1 << 16)))
+# (the context on a stream of its own, its pair BESIDE the fold's first slices: measured 450.5 against 444.4 ms - the fold's
+# kernels starve the pair pass, 5.6-6.5 ms before the next hash instead of 2.0 + 1.0 of waiting for text; off)
+REF_TABLE_PAIR_SIDE_STREAM = os.environ.get("VMPC_REF_TABLE_PAIR_SIDE", "0") != "0"
 
 
 # ---- group glue on single elements (independent of the is_additive/is_multiplicative flags) ----
@@ -429,8 +432,15 @@ def _ref_table_rounds(g_hat, k, L_tilde, z_hat, transcript):
             and m & (m - 1) == 0 and L_tilde.constant == 0 and _tabulated(g_hat, k, whole=True)):
         return None
     from ._native import P4Rounds
+    from .device import get_aux_context
     table = g_hat._table
-    return P4Rounds(g_hat.ctx, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, _coeffs_dev(L_tilde).ptr,
+    # on a stream of its own: a round's pair then runs BESIDE the first slices of the exact fold that is enqueued on the
+    # main stream just before it (a 2^16-element slice is a 1-ms ladder on a quarter of the chip's lanes) instead of in
+    # front of them - the pair is back after ~1.7 ms and the fold's first text has landed by then
+    side = get_aux_context(7) if REF_TABLE_PAIR_SIDE_STREAM else g_hat.ctx
+    if side is not g_hat.ctx:
+        side.wait_for(g_hat.ctx)                 # z_hat and L~ were produced on the main stream
+    return P4Rounds(side, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, _coeffs_dev(L_tilde).ptr,
                     n_total=m, commit_table=USE_WIDE_COMMIT_TABLE and getattr(g_hat, "_wide", None) or None)
 
 
@@ -489,12 +499,16 @@ def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, tra
                 and m & (m - 1) == 0 and table_rounds is None
             # (its scalars on the main stream and two side streams ordered behind them BEFORE the fold is enqueued)
             prep = _early_pair_prepare(g_hat.ctx, L_next, z_next, c, half, gf) if ahead else None
+            pair_after_fold = False
             if table_rounds is not None:
                 if half >= 2 * REF_TABLE_PAIR_MIN:
-                    # the NEXT round's pair from the round context, before this round's exact fold is enqueued
-                    an, bn = table_rounds.round(c)
-                    nxt = (Ed25519Point.from_affine_bytes(an), Ed25519Point.from_affine_bytes(bn))
-                    early = lambda nxt=nxt: nxt                                  # noqa: E731
+                    if table_rounds.ctx is not g_hat.ctx:
+                        pair_after_fold = True          # (own stream: asked for right after the fold is enqueued)
+                    else:
+                        # the NEXT round's pair from the round context, before this round's exact fold is enqueued
+                        an, bn = table_rounds.round(c)
+                        nxt = (Ed25519Point.from_affine_bytes(an), Ed25519Point.from_affine_bytes(bn))
+                        early = lambda nxt=nxt: nxt                              # noqa: E731
                 else:
                     table_rounds.close()
                     table_rounds = None
@@ -506,6 +520,10 @@ def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, tra
                 # and the fold's first slice of text follows ~1 ms later
                 early = _early_pair_launch(unfolded, k, half, prep, then=g_hat.ctx)
             g_hat = g_l.fold(g_r, c, stream_text=transcript.mode == "reference")
+            if pair_after_fold:
+                an, bn = table_rounds.round(c)
+                nxt = (Ed25519Point.from_affine_bytes(an), Ed25519Point.from_affine_bytes(bn))
+                early = lambda nxt=nxt: nxt                                      # noqa: E731
             if ahead and not EARLY_PAIR_FIRST:
                 early = _early_pair_launch(unfolded, k, half, prep)
         if transcript.mode == "reference":
