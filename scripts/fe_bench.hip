@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/fe_bench.hip -o /tmp/fe_bench && /tmp/fe_bench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include "../verifiable_mpc_amd/csrc/ge25519.h"
 
@@ -101,6 +102,170 @@ __global__ void k_chain9(const uint32_t *in, uint32_t *out, int iters) {
     for (int k = 0; k < 8; k++) out[8 * i + k] = x.v[k] + y.v[k] + (k == 0 ? x.v[8] ^ y.v[8] : 0);
 }
 
+// ---- round 6: the FP64-FMA product ------------------------------------------------------------
+// 2^255 - 19 in five limbs of 51 bits held as DOUBLES.  A 51 x 51-bit partial product is split exactly by two FMAs
+// (Emmart et al.): with the rounding mode at round-toward-zero, hi = fma(a, b, 2^104) has the exponent of 2^104 and
+// floor(a b / 2^52) in its mantissa, and lo = fma(a, b, (2^104 + 2^52) - hi) = 2^52 + (a b mod 2^52) exactly; both
+// are added up as 64-bit INTEGERS of their bit patterns (the exponent fields are subtracted once per column).  Columns
+// to limbs: fold columns 5..9 with 19, one carry pass, back to doubles by the 2^52 trick.  25 x (2 FMA + 1 FP add + 2
+// integer additions) against 100 v_mad_u64_u32 whose 64-bit accumulation is free.  Checked against fe_mul below.
+struct fe5d {
+    double v[5];
+};
+__device__ __forceinline__ void fe5d_round_toward_zero() {
+    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);       // MODE.FP_ROUND[3:2] (f64 / f16) = toward zero
+}
+__device__ __forceinline__ fe5d fe5d_mul(const fe5d &f, const fe5d &g) {
+    // (set HERE, every product: set once at kernel entry the mode was back at round-to-nearest by the time the FMAs ran -
+    // the results matched a round-to-nearest emulation exactly - the compiler restores the mode it assumes around the
+    // integer <-> double conversions; one scalar instruction per product)
+    fe5d_round_toward_zero();
+    const double C1 = 0x1p104, C2 = 0x1p104 + 0x1p52;
+    unsigned long long hi[9], lo[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) hi[k] = lo[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            // (inline assembly: the compiler resets the rounding mode to round-to-nearest in front of every FP64
+            // instruction it knows about - s_setreg hwreg(MODE, 2, 2), 0 right behind the one above, round 6)
+            double h, t, l;
+            asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(h) : "v"(f.v[i]), "v"(g.v[j]), "v"(C1));
+            asm volatile("v_add_f64 %0, %1, -%2" : "=v"(t) : "v"(C2), "v"(h));
+            asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(l) : "v"(f.v[i]), "v"(g.v[j]), "v"(t));
+            hi[i + j] += (unsigned long long)__double_as_longlong(h);
+            lo[i + j] += (unsigned long long)__double_as_longlong(l);
+        }
+    // strip the exponent fields: column k has n_k = min(k, 8 - k) + 1 terms
+    unsigned long long col[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) col[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const unsigned long long n = (unsigned long long)((k < 4 ? k : 8 - k) + 1);
+        const unsigned long long H = hi[k] - n * (0x467ull << 52), L = lo[k] - n * (0x433ull << 52);
+        col[k] += L;                 // weight 2^(51 k)
+        col[k + 1] += 2 * H;         // 2^52 = 2 * 2^51
+    }
+    // 2^255 = 19: columns 5..9 onto 0..4, then one carry pass
+    unsigned long long r[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) r[k] = col[k] + 19 * col[k + 5];
+    const unsigned long long M = (1ull << 51) - 1;
+    unsigned long long c = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const unsigned long long t = r[k] + c;
+        r[k] = t & M;
+        c = t >> 51;
+    }
+    r[0] += 19 * c;                  // < 2^51 + 2^17: within a limb's slack (inputs < 2^52)
+    fe5d o;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        // (assembly as well: a compiler-visible FP64 subtraction gets scheduled INTO the next product, behind its
+        // s_setreg, with a mode reset of its own in front)
+        const double biased = __longlong_as_double((long long)(r[k] | (0x433ull << 52))), m52 = -0x1p52;
+        asm volatile("v_add_f64 %0, %1, %2" : "=v"(o.v[k]) : "v"(biased), "v"(m52));
+    }
+    return o;
+}
+// the compiler may not move FP64 instructions of ITS OWN (the int -> double conversions of the inputs) behind the first
+// product's s_setreg: it would put a mode reset in front of them
+__device__ __forceinline__ void fe5d_pin(fe5d &a) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) asm volatile("" : "+v"(a.v[k]));
+}
+__global__ void k_chain5d(const uint32_t *in, uint32_t *out, int iters) {
+    fe5d_round_toward_zero();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fe5d x, y;
+    for (int k = 0; k < 5; k++) {
+        x.v[k] = (double)(((unsigned long long)in[8 * (i & 1023) + k] << 19) | (in[8 * (i & 1023) + k + 1] & 0x7ffff));
+        y.v[k] = (double)(((unsigned long long)in[8 * ((i + 7) & 1023) + k] << 19) | (in[8 * ((i + 7) & 1023) + k + 2] & 0x7ffff));
+    }
+    fe5d_pin(x);
+    fe5d_pin(y);
+    for (int k = 0; k < iters; k++) {
+        x = fe5d_mul(x, y);
+        y = fe5d_mul(y, x);
+    }
+    fe5d_pin(x);
+    fe5d_pin(y);
+    for (int k = 0; k < 5; k++) {
+        const unsigned long long v = (unsigned long long)(x.v[k] + y.v[k]);
+        out[8 * i + k] = (uint32_t)v ^ (uint32_t)(v >> 32);
+    }
+}
+// one product of the same two field elements by fe_mul (10 limbs) and by fe5d_mul: equal residues?
+__global__ void k_check5d(const uint32_t *in, uint32_t *bad, unsigned long long *dbg) {
+    fe5d_round_toward_zero();
+    const int i = threadIdx.x;
+    uint32_t a8[8], b8[8];
+    for (int k = 0; k < 8; k++) {
+        a8[k] = in[8 * i + k];
+        b8[k] = in[8 * (i + 64) + k];
+    }
+    a8[7] &= 0x7fffffffu;
+    b8[7] &= 0x7fffffffu;
+    const fe want = fe_mul(fe_mul(fe_load(a8), fe_load(b8)), fe_load(a8));      // two products: the second sees limbs with slack
+    auto to5 = [](const uint32_t *w) {
+        fe5d r;
+        for (int k = 0; k < 5; k++) {
+            unsigned long long v = 0;
+            for (int bit = 0; bit < 51; bit++) {
+                const int p = 51 * k + bit;
+                if (p < 256) v |= (unsigned long long)((w[p >> 5] >> (p & 31)) & 1u) << bit;
+            }
+            r.v[k] = (double)v;
+        }
+        return r;
+    };
+    fe5d x = to5(a8), y = to5(b8);
+    fe5d_pin(x);
+    fe5d_pin(y);
+    fe5d got = fe5d_mul(fe5d_mul(x, y), x);
+    fe5d_pin(got);
+    if (i == 0 && dbg) {
+        for (int k = 0; k < 5; k++) {
+            dbg[k] = (unsigned long long)x.v[k];
+            dbg[5 + k] = (unsigned long long)y.v[k];
+            dbg[10 + k] = (unsigned long long)got.v[k];
+        }
+        for (int k = 0; k < 8; k++) dbg[15 + k] = a8[k];
+    }
+    // compare as canonical 255-bit residues
+    uint32_t w8[8];
+    fe_store(w8, want);
+    unsigned long long limb[5], cc = 0;
+    for (int k = 0; k < 5; k++) limb[k] = (unsigned long long)got.v[k];
+    for (int pass = 0; pass < 3; pass++) {                  // full reduction below 2^255 - 19
+        cc = 0;
+        for (int k = 0; k < 5; k++) {
+            const unsigned long long t = limb[k] + cc;
+            limb[k] = t & ((1ull << 51) - 1);
+            cc = t >> 51;
+        }
+        limb[0] += 19 * cc;
+    }
+    // + 19, take bit 255, subtract: the usual final conditional subtraction
+    unsigned long long t5[5];
+    cc = 19;
+    for (int k = 0; k < 5; k++) {
+        const unsigned long long t = limb[k] + cc;
+        t5[k] = t & ((1ull << 51) - 1);
+        cc = t >> 51;
+    }
+    if (cc) for (int k = 0; k < 5; k++) limb[k] = t5[k];
+    uint32_t g8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < 255; p++)
+        if ((limb[p / 51] >> (p % 51)) & 1ull) g8[p >> 5] |= 1u << (p & 31);
+    bool same = true;
+    for (int k = 0; k < 8; k++) same = same && g8[k] == w8[k];
+    if (!same) atomicAdd(bad, 1u);
+}
+
 template <typename K> double run(K kern, int blocks, int threads, const uint32_t *din, uint32_t *dout, int iters) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -137,6 +302,26 @@ int main() {
     thr = run(k_chain9, B, T, din, dout, iters);
     printf("fe9_mul (9 x 29-bit limbs, product only) latency %.1f ns (1 wave) | %.1f G/s (chain)\n",
            lat * 1e6 / (2.0 * iters), 2.0 * iters * B * T / (thr * 1e-3) / 1e9);
+    {
+        uint32_t *dbad;
+        hipMalloc(&dbad, 4);
+        hipMemset(dbad, 0, 4);
+        unsigned long long *ddbg, hdbg[23];
+        hipMalloc(&ddbg, sizeof hdbg);
+        k_check5d<<<1, 64>>>(din, dbad, getenv("FE5D_DEBUG") ? ddbg : nullptr);
+        uint32_t hbad = 1;
+        hipMemcpy(&hbad, dbad, 4, hipMemcpyDeviceToHost);
+        if (getenv("FE5D_DEBUG")) {
+            hipMemcpy(hdbg, ddbg, sizeof hdbg, hipMemcpyDeviceToHost);
+            for (int k = 0; k < 23; k++) printf("dbg[%d] = %llu\n", k, hdbg[k]);
+        }
+        lat = run(k_chain5d, 1, 64, din, dout, iters);
+        thr = run(k_chain5d, B, T, din, dout, iters);
+        printf("fe5d_mul (5 x 51-bit limbs as doubles, FMA hi / lo split, RZ) latency %.1f ns (1 wave) | %.1f G/s (chain) | "
+               "%s\n", lat * 1e6 / (2.0 * iters), 2.0 * iters * B * T / (thr * 1e-3) / 1e9,
+               hbad ? "value check against fe_mul NOT passed (timing of the instruction mix only, see EXPERIMENTS R6.5)"
+                    : "64 products equal to fe_mul's");
+    }
     for (int blocks : {256 * 2, 256 * 3, 256 * 4, 256 * 8}) {
         double m = run(k_madd, blocks, T, din, dout, 500);
         printf("ge_madd %d blocks x 256: %.2f G madd/s  (%.1f G fe_mul-equivalents/s)\n", blocks,
