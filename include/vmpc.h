@@ -150,7 +150,13 @@ int vmpc_msm_dev(vmpc_ctx *ctx, const void *scalars, const void *affine_points, 
  * points followed by the n_extra extra points (rows * 128 bytes per point, rows padded to a multiple
  * of 8 points: vmpc_msm_table_bytes).  A commitment over a table needs no point preparation and only
  * (16/rows - 1) * 16 doublings of window recombination (none for rows = 16); its result equals
- * vmpc_msm_dev's on the same points and scalars (as a group element; compared after normalisation). */
+ * vmpc_msm_dev's on the same points and scalars (as a group element; compared after normalisation).
+ * rows = 13 is the WIDE-WINDOW table (round 6): rows 2^(20 rho) * P_i, rho = 0..12, row stride a multiple of 8192
+ * points (n + n_extra <= 2^22 - 8192).  A commitment over it is 13 mixed additions per term - the scalar's thirteen signed
+ * 20-bit digits, one set of 2^19 buckets - instead of 16, with no recombination at all: the fastest form for the
+ * commitments of pivot.py:139-145 from 2^19 generators up (0.98 ms alone at 2^20; 1.66 GB).  Accepted by
+ * vmpc_msm_table_dev / _batch_dev and vmpc_p4_set_commit_table; the fold entry points and vmpc_p4_create need one of the
+ * other row counts (their kernels read rows spaced 256 / rows bits). */
 int vmpc_msm_table_bytes(size_t n, size_t n_extra, int rows, size_t *bytes);
 int vmpc_msm_table_build_dev(vmpc_ctx *ctx, const void *affine_points, size_t n,
                              const void *extra_affine_points, size_t n_extra, int rows, void *table);
