@@ -735,11 +735,16 @@ def config4_timing(vm, parallel, shard, total_log2, world, rank, dist, barrier, 
     exps_arr, sc_arr = rand_scalars(rng, n4), rand_scalars(rng, n4)
     pts = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(exps_arr), keep_proj=False)
     prepared = vm.PointVector(pts.a, None, shard.backend.ctxs[0]).precompute([], rows=1)
+    # ... and as the table pivot._auto_tabulate builds for a shard of this size (2^21 terms per rank at 8 ranks: the
+    # 13-row wide-window table, 3.3 GB per rank)
+    table_rows = vm.pivot._auto_table_rows(n4)[0]
+    tabulated = vm.PointVector(pts.a, None, shard.backend.ctxs[0]).precompute([], rows=table_rows)
     sc = vm.ScalarVector.from_array(sc_arr)
     out = {"total_terms": 1 << total_log2, "terms_per_gpu": n4, "n_gpus": world, "sharding": "cyclic by index",
-           "generators": "resident in prepared form"}
+           "generators": f"resident as a {table_rows}-row table (crs_table), in prepared form (prepared), plain points "
+                         f"(variable_base)", "crs_table_rows": table_rows}
     times = {}
-    for label, p_ in (("prepared", prepared), ("variable_base", pts)):
+    for label, p_ in (("crs_table", tabulated), ("prepared", prepared), ("variable_base", pts)):
         res = shard.commit(sc, p_)                       # grows the workspace; the result that gets checked
         runs = []
         for _ in range(5):
