@@ -69,6 +69,8 @@ extern "C" int vmpc_ctx_create(int device, vmpc_ctx **out) {
     }
     const char *w = getenv("VMPC_MSM_WINDOW");
     if (w) c->window_override = atoi(w);
+    const char *fj = getenv("VMPC_FOLD_JUMP_DIGITS");    // 4: the fold jump with 4-bit digits (A/B knob)
+    if (fj && atoi(fj) == 4) c->fold_jump_digit_bits = 4;
     const char *sp = getenv("VMPC_SHORT_PATH");          // 0: commitments over short 16-row tables take the general path
     if (sp) c->short_path = atoi(sp) != 0;
     // measured and left at their defaults (only with VMPC_EXPERIMENTAL=1):

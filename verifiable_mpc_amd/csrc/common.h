@@ -59,6 +59,7 @@ struct vmpc_ctx {
     int short_path = 1;            // commitments over a 16-row table of <= 2^17 columns: the fused path (msm_short.hip)
     int short_backoff = 0;         // eligible calls still to take the general path after an overflow (vmpc_ctx_sync sets it)
     size_t lds_optin = 0;          // the device's largest dynamic LDS per workgroup (sharedMemPerBlockOptin)
+    int fold_jump_digit_bits = 8;  // signed digits of the fold jump's shared schedule (fold_jump.hip; VMPC_FOLD_JUMP_DIGITS=4: the old form)
     bool sort_wide_ready = false;  // the wide window's fine-sort kernels have their dynamic-LDS limit set (msm_sort.hip)
     bool short_ready = false;      // its kernels' dynamic-LDS limits are set on this context's device
     uint32_t *short_cursors = nullptr;   // [2][128] bin fill counts, zero between calls (the path's last kernel re-arms them)

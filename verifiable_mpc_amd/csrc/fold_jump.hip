@@ -83,15 +83,56 @@ k_fold_jump(const uint32_t *__restrict__ table, size_t stride, size_t m_out, int
     }
 }
 
+// The same walk with signed 8-BIT digits (round 6): a row of 256 / rows bits then holds 32 / rows offsets instead of
+// 64 / rows - HALF the lanes, half the table-line reads (the pass is bound by them: 64 x 128 bytes per generator were
+// 8.6 GB at 2^20) - at the price of up to 128 steps down per lane instead of 8.  With half the lanes the chip is full at
+// two waves per SIMD, so a lane may hold 256 registers: both accumulators stay in registers and a step down is a plain
+// addition.  Schedule entry: bits 0..7 = b, 8..12 = row, 15 = negate, 16..23 = |digit| (1..128).
+__global__ void __launch_bounds__(FJ_BLOCK, 2)
+k_fold_jump8(const uint32_t *__restrict__ table, size_t stride, size_t m_out, int O, int e1,
+             const uint32_t *__restrict__ sched, unsigned n_blocks, uint32_t *__restrict__ partial) {
+    const unsigned per_xcd = (n_blocks + 7) / 8;
+    const unsigned l = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;      // consecutive l on one XCD
+    if (l >= n_blocks) return;
+    const unsigned og = (unsigned)O / FJ_WAVES;
+    const int o = __builtin_amdgcn_readfirstlane((int)((l % og) * FJ_WAVES + (threadIdx.x >> 6)));
+    const size_t j = (size_t)(l / og) * 64 + (threadIdx.x & 63);
+    if (j >= m_out) return;                                               // whole waves only when m_out < 64
+    const uint32_t S = gridDim.y, share = blockIdx.y;
+    const uint32_t *sc = sched + (size_t)o * e1;
+    const uint32_t cnt = sc[0];
+    const uint32_t *col = table + NIELS_WORDS * j;
+    uint32_t *slot = partial + EXT_WORDS * ((j * (size_t)O + o) * S + share);
+    ge_ext run = ge_ext_identity(), acc = ge_ext_identity();
+    bool have = false;
+    uint32_t cur = 128;
+    for (uint32_t e = 0; e <= cnt; e++) {
+        const uint32_t ent = sc[1 + e];
+        const uint32_t v = (ent >> 16) & 0xffu;
+        if (cur > v) {                  // entries of |digit| >= cur are all in `run`: it counts once per level
+            if (have)
+                for (; cur > v; cur--) acc = ge_add(acc, run);
+            cur = v;
+        }
+        if (e == cnt) break;
+        if (S > 1 && e % S != share) continue;                            // (wave-uniform)
+        const ge_niels q = niels_ld_line(col + NIELS_WORDS * (((ent >> 8) & 0x1f) * stride + (size_t)(ent & 0xff) * m_out));
+        run = ge_madd(run, ge_niels_select_neg(q, ((ent >> 15) & 1) != 0));
+        have = true;
+    }
+    ext_st(slot, acc);
+}
+
 __global__ void __launch_bounds__(FJ_BLOCK)
-k_fold_jump_combine(const uint32_t *__restrict__ partial, size_t m_out, int O, int S, uint32_t *__restrict__ out_proj) {
+k_fold_jump_combine(const uint32_t *__restrict__ partial, size_t m_out, int O, int S, int digit_bits,
+                    uint32_t *__restrict__ out_proj) {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m_out) return;
     const uint32_t *src = partial + EXT_WORDS * j * (size_t)O * S;
     ge_ext acc = ge_ext_identity();
     for (int o = O - 1; o >= 0; o--) {
         if (o != O - 1)
-            for (int d = 0; d < 4; d++) acc = ge_dbl(acc);
+            for (int d = 0; d < digit_bits; d++) acc = ge_dbl(acc);
         for (int sh = 0; sh < S; sh++) acc = ge_add(acc, ext_ld(src + EXT_WORDS * ((size_t)o * S + sh)));
     }
     fe_st8(out_proj + 24 * j, acc.X);
@@ -107,7 +148,7 @@ k_fold_jump_combine(const uint32_t *__restrict__ partial, size_t m_out, int O, i
 // One inversion per output covers all its rows, row 0 included (Montgomery's trick, as in k_msm_table_build):
 // pass 1 parks (X, Y, Z, Z_0 ... Z_r) in the row's own 128-byte slot, pass 2 (lane 0 of the quad) walks back.
 __global__ void __launch_bounds__(FJ_BLOCK)
-k_fold_jump_table(const uint32_t *__restrict__ partial, size_t m_out, int O, int S, size_t stride, int rows,
+k_fold_jump_table(const uint32_t *__restrict__ partial, size_t m_out, int O, int S, int digit_bits, size_t stride, int rows,
                   uint32_t *__restrict__ table) {
     const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const int q = threadIdx.x & 3;
@@ -117,7 +158,7 @@ k_fold_jump_table(const uint32_t *__restrict__ partial, size_t m_out, int O, int
     for (int sh = 1; sh < S; sh++)
         P = quadD_add_cached(P, quadD_to_cached(fe_ld(src + EXT_WORDS * ((size_t)(O - 1) * S + sh) + FE_LIMBS * q), q), q);
     for (int o = O - 2; o >= 0; o--) {
-        for (int d = 0; d < 4; d++) P = quadD_dbl(P, q);
+        for (int d = 0; d < digit_bits; d++) P = quadD_dbl(P, q);
         for (int sh = 0; sh < S; sh++)
             P = quadD_add_cached(P, quadD_to_cached(fe_ld(src + EXT_WORDS * ((size_t)o * S + sh) + FE_LIMBS * q), q), q);
     }
@@ -171,35 +212,39 @@ static int table_fold(vmpc_ctx *ctx, const void *table, size_t table_n, size_t t
     VMPC_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t stride = (table_n + table_extra + 7) & ~(size_t)7;       // msm.hip: msm_table_stride
     const size_t m_out = n_cols >> k;
-    const int B = 1 << k, O = 64 / rows, e1 = rows * B + 2;
-    // the shared schedule: signed 4-bit digits of the 2^k scalars, per offset sorted by |digit| descending
+    // digit width: 8 bits where a row still holds at least one offset per wave of a workgroup (rows <= 8: the CRS
+    // table of a 2^20-generator proof) - half the lanes and table reads of the 4-bit form (k_fold_jump8); else 4
+    int digit_bits = (rows <= 8 && ctx->fold_jump_digit_bits != 4) ? 8 : 4;
+    const int n_digits = 256 / digit_bits, half = 1 << (digit_bits - 1), per_word = 32 / digit_bits;
+    const int B = 1 << k, O = n_digits / rows, e1 = rows * B + 2;
+    // the shared schedule: signed digits of the 2^k scalars, per offset sorted by |digit| descending
     std::vector<uint32_t> sched((size_t)O * e1, 0);
     {
-        std::vector<std::vector<uint32_t>> by_value((size_t)O * 9);
+        std::vector<std::vector<uint32_t>> by_value((size_t)O * (half + 1));
         for (int b = 0; b < B; b++) {
             uint32_t w[8];
             memcpy(w, scalars + 32 * b, 32);
             if (fr_geq_l(w)) return VMPC_E_NONCANON;
             uint32_t carry = 0;
-            for (int p = 0; p < 64; p++) {
-                uint32_t raw = ((w[p / 8] >> (4 * (p % 8))) & 15u) + carry;
+            for (int p = 0; p < n_digits; p++) {
+                uint32_t raw = ((w[p / per_word] >> (digit_bits * (p % per_word))) & (uint32_t)(2 * half - 1)) + carry;
                 int d = (int)raw;
                 carry = 0;
-                if (raw >= 8) {
-                    d = (int)raw - 16;
+                if (raw >= (uint32_t)half) {
+                    d = (int)raw - 2 * half;
                     carry = 1;
                 }
                 if (d == 0) continue;
                 const uint32_t v = (uint32_t)(d < 0 ? -d : d);
-                by_value[(size_t)(p % O) * 9 + v].push_back((uint32_t)b | ((uint32_t)(p / O) << 8) |
-                                                            ((d < 0 ? 1u : 0u) << 15) | (v << 16));
+                by_value[(size_t)(p % O) * (half + 1) + v].push_back((uint32_t)b | ((uint32_t)(p / O) << 8) |
+                                                                     ((d < 0 ? 1u : 0u) << 15) | (v << 16));
             }
         }
         for (int o = 0; o < O; o++) {
             uint32_t *dst = sched.data() + (size_t)o * e1;
             uint32_t n = 0;
-            for (int v = 8; v >= 1; v--)
-                for (uint32_t ent : by_value[(size_t)o * 9 + v]) dst[1 + n++] = ent;
+            for (int v = half; v >= 1; v--)
+                for (uint32_t ent : by_value[(size_t)o * (half + 1) + v]) dst[1 + n++] = ent;
             dst[0] = n;
         }
     }
@@ -219,18 +264,22 @@ static int table_fold(vmpc_ctx *ctx, const void *table, size_t table_n, size_t t
     VMPC_CHECK(vmpc_stage_h2d(ctx, d_sched, sched.data(), sched.size() * 4));
     const unsigned n_blocks = (unsigned)(((m_out + 63) / 64) * (size_t)(O / FJ_WAVES));
     const unsigned grid = ((n_blocks + 7) / 8) * 8;
-    k_fold_jump<<<dim3(grid, (unsigned)S), FJ_BLOCK, 0, ctx->stream>>>((const uint32_t *)table, stride, m_out, O, e1, d_sched,
-                                                                       n_blocks, d_partial);
+    if (digit_bits == 8)
+        k_fold_jump8<<<dim3(grid, (unsigned)S), FJ_BLOCK, 0, ctx->stream>>>((const uint32_t *)table, stride, m_out, O, e1,
+                                                                            d_sched, n_blocks, d_partial);
+    else
+        k_fold_jump<<<dim3(grid, (unsigned)S), FJ_BLOCK, 0, ctx->stream>>>((const uint32_t *)table, stride, m_out, O, e1,
+                                                                           d_sched, n_blocks, d_partial);
     VMPC_KERNEL_CHECK();
     if (out_affine) {
         k_fold_jump_combine<<<(unsigned)((m_out + FJ_BLOCK - 1) / FJ_BLOCK), FJ_BLOCK, 0, ctx->stream>>>(d_partial, m_out,
-                                                                                                     O, S, d_proj);
+                                                                                                     O, S, digit_bits, d_proj);
         VMPC_KERNEL_CHECK();
         return vmpc_normalize_launch(ctx, d_proj, m_out, out_affine);
     }
     const size_t out_stride = (m_out + out_n_extra + 7) & ~(size_t)7;
     k_fold_jump_table<<<(unsigned)((4 * m_out + FJ_BLOCK - 1) / FJ_BLOCK), FJ_BLOCK, 0, ctx->stream>>>(
-        d_partial, m_out, O, S, out_stride, out_rows, (uint32_t *)out_table);
+        d_partial, m_out, O, S, digit_bits, out_stride, out_rows, (uint32_t *)out_table);
     VMPC_KERNEL_CHECK();
     if (extras_block) {     // the extras' columns as an (out_stride - m_out)-column table of their own: copy, row by row
         const size_t cols = out_stride - m_out;
