@@ -161,7 +161,7 @@ bool msm_reduce_tree_fits(const msm_plan &p) {
     const int G = p.chunks / RT_LEAVES;
     // (the one set of 2^19 buckets of a wide-window commitment: chunks of 16 buckets, or 256 groups combined in two
     // halves - msm_reduce_tree_split)
-    return G >= 1 && (G <= 128 || (p.wide && G == 256)) && (G & (G - 1)) == 0 && p.chunk_len <= (p.wide ? 16 : 8) &&
+    return G >= 1 && (G <= 128 || (p.wide && G == 256)) && (G & (G - 1)) == 0 && p.chunk_len <= (p.wide ? 32 : 8) &&
            (p.chunk_len & (p.chunk_len - 1)) == 0;
 }
 
