@@ -1249,7 +1249,7 @@ def main():
                                  "process started before GPU initialisation"}
     if sampler is not None:
         sampler.stop()
-    # one commitment alone over a 4-row fixed-base table of the same generators (PointVector.precompute: what a CRS
+    # (for comparison) one commitment alone over a 4-row fixed-base table of the same generators (what a CRS
     # that serves many commitments holds; 3 extra multiples per generator): the recombination chain is 48 doublings
     # instead of 240 and the reduction covers 4 bucket sets instead of 16
     alone_table = None
@@ -1377,7 +1377,7 @@ def main():
                                   "headline": "median of the repeats (each: EXACTLY K steps between barrier + device "
                                               "synchronisation, max over ranks)",
                                   # the DEFAULT path of a generator vector that is committed to more than once
-                                  # (pivot._auto_tabulate: a 4-row table at 2^20); the prepared form beside it
+                                  # (pivot._auto_tabulate: the 13-row wide-window table at 2^20); other forms beside it
                                   "latency_ms_one_commitment_alone":
                                       round(iso_ms, 4) if args.table_rows == 13 else
                                       (alone_table or {}).get("ms_per_commitment") or round(iso_ms, 4),
