@@ -38,7 +38,7 @@ SYMBOLS = [
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev", "vmpc_fr_tail_scalars_block_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
     "vmpc_bn256_validate_dev", "vmpc_bn256_fixed_base_dev",
-    "vmpc_msm_table_fold_dev", "vmpc_msm_table_fold_table_dev", "vmpc_p4_create", "vmpc_p4_set_commit_table", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_run_compact", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev", "vmpc_bn256_table_msm_multi_dev",
+    "vmpc_msm_table_fold_dev", "vmpc_msm_table_fold_table_dev", "vmpc_p4_create", "vmpc_p4_create_opts", "vmpc_p4_prefold", "vmpc_p4_set_commit_table", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_run_compact", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev", "vmpc_bn256_table_msm_multi_dev",
     "vmpc_comm_unique_id", "vmpc_comm_create_rccl", "vmpc_comm_create_callback", "vmpc_comm_destroy", "vmpc_comm_info",
     "vmpc_comm_allgather_dev", "vmpc_comm_points_allsum_dev", "vmpc_p4_create_sharded", "vmpc_gather_probe_dev", "vmpc_bn256_madd_rate",
     "vmpc_stream_create", "vmpc_stream_destroy", "vmpc_ctx_set_bucket_stream",
@@ -145,6 +145,8 @@ def load_library():
         "vmpc_msm_table_fold_table_dev": (i32, [vp, vp, sz, sz, i32, sz, i32, vp, vp, sz, i32, vp]),
         "vmpc_p4_create": (i32, [vp, vp, sz, sz, i32, i32, i32, vp, vp, vp, ctypes.POINTER(vp)]),
         "vmpc_p4_set_commit_table": (i32, [vp, vp, i32]),
+        "vmpc_p4_create_opts": (i32, [vp, vp, sz, sz, i32, i32, i32, vp, vp, vp, i32, ctypes.POINTER(vp)]),
+        "vmpc_p4_prefold": (i32, [vp]),
         "vmpc_p4_round": (i32, [vp, vp, vp, vp]),
         "vmpc_p4_finish": (i32, [vp, vp, vp]),
         "vmpc_p4_run_compact": (i32, [vp, vp, i32, vp, vp]),
@@ -972,7 +974,8 @@ class Comm:
 class P4Rounds:
     """vmpc_p4_*: the Protocol-4 prover's rounds with z_hat, L~ and the challenge products resident in HBM."""
 
-    def __init__(self, ctx, table, h_slots, k_slot, z_ptr, l_ptr, n_total=None, comm=None, commit_table=None):
+    def __init__(self, ctx, table, h_slots, k_slot, z_ptr, l_ptr, n_total=None, comm=None, commit_table=None,
+                 jump_k=None):
         """comm (a Comm): `table` holds this rank's block of g_hat (vmpc_p4_create_sharded), z / L~ all N scalars.
         commit_table: a second table over the same generators and extras for the pairs of the rounds before the
         fold (the 13-row wide-window table, vmpc_p4_set_commit_table)"""
@@ -989,6 +992,11 @@ class P4Rounds:
                                                   len(table.extra_bytes), table.rows, k_slot, k_aff,
                                                   ctypes.c_void_p(z_ptr), ctypes.c_void_p(l_ptr), ctypes.byref(h)),
                    "vmpc_p4_create_sharded")
+        elif jump_k is not None:
+            _check(ctx.lib.vmpc_p4_create_opts(ctx.handle, ctypes.c_void_p(table.ptr), table.n, len(table.extra_bytes),
+                                               table.rows, h_slots, k_slot, k_aff, ctypes.c_void_p(z_ptr),
+                                               ctypes.c_void_p(l_ptr), int(jump_k), ctypes.byref(h)),
+                   "vmpc_p4_create_opts")
         else:
             _check(ctx.lib.vmpc_p4_create(ctx.handle, ctypes.c_void_p(table.ptr), table.n, len(table.extra_bytes),
                                           table.rows, h_slots, k_slot, k_aff, ctypes.c_void_p(z_ptr),
@@ -1004,6 +1012,10 @@ class P4Rounds:
         c = ctypes.create_string_buffer(scalar_to_bytes(prev_challenge), 32) if prev_challenge is not None else None
         _check(self.ctx.lib.vmpc_p4_round(self.handle, c, a, b), "vmpc_p4_round")
         return a.raw, b.raw
+
+    def prefold(self):
+        """a generator fold that is due (jump_k challenges fed): enqueue it now, wait for nothing (vmpc_p4_prefold)"""
+        _check(self.ctx.lib.vmpc_p4_prefold(self.handle), "vmpc_p4_prefold")
 
     def finish(self, last_challenge):
         z = ctypes.create_string_buffer(64)

@@ -61,7 +61,15 @@ EARLY_PAIR_FIRST = os.environ.get("VMPC_EARLY_PAIR_FIRST", "1") != "0"     # the
 # no longer waits for it AND the pair over the folded vector: 11.7 -> ~2.5 ms before round 1's hash, 6.8 -> 2.5 before
 # round 2's.  Below the threshold a pass over the full table (1.3 ms whatever the round) costs more than the short fold
 # + pair it replaces.  0: never.
-REF_TABLE_PAIR_MIN = int(os.environ.get("VMPC_REF_TABLE_PAIR_MIN", str(1 << 16)))
+REF_TABLE_PAIR_MIN = int(os.environ.get("VMPC_REF_TABLE_PAIR_MIN", "2"))
+# ... and ALL the way down (round 6, second step; the first one stopped at 2^17 elements): the context folds ITS generators
+# once, after REF_TABLE_JUMP_K challenges, in one pass over the table (csrc/fold_jump.hip; 2.9 ms into 2^15 columns,
+# twice that into 2^16) - asked for right after the round that feeds the last of them (vmpc_p4_prefold), so that it runs
+# on the GPU while the host hashes that round's text - and every later pair is a commitment over the folded table (the
+# fused short path, 0.25 ms) instead of an MSM over the exactly folded short vector (0.55 ms behind a 0.78-ms fold).
+# Measured (scripts/ref_stall_probe.py, time outside sha256.update): 44.7 / 41.1 / 40.0 / 41.7 ms at 3 / 4 / 5 / 6
+# challenges against 41.4 with the context closed at 2^17 elements.
+REF_TABLE_JUMP_K = int(os.environ.get("VMPC_REF_TABLE_JUMP_K", "5"))
 # (the context on a stream of its own, its pair BESIDE the fold's first slices: measured 450.5 against 444.4 ms - the fold's
 # kernels starve the pair pass, 5.6-6.5 ms before the next hash instead of 2.0 + 1.0 of waiting for text; off)
 REF_TABLE_PAIR_SIDE_STREAM = os.environ.get("VMPC_REF_TABLE_PAIR_SIDE", "0") != "0"
@@ -428,7 +436,7 @@ def _ref_table_rounds(g_hat, k, L_tilde, z_hat, transcript):
     """the round context for the reference-transcript prover's big rounds, or None (see REF_TABLE_PAIR_MIN)"""
     m = len(z_hat) if hasattr(z_hat, "__len__") else 0
     if not (REF_TABLE_PAIR_MIN and NATIVE_ROUNDS and transcript.mode == "reference" and isinstance(z_hat, ScalarVector)
-            and isinstance(L_tilde.coeffs, ScalarVector) and len(g_hat) == m and m >= 2 * REF_TABLE_PAIR_MIN
+            and isinstance(L_tilde.coeffs, ScalarVector) and len(g_hat) == m and m >= max(8, 2 * REF_TABLE_PAIR_MIN)
             and m & (m - 1) == 0 and L_tilde.constant == 0 and _tabulated(g_hat, k, whole=True)):
         return None
     from ._native import P4Rounds
@@ -441,7 +449,8 @@ def _ref_table_rounds(g_hat, k, L_tilde, z_hat, transcript):
     if side is not g_hat.ctx:
         side.wait_for(g_hat.ctx)                 # z_hat and L~ were produced on the main stream
     return P4Rounds(side, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, _coeffs_dev(L_tilde).ptr,
-                    n_total=m, commit_table=USE_WIDE_COMMIT_TABLE and getattr(g_hat, "_wide", None) or None)
+                    n_total=m, commit_table=USE_WIDE_COMMIT_TABLE and getattr(g_hat, "_wide", None) or None,
+                    jump_k=REF_TABLE_JUMP_K)
 
 
 def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, transcript, tail_cs, early):
@@ -450,6 +459,7 @@ def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, tra
     # reference transcript: the round context that supplies the big rounds' pairs (closed below the threshold, or with
     # this frame)
     table_rounds = _ref_table_rounds(g_hat, k, L_tilde, z_hat, transcript)
+    fed = 0                  # challenges the context has been given since its last fold
     if table_rounds is not None:
         a0, b0 = table_rounds.round(None)
         first = (Ed25519Point.from_affine_bytes(a0), Ed25519Point.from_affine_bytes(b0))
@@ -502,6 +512,7 @@ def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, tra
             pair_after_fold = False
             if table_rounds is not None:
                 if half >= 2 * REF_TABLE_PAIR_MIN:
+                    fed += 1
                     if table_rounds.ctx is not g_hat.ctx:
                         pair_after_fold = True          # (own stream: asked for right after the fold is enqueued)
                     else:
@@ -524,6 +535,10 @@ def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, tra
                 an, bn = table_rounds.round(c)
                 nxt = (Ed25519Point.from_affine_bytes(an), Ed25519Point.from_affine_bytes(bn))
                 early = lambda nxt=nxt: nxt                                      # noqa: E731
+            if table_rounds is not None and fed == REF_TABLE_JUMP_K:
+                # the context's one fold of its generators, behind the exact fold just enqueued, under the next hash
+                table_rounds.prefold()
+                fed = -(1 << 30)
             if ahead and not EARLY_PAIR_FIRST:
                 early = _early_pair_launch(unfolded, k, half, prep)
         if transcript.mode == "reference":

@@ -315,7 +315,7 @@ static int p4_next_jump(int jump_k, size_t jump_min, int direct_log2, bool fold_
 // z_hat, L_tilde: N = world * (table_n + h_slots) scalars each (device, canonical residues), N a power of two >= 4.
 static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t table_n, size_t table_extra, int rows,
                      int h_slots, int k_slot, const uint8_t k_affine[64], const void *z_hat, const void *L_tilde,
-                     vmpc_p4 **out) {
+                     vmpc_p4 **out, int jump_k_req = -1) {
     if (!ctx || !table || !z_hat || !L_tilde || !out || !k_affine || h_slots < 0 || k_slot < h_slots ||
         (size_t)k_slot >= table_extra || !(rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16))
         return VMPC_E_INVAL;       // (rows = 13, the wide-window table, serves commitments only)
@@ -340,6 +340,7 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     p->round = p->committed = p->cur = p->log2_n = 0;
     p->jump_k = 5;                               // VMPC_P4_JUMP=0 keeps every round on the unfolded CRS
     if (const char *e = getenv("VMPC_P4_JUMP")) p->jump_k = atoi(e);
+    if (jump_k_req >= 0) p->jump_k = jump_k_req;             // (vmpc_p4_create_opts)
     if (p->jump_k < 0 || p->jump_k > 6) p->jump_k = 0;
     p->jump_min = (size_t)1 << 18;
     if (const char *e = getenv("VMPC_P4_JUMP_MIN_LOG2")) p->jump_min = (size_t)1 << atoi(e);
@@ -454,6 +455,28 @@ extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, 
                               int h_slots, int k_slot, const uint8_t k_affine[64], const void *z_hat,
                               const void *L_tilde, vmpc_p4 **out) {
     return p4_create(ctx, nullptr, table, table_n, table_extra, rows, h_slots, k_slot, k_affine, z_hat, L_tilde, out);
+}
+
+// The same with the number of rounds before the generator fold chosen by the caller (0: never; < 0: the default), and
+// vmpc_p4_prefold: make a fold that is due NOW - enqueued on the context's stream, nothing waited for - instead of at
+// the start of the next vmpc_p4_round.  For a caller with time between two rounds: the reference-transcript prover
+// hashes tens of megabytes of text on the host while the GPU is idle (compressed_pivot.py:51-59).
+extern "C" int vmpc_p4_create_opts(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
+                                   int h_slots, int k_slot, const uint8_t k_affine[64], const void *z_hat,
+                                   const void *L_tilde, int jump_k, vmpc_p4 **out) {
+    return p4_create(ctx, nullptr, table, table_n, table_extra, rows, h_slots, k_slot, k_affine, z_hat, L_tilde, out,
+                     jump_k);
+}
+
+static bool p4_jump_due(const vmpc_p4 *p);
+static int p4_jump(vmpc_p4 *p);
+extern "C" int vmpc_p4_prefold(vmpc_p4 *p) {
+    if (!p || p->poisoned) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
+    if (!p4_jump_due(p)) return VMPC_OK;
+    const int rc = p4_jump(p);
+    if (rc != VMPC_OK) p->poisoned = true;
+    return rc;
 }
 
 extern "C" int vmpc_p4_create_sharded(vmpc_ctx *ctx, vmpc_comm *comm, const void *block_table, size_t block_n,
