@@ -70,9 +70,12 @@ REF_TABLE_PAIR_MIN = int(os.environ.get("VMPC_REF_TABLE_PAIR_MIN", "2"))
 # Measured (scripts/ref_stall_probe.py, time outside sha256.update): 44.7 / 41.1 / 40.0 / 41.7 ms at 3 / 4 / 5 / 6
 # challenges against 41.4 with the context closed at 2^17 elements.
 REF_TABLE_JUMP_K = int(os.environ.get("VMPC_REF_TABLE_JUMP_K", "5"))
-# (the context on a stream of its own, its pair BESIDE the fold's first slices: measured 450.5 against 444.4 ms - the fold's
-# kernels starve the pair pass, 5.6-6.5 ms before the next hash instead of 2.0 + 1.0 of waiting for text; off)
-REF_TABLE_PAIR_SIDE_STREAM = os.environ.get("VMPC_REF_TABLE_PAIR_SIDE", "0") != "0"
+# the context on a stream of its own: a round's pair is asked for right after the FIRST slice of the round's exact fold
+# (a short one, device.PointVector.fold after_first) is enqueued on the main stream and runs beside it; the other
+# slices follow the pair.  Small rounds: 0.57 ms of gap + 0.48 of waiting for text instead of 0.42 + 0.83; big rounds
+# 3.0 + 0.05 instead of 2.0 + 1.1; 34.3 against 38.0 ms outside the hash (profiles/r06_ref_pair_side.txt).  (With ALL
+# the fold's slices enqueued ahead of the pair it lost, 450.5 against 444.4 ms: the fold's kernels starve the pair.)
+REF_TABLE_PAIR_SIDE_STREAM = os.environ.get("VMPC_REF_TABLE_PAIR_SIDE", "1") != "0"
 
 
 # ---- group glue on single elements (independent of the is_additive/is_multiplicative flags) ----
@@ -442,9 +445,9 @@ def _ref_table_rounds(g_hat, k, L_tilde, z_hat, transcript):
     from ._native import P4Rounds
     from .device import get_aux_context
     table = g_hat._table
-    # on a stream of its own: a round's pair then runs BESIDE the first slices of the exact fold that is enqueued on the
-    # main stream just before it (a 2^16-element slice is a 1-ms ladder on a quarter of the chip's lanes) instead of in
-    # front of them - the pair is back after ~1.7 ms and the fold's first text has landed by then
+    # on a stream of its own: a round's pair then runs BESIDE the first slice of the exact fold that is enqueued on the
+    # main stream just before it (a 2^14-element slice is a 1-ms ladder on a sixteenth of the chip's lanes) instead of in
+    # front of it, and the fold's first text has landed by the time the pair is back
     side = get_aux_context(7) if REF_TABLE_PAIR_SIDE_STREAM else g_hat.ctx
     if side is not g_hat.ctx:
         side.wait_for(g_hat.ctx)                 # z_hat and L~ were produced on the main stream
@@ -530,10 +533,12 @@ def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, tra
                 # 8.6 ms the four commitments took ~40 ms to come back (EXPERIMENTS R5.9); ahead of it they take ~2 ms,
                 # and the fold's first slice of text follows ~1 ms later
                 early = _early_pair_launch(unfolded, k, half, prep, then=g_hat.ctx)
-            g_hat = g_l.fold(g_r, c, stream_text=transcript.mode == "reference")
-            if pair_after_fold:
-                an, bn = table_rounds.round(c)
-                nxt = (Ed25519Point.from_affine_bytes(an), Ed25519Point.from_affine_bytes(bn))
+            got = []
+            g_hat = g_l.fold(g_r, c, stream_text=transcript.mode == "reference",
+                             after_first=(lambda: got.append(table_rounds.round(c))) if pair_after_fold else None)
+            if got:
+                # (own stream: the pair ran beside the exact fold's FIRST slice; the other slices were enqueued after it)
+                nxt = (Ed25519Point.from_affine_bytes(got[0][0]), Ed25519Point.from_affine_bytes(got[0][1]))
                 early = lambda nxt=nxt: nxt                                      # noqa: E731
             if table_rounds is not None and fed == REF_TABLE_JUMP_K:
                 # the context's one fold of its generators, behind the exact fold just enqueued, under the next hash

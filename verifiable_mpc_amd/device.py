@@ -455,12 +455,14 @@ class PointVector:
 
     TEXT_SLICE = 1 << 16     # fold(stream_text=True): elements folded, formatted and sent to the host at a time
 
-    def fold(self, other, c, keep_proj=None, stream_text=False):
+    def fold(self, other, c, keep_proj=None, stream_text=False, after_first=None):
         """[(self[i] ** c) * other[i]] (compressed_pivot.py:64/:178), csrc/exact.hip k_fold.
         stream_text: the result's transcript text is wanted next (the reference transcript hashes the folded
         generators every round, compressed_pivot.py:52): a long vector is folded slice by slice, each slice formatted
         and copied on the side stream as soon as it exists, so the host hashes the first slices while the rest is
-        still being folded (an exact 2^19-element fold is 8.6 ms; hashing its 123 MB of text takes 50)."""
+        still being folded (an exact 2^19-element fold is 8.6 ms; hashing its 123 MB of text takes 50).
+        after_first: called once the first slice (the whole fold, if it is not sliced) and its text are enqueued -
+        the caller's own work on ANOTHER stream that should run beside that slice and ahead of the rest."""
         assert len(self) == len(other)
         half = len(self)
         if keep_proj is None:
@@ -475,14 +477,23 @@ class PointVector:
             self.ctx.fold(lp, rp, not use_proj, reduce_scalar(c), half, pbuf.ptr if pbuf else None, abuf.ptr)
             if stream_text:
                 out.text_begin()
+            if after_first is not None:
+                after_first()
             return out
         side, pieces = get_aux_context(2), []
-        for a in range(0, half, self.TEXT_SLICE):
-            cnt = min(self.TEXT_SLICE, half - a)
+        # (with a co-runner the first slice is a short one: fewer lanes taken from the work beside it, and its text
+        # is on the host sooner)
+        first = int(os.environ.get("VMPC_FOLD_FIRST_SLICE", str(self.TEXT_SLICE // 4))) if after_first is not None \
+            else self.TEXT_SLICE
+        cuts = [0] + list(range(first, half, self.TEXT_SLICE))
+        for a, b in zip(cuts, cuts[1:] + [half]):
+            cnt = b - a
             self.ctx.fold(lp + stride * a, rp + stride * a, not use_proj, reduce_scalar(c), cnt, pbuf.ptr + 96 * a,
                           abuf.ptr + 64 * a)
             side.wait_for(self.ctx)
             pieces.append(side.format_begin("points", pbuf.ptr + 96 * a, cnt, keepalive=pbuf, own_signal=True))
+            if a == 0 and after_first is not None:
+                after_first()
         out._pending_text = (formats.point_style(), _native.TextSequence(pieces))
         return out
 
