@@ -404,7 +404,8 @@ int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, size_t tabl
                    int k_slot, const uint8_t k_affine[64], const void *z_hat, const void *L_tilde, vmpc_p4 **out);
 /* vmpc_p4_create with the number of rounds before the generators are folded chosen by the caller (jump_k = 0: never,
  * < 0: the default of 5), and vmpc_p4_prefold: make a fold that is due - jump_k challenges have been fed - NOW, enqueued
- * on the context's stream without waiting, instead of at the start of the next vmpc_p4_round. */
+ * on the context's stream without waiting, instead of at the start of the next vmpc_p4_round (not between
+ * vmpc_p4_round_begin and _end). */
 int vmpc_p4_create_opts(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows, int h_slots,
                         int k_slot, const uint8_t k_affine[64], const void *z_hat, const void *L_tilde, int jump_k,
                         vmpc_p4 **out);
@@ -429,6 +430,12 @@ int vmpc_p4_create_sharded(vmpc_ctx *ctx, vmpc_comm *comm, const void *block_tab
  * Valid log2(N) - 1 times.  If a call fails after the witness fold was enqueued the context is unusable: every
  * further call returns VMPC_E_INVAL, destroy it (vmpc_ctx_destroy refuses while a round context is alive). */
 int vmpc_p4_round(vmpc_p4 *p4, const uint8_t prev_challenge[32], uint8_t out_A[64], uint8_t out_B[64]);
+/* vmpc_p4_round in two halves, for a caller with host work of its own to do while the pair is computed (the reference
+ * transcript's prover enqueues the round's exact generator fold on another stream meanwhile): _begin folds the witness
+ * with prev_challenge and enqueues the commitments without waiting, _end waits and returns A_i, B_i.  Until _end every
+ * other vmpc_p4_* call on this context except vmpc_p4_destroy returns VMPC_E_INVAL. */
+int vmpc_p4_round_begin(vmpc_p4 *p4, const uint8_t prev_challenge[32]);
+int vmpc_p4_round_end(vmpc_p4 *p4, uint8_t out_A[64], uint8_t out_B[64]);
 /* after the last round: fold with its challenge and return z' (two 32-byte residues, compressed_pivot.py:77-79) */
 int vmpc_p4_finish(vmpc_p4 *p4, const uint8_t last_challenge[32], uint8_t out_z_prime[64]);
 /* every round and the finish behind one call, with the COMPACT transcript's challenge chain (verifiable_mpc_amd/

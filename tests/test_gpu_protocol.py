@@ -183,7 +183,7 @@ def test_hash_input_dump_is_what_gets_hashed(vm, golden_small, monkeypatch):
     assert records[n_prover + 1].startswith("Method protocol_4_verifier:")
 
 
-@pytest.mark.parametrize("early_pair", [False, True, "table_rounds", "table_rounds_wide"])
+@pytest.mark.parametrize("early_pair", [False, True, "table_rounds", "table_rounds_wide", "table_rounds_main_stream"])
 def test_protocol5_n1023_device_mode(vm, golden_n1023, monkeypatch, record_hashes, early_pair):
     """N = 1024 in device mode against the reference-made fixture; also with the next round's pair committed over the
     unfolded vector beside the fold (compressed_pivot._early_pair_*, an experiment that is off by default), and with
@@ -196,14 +196,15 @@ def test_protocol5_n1023_device_mode(vm, golden_n1023, monkeypatch, record_hashe
     if isinstance(early_pair, str):
         monkeypatch.setattr(vm.compressed_pivot, "REF_TABLE_PAIR_MIN", 16)
         monkeypatch.setenv("VMPC_P4_COMMIT_TABLE_MIN_LOG2", "0")
+        # (the context on a stream of its own - round_begin / round_end beside the exact fold - or on the main one)
+        monkeypatch.setattr(vm.compressed_pivot, "REF_TABLE_PAIR_SIDE_STREAM", not early_pair.endswith("main_stream"))
         gens["g"].precompute([gens["h"], gens["k"]], wide=early_pair.endswith("wide"))
         made = []
-        orig = vm._native.P4Rounds.round
-
-        def spy(self, c=None):
-            made.append(c)
-            return orig(self, c)
-        monkeypatch.setattr(vm._native.P4Rounds, "round", spy)
+        for name in ("round", "round_begin"):
+            def spy(self, c=None, orig=getattr(vm._native.P4Rounds, name)):
+                made.append(c)
+                return orig(self, c)
+            monkeypatch.setattr(vm._native.P4Rounds, name, spy)
     gf = vm.GF(group.order)
     x = vm.ScalarVector.from_ints([h2i(v) for v in case["x"]])
     L = vm.pivot.LinearForm(vm.ScalarVector.from_ints([h2i(v) for v in case["L"]]))
@@ -649,6 +650,41 @@ def test_two_round_contexts_on_one_vmpc_ctx(vm):
     a.close()
     assert got1 == want1 and got2 == want2 and want1 != want2
     assert alone(z1) == want1
+
+
+def test_native_round_in_two_halves(vm):
+    """vmpc_p4_round_begin + vmpc_p4_round_end = vmpc_p4_round; between the halves the context refuses every other
+    call (and a fold of its generators that is due: vmpc_p4_prefold)"""
+    ctx = vm.get_context()
+    group = vm.EllipticCurve("Ed25519", "projective")
+    h = group.generator
+    k = vm.Ed25519Point.repeat(h, 4242)
+    g = vm.PointVector.fixed_base(h, list(range(3, 34)))           # 31 generators + h = 32
+    g.precompute([h, k])
+    z = vm.ScalarVector.from_ints(list(range(1, 33)))
+    L = vm.ScalarVector.from_ints(list(range(7, 39)))
+    whole = vm._native.P4Rounds(ctx, g._table, 1, 1, z.ptr, L.ptr)
+    want = [whole.round(None), whole.round(11), whole.round(12), whole.round(13), whole.finish(14)]
+    whole.close()
+    r = vm._native.P4Rounds(ctx, g._table, 1, 1, z.ptr, L.ptr)
+    with pytest.raises(vm._native.VmpcError):
+        r.round_end()                                  # nothing in flight
+    got = []
+    for i, c in enumerate((None, 11, 12, 13)):
+        r.round_begin(c)
+        for bad in (lambda: r.round_begin(5), lambda: r.round(5), r.prefold, lambda: r.finish(14)):
+            with pytest.raises(vm._native.VmpcError):
+                bad()
+        got.append(r.round_end())
+        r.prefold()                                    # (nothing due on a 32-element vector: a no-op)
+    got.append(r.finish(14))
+    r.close()
+    assert got == want
+    # a context destroyed with a round in flight
+    r = vm._native.P4Rounds(ctx, g._table, 1, 1, z.ptr, L.ptr)
+    r.round_begin(None)
+    r.close()
+    ctx.sync()
 
 
 def test_native_round_context_argument_checks(vm):

@@ -38,7 +38,7 @@ SYMBOLS = [
     "vmpc_sha256_chunks_dev", "vmpc_fr_challenge_products_dev", "vmpc_fr_tail_scalars_dev", "vmpc_fr_tail_scalars_inc_dev", "vmpc_fr_tail_scalars_block_dev",
     "vmpc_bn256_g1_msm", "vmpc_bn256_g2_msm", "vmpc_bn256_g1_msm_dev", "vmpc_bn256_g2_msm_dev",
     "vmpc_bn256_validate_dev", "vmpc_bn256_fixed_base_dev",
-    "vmpc_msm_table_fold_dev", "vmpc_msm_table_fold_table_dev", "vmpc_p4_create", "vmpc_p4_create_opts", "vmpc_p4_prefold", "vmpc_p4_set_commit_table", "vmpc_p4_round", "vmpc_p4_finish", "vmpc_p4_run_compact", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev", "vmpc_bn256_table_msm_multi_dev",
+    "vmpc_msm_table_fold_dev", "vmpc_msm_table_fold_table_dev", "vmpc_p4_create", "vmpc_p4_create_opts", "vmpc_p4_prefold", "vmpc_p4_set_commit_table", "vmpc_p4_round", "vmpc_p4_round_begin", "vmpc_p4_round_end", "vmpc_p4_finish", "vmpc_p4_run_compact", "vmpc_p4_destroy", "vmpc_bn256_table_bytes", "vmpc_bn256_table_build_dev", "vmpc_bn256_table_msm_dev", "vmpc_bn256_table_msm_multi_dev",
     "vmpc_comm_unique_id", "vmpc_comm_create_rccl", "vmpc_comm_create_callback", "vmpc_comm_destroy", "vmpc_comm_info",
     "vmpc_comm_allgather_dev", "vmpc_comm_points_allsum_dev", "vmpc_p4_create_sharded", "vmpc_gather_probe_dev", "vmpc_bn256_madd_rate",
     "vmpc_stream_create", "vmpc_stream_destroy", "vmpc_ctx_set_bucket_stream",
@@ -148,6 +148,8 @@ def load_library():
         "vmpc_p4_create_opts": (i32, [vp, vp, sz, sz, i32, i32, i32, vp, vp, vp, i32, ctypes.POINTER(vp)]),
         "vmpc_p4_prefold": (i32, [vp]),
         "vmpc_p4_round": (i32, [vp, vp, vp, vp]),
+        "vmpc_p4_round_begin": (i32, [vp, vp]),
+        "vmpc_p4_round_end": (i32, [vp, vp, vp]),
         "vmpc_p4_finish": (i32, [vp, vp, vp]),
         "vmpc_p4_run_compact": (i32, [vp, vp, i32, vp, vp]),
         "vmpc_p4_destroy": (i32, [vp]),
@@ -1011,6 +1013,16 @@ class P4Rounds:
         a, b = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
         c = ctypes.create_string_buffer(scalar_to_bytes(prev_challenge), 32) if prev_challenge is not None else None
         _check(self.ctx.lib.vmpc_p4_round(self.handle, c, a, b), "vmpc_p4_round")
+        return a.raw, b.raw
+
+    def round_begin(self, prev_challenge=None):
+        """round() without the wait: the pair is enqueued on the context's stream; round_end() collects it"""
+        c = ctypes.create_string_buffer(scalar_to_bytes(prev_challenge), 32) if prev_challenge is not None else None
+        _check(self.ctx.lib.vmpc_p4_round_begin(self.handle, c), "vmpc_p4_round_begin")
+
+    def round_end(self):
+        a, b = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+        _check(self.ctx.lib.vmpc_p4_round_end(self.handle, a, b), "vmpc_p4_round_end")
         return a.raw, b.raw
 
     def prefold(self):

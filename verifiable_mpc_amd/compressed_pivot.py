@@ -283,11 +283,14 @@ def _tabulated(g_hat, k, whole=False):
     return slot is not None and slot >= g_hat._table_tail
 
 
-def _round_prover_scalars(L_tilde, z_hat, half, gf):
-    """Exponents of k in A_i, B_i and the split witness (compressed_pivot.py:35-42)."""
+def _round_prover_scalars(L_tilde, z_hat, half, gf, exponents=True):
+    """Exponents of k in A_i, B_i and the split witness (compressed_pivot.py:35-42).
+    exponents=False: the split only (the round's A_i, B_i are on their way already)."""
     if _on_device(L_tilde.coeffs, z_hat):
         Lc, z = _coeffs_dev(L_tilde), pivot._as_device(z_hat)
         z_l, z_r = z[:half], z[half:]
+        if not exponents:
+            return z_l, z_r, None, None
         # the two inner products stay on the device: they are only ever exponents of k in A_i, B_i
         gamma_a = Lc[half:].dot_dev(z_l)       # L~(0 || z_l)
         gamma_b = Lc[:half].dot_dev(z_r)       # L~(z_r || 0)
@@ -476,7 +479,7 @@ def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, tra
                 and isinstance(L_tilde.coeffs, ScalarVector) and len(g_hat) == m and m >= 4 and m & (m - 1) == 0 \
                 and _tabulated(g_hat, k, whole=True):
             return _protocol_4_native_rounds(g_hat, k, L_tilde, z_hat, gf, proof, round_i, transcript)
-        z_l, z_r, gamma_a, gamma_b = _round_prover_scalars(L_tilde, z_hat, half, gf)
+        z_l, z_r, gamma_a, gamma_b = _round_prover_scalars(L_tilde, z_hat, half, gf, exponents=early is None)
         logger_cp.debug("Calculate A_i, B_i.")
         if tail_cs is None and transcript.mode == "compact" and isinstance(z_l, ScalarVector) \
                 and len(g_hat) == m and m >= 4 and (len(g_hat) <= TAIL_BASE or _tabulated(g_hat, k)):
@@ -533,17 +536,29 @@ def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, tra
                 # 8.6 ms the four commitments took ~40 ms to come back (EXPERIMENTS R5.9); ahead of it they take ~2 ms,
                 # and the fold's first slice of text follows ~1 ms later
                 early = _early_pair_launch(unfolded, k, half, prep, then=g_hat.ctx)
-            got = []
-            g_hat = g_l.fold(g_r, c, stream_text=transcript.mode == "reference",
-                             after_first=(lambda: got.append(table_rounds.round(c))) if pair_after_fold else None)
-            if got:
-                # (own stream: the pair ran beside the exact fold's FIRST slice; the other slices were enqueued after it)
-                nxt = (Ed25519Point.from_affine_bytes(got[0][0]), Ed25519Point.from_affine_bytes(got[0][1]))
-                early = lambda nxt=nxt: nxt                                      # noqa: E731
-            if table_rounds is not None and fed == REF_TABLE_JUMP_K:
+            fold_due = table_rounds is not None and fed == REF_TABLE_JUMP_K
+            if fold_due:
+                fed = -(1 << 30)
+            hook = None
+            if pair_after_fold:
+                # own stream: the pair is ENQUEUED right after the exact fold's first slice (it runs beside it; the
+                # other slices are ordered behind it) and collected when the next round asks for it - the host work
+                # in between (the rest of the fold's launches, Q, L~'s text) no longer waits for the pair
+                def hook(more, rounds=table_rounds, main=g_hat.ctx):
+                    rounds.round_begin(c)
+                    if more:
+                        main.wait_for(rounds.ctx)
+
+                def early(rounds=table_rounds, fold_due=fold_due):
+                    an, bn = rounds.round_end()
+                    if fold_due:
+                        # the context's one fold of its generators, behind the pair, under the next hash
+                        rounds.prefold()
+                    return Ed25519Point.from_affine_bytes(an), Ed25519Point.from_affine_bytes(bn)
+            g_hat = g_l.fold(g_r, c, stream_text=transcript.mode == "reference", after_first=hook)
+            if fold_due and not pair_after_fold:
                 # the context's one fold of its generators, behind the exact fold just enqueued, under the next hash
                 table_rounds.prefold()
-                fed = -(1 << 30)
             if ahead and not EARLY_PAIR_FIRST:
                 early = _early_pair_launch(unfolded, k, half, prep)
         if transcript.mode == "reference":

@@ -254,6 +254,7 @@ struct vmpc_p4 {
     size_t block_lo, block_n;
     char *mine, *gathered;            // 2 partial points of this rank; world x 2 gathered ones
     bool poisoned;                    // a call failed after the fold state advanced: only destroy is valid
+    bool in_flight;                   // vmpc_p4_round_begin without its vmpc_p4_round_end yet
     const void *table0;               // the caller's table (the unfolded CRS / block)
     // a second table over the SAME generators and extras for the pair commitments of the rounds before the fold
     // (vmpc_p4_set_commit_table: the 13-row wide-window table - 13 mixed additions per term instead of 16); the fold
@@ -336,6 +337,7 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     p->commit_min_cols = 0;
     p->arena_pooled = false;
     p->poisoned = false;
+    p->in_flight = false;
     p->dots_grid = 0;
     p->round = p->committed = p->cur = p->log2_n = 0;
     p->jump_k = 5;                               // VMPC_P4_JUMP=0 keeps every round on the unfolded CRS
@@ -471,7 +473,9 @@ extern "C" int vmpc_p4_create_opts(vmpc_ctx *ctx, const void *table, size_t tabl
 static bool p4_jump_due(const vmpc_p4 *p);
 static int p4_jump(vmpc_p4 *p);
 extern "C" int vmpc_p4_prefold(vmpc_p4 *p) {
-    if (!p || p->poisoned) return VMPC_E_INVAL;
+    // (not while a round is in flight: staging the fold's schedule may re-allocate the pinned block that round's
+    // result is written to)
+    if (!p || p->poisoned || p->in_flight) return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
     if (!p4_jump_due(p)) return VMPC_OK;
     const int rc = p4_jump(p);
@@ -720,9 +724,8 @@ static int p4_round_enqueue(vmpc_p4 *p, const uint32_t *c_mem) {
     return VMPC_OK;
 }
 
-static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
+static int p4_round_collect(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
     vmpc_ctx *ctx = p->ctx;
-    VMPC_CHECK(p4_round_enqueue(p, nullptr));
     const uint8_t *ext = (const uint8_t *)ctx->pin_out;
     // The first round's synchronisation also fetches the device status words (a non-canonical scalar in the caller's
     // z_hat / L~ shows up in this round's recoding); later rounds only consume scalars this context produced, so
@@ -734,13 +737,18 @@ static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
     return VMPC_OK;
 }
 
+static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
+    VMPC_CHECK(p4_round_enqueue(p, nullptr));
+    return p4_round_collect(p, out_A, out_B);
+}
+
 // One round: prev_challenge = the challenge derived from the PREVIOUS call's A, B (NULL on the first call).
 // Returns A_i, B_i as 64-byte affine points.  Synchronises the context's stream (the results are needed
 // for the next hash).  A failure after the fold has advanced the state leaves the context unusable (every
 // further call returns VMPC_E_INVAL; destroy it).
 extern "C" int vmpc_p4_round(vmpc_p4 *p, const uint8_t prev_challenge[32], uint8_t out_A[64], uint8_t out_B[64]) {
     // the first call has no challenge yet, every later one needs the previous round's; log2(N) - 1 rounds in all
-    if (!p || p->poisoned || !out_A || !out_B || (p->committed == 0) != (prev_challenge == nullptr) ||
+    if (!p || p->poisoned || p->in_flight || !out_A || !out_B || (p->committed == 0) != (prev_challenge == nullptr) ||
         (prev_challenge && p->m / 2 < 4))
         return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
@@ -751,9 +759,34 @@ extern "C" int vmpc_p4_round(vmpc_p4 *p, const uint8_t prev_challenge[32], uint8
     return rc;
 }
 
+// vmpc_p4_round in two halves: _begin enqueues the round on the context's stream and returns at once, _end waits for
+// it and hands back A_i, B_i.  Between the two the context's stream (and its pinned result block) must be left alone:
+// every other vmpc_p4_* call on this context returns VMPC_E_INVAL until _end has been called.
+extern "C" int vmpc_p4_round_begin(vmpc_p4 *p, const uint8_t prev_challenge[32]) {
+    if (!p || p->poisoned || p->in_flight || (p->committed == 0) != (prev_challenge == nullptr) ||
+        (prev_challenge && p->m / 2 < 4))
+        return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
+    VMPC_CHECK(p4_fold_dots(p, prev_challenge));
+    const int rc = p4_round_enqueue(p, nullptr);
+    if (rc != VMPC_OK) p->poisoned = true;
+    else p->in_flight = true;
+    return rc;
+}
+
+extern "C" int vmpc_p4_round_end(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
+    if (!p || p->poisoned || !p->in_flight || !out_A || !out_B) return VMPC_E_INVAL;
+    VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
+    p->in_flight = false;
+    const int rc = p4_round_collect(p, out_A, out_B);
+    if (rc != VMPC_OK) p->poisoned = true;
+    return rc;
+}
+
 // After the last round's challenge: fold once more and hand back z' (2 x 32 bytes, compressed_pivot.py:77-79).
 extern "C" int vmpc_p4_finish(vmpc_p4 *p, const uint8_t last_challenge[32], uint8_t out_z_prime[64]) {
-    if (!p || p->poisoned || !last_challenge || !out_z_prime || p->m != 4 || p->committed != p->total_rounds)
+    if (!p || p->poisoned || p->in_flight || !last_challenge || !out_z_prime || p->m != 4 ||
+        p->committed != p->total_rounds)
         return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
     VMPC_CHECK(p4_fold_dots(p, last_challenge));
@@ -913,7 +946,8 @@ static bool p4_can_queue_ahead(vmpc_p4 *p) {
 // (A_i || B_i) = 128 bytes each; out_z_prime: the two final residues.  The context must be fresh.
 extern "C" int vmpc_p4_run_compact(vmpc_p4 *p, uint8_t state[32], int first_round_index, uint8_t *out_AB,
                                    uint8_t out_z_prime[64]) {
-    if (!p || !state || !out_AB || !out_z_prime || p->committed != 0 || first_round_index < 0) return VMPC_E_INVAL;
+    if (!p || !state || !out_AB || !out_z_prime || p->committed != 0 || p->in_flight || first_round_index < 0)
+        return VMPC_E_INVAL;
     uint8_t challenge[32];
     const int rounds = p->total_rounds;
     if (!p4_can_queue_ahead(p)) {

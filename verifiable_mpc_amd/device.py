@@ -461,8 +461,9 @@ class PointVector:
         generators every round, compressed_pivot.py:52): a long vector is folded slice by slice, each slice formatted
         and copied on the side stream as soon as it exists, so the host hashes the first slices while the rest is
         still being folded (an exact 2^19-element fold is 8.6 ms; hashing its 123 MB of text takes 50).
-        after_first: called once the first slice (the whole fold, if it is not sliced) and its text are enqueued -
-        the caller's own work on ANOTHER stream that should run beside that slice and ahead of the rest."""
+        after_first(more): called once the first slice (the whole fold, if it is not sliced) and its text are
+        enqueued - the caller's own work on ANOTHER stream that should run beside that slice and ahead of the rest;
+        more: further slices will be enqueued on this vector's stream after the call returns."""
         assert len(self) == len(other)
         half = len(self)
         if keep_proj is None:
@@ -478,7 +479,7 @@ class PointVector:
             if stream_text:
                 out.text_begin()
             if after_first is not None:
-                after_first()
+                after_first(False)
             return out
         side, pieces = get_aux_context(2), []
         # (with a co-runner the first slice is a short one: fewer lanes taken from the work beside it, and its text
@@ -493,7 +494,7 @@ class PointVector:
             side.wait_for(self.ctx)
             pieces.append(side.format_begin("points", pbuf.ptr + 96 * a, cnt, keepalive=pbuf, own_signal=True))
             if a == 0 and after_first is not None:
-                after_first()
+                after_first(True)
         out._pending_text = (formats.point_style(), _native.TextSequence(pieces))
         return out
 
