@@ -318,6 +318,51 @@ def test_fold_replays_reference_sequence(nat, ctx):
     assert dl_proj(ctx, op.ptr, half) == ac.fold_generators(gla, gra, c)
 
 
+@pytest.mark.parametrize("half", [1, 15, 16, 17, 50])
+def test_fold_two_wave_ladder_bit_lengths(nat, ctx, half):
+    """the short-vector fold (csrc/exact.hip k_fold_pipe: the doubling chain and the additions on two waves, batches of
+    8 bits through LDS): scalars whose bit lengths sit on and around the batch boundaries, all-ones and single-bit
+    scalars, against the oracle's replay of compressed_pivot.py:64 - exact (X, Y, Z)"""
+    rng = random.Random(1200 + half)
+    gl = ac.create_generators([rng.randrange(1, ELL) for _ in range(half)])["g"]
+    gr = ac.create_generators([rng.randrange(1, ELL) for _ in range(half)])["g"]
+    dl_, dr_ = ctx.upload(proj_bytes(gl)), ctx.upload(proj_bytes(gr))
+    cs = [0, 1, 2, 3, 0x7f, 0x80, 0xff, 0x100, 0x101, 0xffff, 0x10000, (1 << 64) - 1, 1 << 64, 1 << 251, 1 << 252,
+          (1 << 252) - 1, ELL - 1, ELL - 2, rng.randrange(ELL), rng.randrange(1 << 129)]
+    for c in cs:
+        op, oa = ctx.alloc(96 * half), ctx.alloc(64 * half)
+        ctx.fold(dl_.ptr, dr_.ptr, False, c, half, op.ptr, oa.ptr)
+        ctx.sync()
+        want = ac.fold_generators(gl, gr, c)
+        assert dl_proj(ctx, op.ptr, half) == want, hex(c)
+        assert [a[:2] for a in dl_aff(ctx, oa.ptr, half)] == [ed.pt_affine(w) for w in want], hex(c)
+
+
+def test_fold_every_kernel_agrees_with_the_oracle(nat, ctx):
+    """one vector length per fold kernel (two-wave ladder <= 2^13 < quad <= 2^14 < one lane per element) against the
+    threaded C oracle's replay (oracle/ed25519_oracle.c oracle_fold), exact (X, Y, Z)"""
+    import numpy as np
+    from oracle import c_oracle
+    rng = np.random.default_rng(77)
+    c_oracle.set_threads(c_oracle.host_threads())
+    try:
+        for half in (8192, 8193, 16384, 16400):
+            ex = rng.integers(0, 256, size=(2 * half, 32), dtype=np.uint8)
+            ex[:, 31] &= 0x0F
+            base = np.frombuffer(proj_bytes([ed.BASE]), np.uint8)
+            proj, _ = c_oracle.fixed_base(base, ex)
+            pts = c_oracle.PointArray(proj)
+            c = int.from_bytes(rng.integers(0, 256, size=32, dtype=np.uint8).tobytes(), "little") % ELL
+            want = pts[:half].fold(pts[half:], c)
+            d = ctx.upload(proj.tobytes())
+            op = ctx.alloc(96 * half)
+            ctx.fold(d.ptr, d.ptr + 96 * half, False, c, half, op.ptr, None)
+            ctx.sync()
+            assert ctx.download(op.ptr, 96 * half).tobytes() == want.a.tobytes(), half
+    finally:
+        c_oracle.set_threads(1)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 13, 64, 65])
 def test_tree_reduce_order(nat, ctx, n):
     """pivot.list_mul (pivot.py:26-28): same tree shape => same projective representative."""

@@ -84,7 +84,7 @@ k_fold(const uint32_t *__restrict__ gl, const uint32_t *__restrict__ gr, int in_
 // Below ~2^16 elements the one-lane-per-element fold leaves the chip idle and costs the full
 // ~3300-multiplication dependency chain (2.1 ms).  Here four lanes share an element and run
 // the SAME formulas level by level (dbl-2008-bbjlp: 4 squarings | 3 products; add-2008-bbjlp:
-// 4 | 2 | 1 | 3 | 2), so the chain is ~1100 multiplications long.  Field arithmetic is exact
+// 4 | 4 | 1 | 3), so the chain is ~1000 multiplications long.  Field arithmetic is exact
 // and commutative/associative, so the (X:Y:Z) produced are bit-identical to k_fold's.
 __device__ __forceinline__ void quad_proj_dbl(ge_proj &p, int q) {
     fe in = fe_pick4(p.X, p.Y, p.Z, fe_add(p.X, p.Y), q);
@@ -101,29 +101,25 @@ __device__ __forceinline__ void quad_proj_dbl(ge_proj &p, int q) {
     p.Z = quad_bcast(prod, 2);
 }
 
+// add-2008-bbjlp in FOUR levels (4 | 4 | 1 | 3 products; the formula's own order has five: 4 | 2 | 1 | 3 | 2): A times
+// the two brackets of X3, Y3 moves up to the level of B = A^2 and C D.  Products are exact mod p, so the residues -
+// and the canonical limbs that are stored - do not depend on that order.
 __device__ __forceinline__ ge_proj quad_proj_add(const ge_proj &p, const ge_proj &r, int q) {
     // level 1: A = Z1 Z2, C = X1 X2, D = Y1 Y2, S = (X1+Y1)(X2+Y2)
-    fe u = fe_pick4(p.Z, p.X, p.Y, fe_add(p.X, p.Y), q);
-    fe v = fe_pick4(r.Z, r.X, r.Y, fe_add(r.X, r.Y), q);
-    fe l1 = fe_mul(u, v);
+    fe l1 = fe_mul(fe_pick4(p.Z, p.X, p.Y, fe_add(p.X, p.Y), q), fe_pick4(r.Z, r.X, r.Y, fe_add(r.X, r.Y), q));
     fe A = quad_bcast(l1, 0), C = quad_bcast(l1, 1), D = quad_bcast(l1, 2), S = quad_bcast(l1, 3);
-    // level 2: B = A^2 (lane 0), U = C D (lane 1)
-    fe l2 = fe_mul(fe_pick4(A, C, A, C, q), fe_pick4(A, D, A, D, q));
-    fe B = quad_bcast(l2, 0), U = quad_bcast(l2, 1);
+    // level 2: B = A^2, U = C D, A (S - C - D), A (D + C)
+    fe l2 = fe_mul(fe_pick4(A, C, A, A, q), fe_pick4(A, D, fe_sub(fe_sub(S, C), D), fe_add(D, C), q));
+    fe B = quad_bcast(l2, 0), U = quad_bcast(l2, 1), AS = quad_bcast(l2, 2), AC = quad_bcast(l2, 3);
     // level 3 (every lane): E = d * C * D
     fe E = fe_mul(fe_const_d(), U);
-    fe F = fe_sub(B, E);
-    fe G = fe_add(B, E);
-    // level 4: A F, A G, F G
-    fe l4 = fe_mul(fe_pick4(A, A, F, F, q), fe_pick4(F, G, G, G, q));
-    fe AF = quad_bcast(l4, 0), AG = quad_bcast(l4, 1), FG = quad_bcast(l4, 2);
-    // level 5: X3 = A F (S - C - D), Y3 = A G (D + C)
-    fe l5 = fe_mul(fe_pick4(AF, AG, AF, AG, q),
-                   fe_pick4(fe_sub(fe_sub(S, C), D), fe_add(D, C), fe_sub(fe_sub(S, C), D), fe_add(D, C), q));
+    fe F = fe_sub(B, E), G = fe_add(B, E);
+    // level 4: X3 = F * A (S - C - D), Y3 = G * A (D + C), Z3 = F G
+    fe l4 = fe_mul(fe_pick4(F, G, F, F, q), fe_pick4(AS, AC, G, G, q));
     ge_proj o;
-    o.X = quad_bcast(l5, 0);
-    o.Y = quad_bcast(l5, 1);
-    o.Z = FG;
+    o.X = quad_bcast(l4, 0);
+    o.Y = quad_bcast(l4, 1);
+    o.Z = quad_bcast(l4, 2);
     return o;
 }
 
@@ -154,6 +150,106 @@ k_fold_quad(const uint32_t *__restrict__ gl, const uint32_t *__restrict__ gr, in
     }
     r = quad_proj_add(r, b, q);              // * g_r
     if (live && q == 0) ex_store_point(r, i, out_proj, out_aff);
+}
+
+// ---- fold, two waves per 16 elements (the shortest vectors) --------------------------------------
+// In the right-to-left ladder the doublings d_{j+1} = 2 d_j never wait for the additions acc += d_j - k_fold_quad runs
+// both chains in one instruction stream and pays 2 + 4 levels of multiplications per set bit.  Here a workgroup is two
+// waves over the same 16 elements (a quad per element in each): wave 0 walks the doubling chain and leaves d_j in LDS,
+// FP_K of them at a time; wave 1, one batch behind, adds the d_j of the set bits - the SAME operations on the same
+// operands in the same order, so the (X:Y:Z) are k_fold's bit for bit; the two chains run on two SIMDs side by side
+// (0.78 -> ~0.4 ms for a full-length scalar, whatever the vector's length up to one wave per SIMD).
+#define FP_K 8                 // doublings per batch
+#define FP_ELEMS 16            // elements per workgroup
+#define FP_MAX_DEFAULT (8 * 1024)
+
+// LDS: [buffer][k][16-byte piece 0..7][element] - a piece index across the 16 elements is 256 contiguous bytes
+__device__ __forceinline__ uint4 *fp_slot(uint4 *ring, int buf, int k, int piece, int elem) {
+    return ring + (((buf * FP_K + k) * 8 + piece) * FP_ELEMS + elem);
+}
+
+// PAIRS: (doubling wave, adding wave) pairs per workgroup.  One pair per workgroup spreads a short vector over the most
+// CUs; at 8192 elements that is two workgroups per CU and the dispatcher does not keep their four waves on four SIMDs
+// (858 us against 520 for 4096 elements) - two pairs per workgroup, one workgroup per CU, does.
+template <int PAIRS>
+__global__ void __launch_bounds__(128 * PAIRS)
+k_fold_pipe(const uint32_t *__restrict__ gl, const uint32_t *__restrict__ gr, int in_affine, u256_arg c,
+            size_t half, uint32_t *__restrict__ out_proj, uint32_t *__restrict__ out_aff) {
+    __shared__ uint4 ring_all[PAIRS * 2 * FP_K * 8 * FP_ELEMS];            // 32 KiB per pair
+    const int wave = (threadIdx.x >> 6) / PAIRS, pair = (threadIdx.x >> 6) % PAIRS, lane = threadIdx.x & 63;
+    uint4 *ring = ring_all + pair * (2 * FP_K * 8 * FP_ELEMS);
+    const int elem = lane >> 2, q = lane & 3;
+    size_t i = ((size_t)blockIdx.x * PAIRS + pair) * FP_ELEMS + elem;
+    const bool live = i < half;
+    if (!live) i = half - 1;
+    const int bl = u256_bit_length(c.v);
+    const int batches = (bl + FP_K - 1) / FP_K;
+    ge_proj d, acc = ge_proj_identity();
+    if (wave == 0) d = ex_load_point(gl, i, in_affine != 0);
+#pragma unroll 1
+    for (int t = 0; t <= batches; t++) {
+        if (wave == 0) {
+            if (t < batches) {
+#pragma unroll 1
+                for (int k = 0; k < FP_K; k++) {
+                    if (t * FP_K + k >= bl) break;
+                    // lanes 0, 1, 2 of the quad leave X, Y, Z (10 limbs each; pieces 0-2, 3-5 and 6-7 + the 8 spare
+                    // bytes: X in pieces 0..2 words 0..9 ... laid out as 30 consecutive words + 2 of padding)
+                    uint32_t w[32];
+#pragma unroll
+                    for (int l = 0; l < FE_LIMBS; l++) {
+                        w[l] = d.X.v[l];
+                        w[FE_LIMBS + l] = d.Y.v[l];
+                        w[2 * FE_LIMBS + l] = d.Z.v[l];
+                    }
+                    w[30] = w[31] = 0;
+                    // (every lane of the quad holds the whole point: lane q stores pieces 2q and 2q + 1)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        uint4 v;
+                        switch (q) {
+                            case 0: v = make_uint4(w[0 + 4 * h], w[1 + 4 * h], w[2 + 4 * h], w[3 + 4 * h]); break;
+                            case 1: v = make_uint4(w[8 + 4 * h], w[9 + 4 * h], w[10 + 4 * h], w[11 + 4 * h]); break;
+                            case 2: v = make_uint4(w[16 + 4 * h], w[17 + 4 * h], w[18 + 4 * h], w[19 + 4 * h]); break;
+                            default: v = make_uint4(w[24 + 4 * h], w[25 + 4 * h], w[26 + 4 * h], w[27 + 4 * h]); break;
+                        }
+                        *fp_slot(ring, t & 1, k, 2 * q + h, elem) = v;
+                    }
+                    quad_proj_dbl(d, q);
+                }
+            }
+        } else if (t >= 1) {
+            const int tb = t - 1;
+#pragma unroll 1
+            for (int k = 0; k < FP_K; k++) {
+                const int bit = tb * FP_K + k;
+                if (bit >= bl) break;
+                if (!((c.v[bit >> 5] >> (bit & 31)) & 1u)) continue;
+                uint32_t w[32];
+#pragma unroll
+                for (int piece = 0; piece < 8; piece++) {
+                    const uint4 v = *fp_slot(ring, tb & 1, k, piece, elem);
+                    w[4 * piece] = v.x;
+                    w[4 * piece + 1] = v.y;
+                    w[4 * piece + 2] = v.z;
+                    w[4 * piece + 3] = v.w;
+                }
+                ge_proj dj;
+#pragma unroll
+                for (int l = 0; l < FE_LIMBS; l++) {
+                    dj.X.v[l] = w[l];
+                    dj.Y.v[l] = w[FE_LIMBS + l];
+                    dj.Z.v[l] = w[2 * FE_LIMBS + l];
+                }
+                acc = quad_proj_add(acc, dj, q);
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 1) {
+        ge_proj r = quad_proj_add(acc, ex_load_point(gr, i, in_affine != 0), q);      // * g_r
+        if (live && q == 0) ex_store_point(r, i, out_proj, out_aff);
+    }
 }
 
 // ---- repeat -------------------------------------------------------------------------------
@@ -298,7 +394,19 @@ extern "C" int vmpc_fold_dev(vmpc_ctx *ctx, const void *g_l, const void *g_r, in
         const char *e = getenv("VMPC_FOLD_QUAD_MAX");
         return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)EX_FOLD_QUAD_MAX;
     }();
-    if (half <= quad_max)
+    static const size_t pipe_max = [] {
+        const char *e = getenv("VMPC_FOLD_PIPE_MAX");
+        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)FP_MAX_DEFAULT;
+    }();
+    if (half <= pipe_max && half > (size_t)FP_ELEMS * ctx->cu_count)
+        k_fold_pipe<2><<<(unsigned)((half + 2 * FP_ELEMS - 1) / (2 * FP_ELEMS)), 256, 0, ctx->stream>>>(
+            (const uint32_t *)g_l, (const uint32_t *)g_r, in_affine, ca, half, (uint32_t *)out_proj,
+            (uint32_t *)out_affine);
+    else if (half <= pipe_max)
+        k_fold_pipe<1><<<(unsigned)((half + FP_ELEMS - 1) / FP_ELEMS), 128, 0, ctx->stream>>>(
+            (const uint32_t *)g_l, (const uint32_t *)g_r, in_affine, ca, half, (uint32_t *)out_proj,
+            (uint32_t *)out_affine);
+    else if (half <= quad_max)
         k_fold_quad<<<ex_grid(4 * half), EX_BLOCK, 0, ctx->stream>>>(
             (const uint32_t *)g_l, (const uint32_t *)g_r, in_affine, ca, half, (uint32_t *)out_proj,
             (uint32_t *)out_affine);
