@@ -25,6 +25,10 @@ import time
 
 import numpy as np
 
+# hardware queues for the HIP runtime (libvmpc_hip sets the same default when it is loaded - csrc/api.hip -; here too,
+# because torch may initialise HIP first; with the default of 4 which streams run in order behind each other depends
+# on how many were created before them)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -7,6 +7,16 @@
 
 thread_local char vmpc_err_buf[512] = {0};
 
+// The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and
+// streams that share a hardware queue run IN ORDER.  This library overlaps work on more streams than that (the main
+// stream, the transcript-text stream, the round context's stream, the second commitment of a pair, one stream per
+// pipeline slot): with four queues, whether the text stream ended up behind the stream whose folds it is supposed to
+// run beside depended on how many contexts had been created before it - 55 instead of 30 ms outside the hash of a
+// reference-transcript proof (EXPERIMENTS.md R6.7).  The runtime reads the variable when it initialises, i.e. at the
+// process's first HIP call: set here, at load time, unless the host application chose a value (or initialised HIP
+// before loading this library - then it has to export the variable itself).
+__attribute__((constructor)) static void vmpc_hw_queues_default() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 int vmpc_fr_check_dev(vmpc_ctx *ctx, const void *v, size_t n);  // frvec.hip
 
 extern "C" const char *vmpc_last_error(void) { return vmpc_err_buf; }
