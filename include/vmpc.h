@@ -403,12 +403,14 @@ typedef struct vmpc_p4 vmpc_p4;
 int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows, int h_slots,
                    int k_slot, const uint8_t k_affine[64], const void *z_hat, const void *L_tilde, vmpc_p4 **out);
 /* vmpc_p4_create with the number of rounds before the generators are folded chosen by the caller (jump_k = 0: never,
- * < 0: the default of 5), and vmpc_p4_prefold: make a fold that is due - jump_k challenges have been fed - NOW, enqueued
- * on the context's stream without waiting, instead of at the start of the next vmpc_p4_round (not between
- * vmpc_p4_round_begin and _end). */
+ * < 0: the default of 5) and, with lazy_fold != 0, a fold that waits for vmpc_p4_prefold: the round that is given the
+ * jump_k-th challenge still commits over the unfolded table, and the fold is enqueued - on the context's stream,
+ * nothing waited for - when the caller asks (not between vmpc_p4_round_begin and _end), at the latest at the start of
+ * the round after.  vmpc_p4_prefold without a fold that is due does nothing.  vmpc_p4_run_compact refuses a lazy
+ * context. */
 int vmpc_p4_create_opts(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows, int h_slots,
                         int k_slot, const uint8_t k_affine[64], const void *z_hat, const void *L_tilde, int jump_k,
-                        vmpc_p4 **out);
+                        int lazy_fold, vmpc_p4 **out);
 int vmpc_p4_prefold(vmpc_p4 *p4);
 /* A second table over the SAME generators and extras (same n, same extras in the same order) for the A_i, B_i
  * commitments of the rounds BEFORE the generators are folded - the 13-row wide-window table (vmpc_msm_table_build_dev

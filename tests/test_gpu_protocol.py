@@ -687,6 +687,43 @@ def test_native_round_in_two_halves(vm):
     ctx.sync()
 
 
+@pytest.mark.parametrize("log_n", [6, 9])
+def test_lazy_generator_fold_gives_the_same_rounds(vm, monkeypatch, log_n):
+    """vmpc_p4_create_opts(lazy_fold): the round that is given the jump_k-th challenge commits over the UNFOLDED table
+    and the fold is made by vmpc_p4_prefold (or at the start of the round after) - the same A_i, B_i as the eager fold
+    and as a context that never folds"""
+    monkeypatch.setenv("VMPC_P4_JUMP_MIN_LOG2", "3")
+    ctx = vm.get_context()
+    group = vm.EllipticCurve("Ed25519", "projective")
+    h = group.generator
+    k = vm.Ed25519Point.repeat(h, 4242)
+    n = (1 << log_n) - 1
+    rng = random.Random(log_n)
+    g = vm.PointVector.fixed_base(h, [rng.randrange(1, 2**252) for _ in range(n)])
+    g.precompute([h, k])
+    z = vm.ScalarVector.from_ints([rng.randrange(2**252) for _ in range(n + 1)])
+    L = vm.ScalarVector.from_ints([rng.randrange(2**252) for _ in range(n + 1)])
+    cs = [None] + [rng.randrange(1, 2**252) for _ in range(log_n - 2)]
+
+    def rounds(prefold_after=None, **kw):
+        r = vm._native.P4Rounds(ctx, g._table, 1, 1, z.ptr, L.ptr, **kw)
+        out = []
+        for i, c in enumerate(cs):
+            out.append(r.round(c))
+            if prefold_after is not None and i == prefold_after:
+                r.prefold()
+        out.append(r.finish(12345))
+        r.close()
+        return out
+
+    want = rounds(jump_k=0)                                   # never folds
+    assert rounds(jump_k=2) == want                           # folds at the start of the round given c_1
+    assert rounds(jump_k=2, lazy_fold=True) == want           # ... never asked: at the start of the round after
+    assert rounds(jump_k=2, lazy_fold=True, prefold_after=2) == want      # asked right after that round
+    assert rounds(jump_k=2, lazy_fold=True, prefold_after=1) == want      # asked too early: nothing is due, no-op
+    assert rounds(jump_k=3, lazy_fold=True, prefold_after=3) == want
+
+
 def test_native_round_context_argument_checks(vm):
     ctx = vm.get_context()
     group = vm.EllipticCurve("Ed25519", "projective")

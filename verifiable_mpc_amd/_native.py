@@ -145,7 +145,7 @@ def load_library():
         "vmpc_msm_table_fold_table_dev": (i32, [vp, vp, sz, sz, i32, sz, i32, vp, vp, sz, i32, vp]),
         "vmpc_p4_create": (i32, [vp, vp, sz, sz, i32, i32, i32, vp, vp, vp, ctypes.POINTER(vp)]),
         "vmpc_p4_set_commit_table": (i32, [vp, vp, i32]),
-        "vmpc_p4_create_opts": (i32, [vp, vp, sz, sz, i32, i32, i32, vp, vp, vp, i32, ctypes.POINTER(vp)]),
+        "vmpc_p4_create_opts": (i32, [vp, vp, sz, sz, i32, i32, i32, vp, vp, vp, i32, i32, ctypes.POINTER(vp)]),
         "vmpc_p4_prefold": (i32, [vp]),
         "vmpc_p4_round": (i32, [vp, vp, vp, vp]),
         "vmpc_p4_round_begin": (i32, [vp, vp]),
@@ -977,10 +977,11 @@ class P4Rounds:
     """vmpc_p4_*: the Protocol-4 prover's rounds with z_hat, L~ and the challenge products resident in HBM."""
 
     def __init__(self, ctx, table, h_slots, k_slot, z_ptr, l_ptr, n_total=None, comm=None, commit_table=None,
-                 jump_k=None):
+                 jump_k=None, lazy_fold=False):
         """comm (a Comm): `table` holds this rank's block of g_hat (vmpc_p4_create_sharded), z / L~ all N scalars.
         commit_table: a second table over the same generators and extras for the pairs of the rounds before the
-        fold (the 13-row wide-window table, vmpc_p4_set_commit_table)"""
+        fold (the 13-row wide-window table, vmpc_p4_set_commit_table)
+        jump_k, lazy_fold: vmpc_p4_create_opts (rounds before the generator fold; the fold waits for prefold())"""
         self.ctx, self.table, self.comm, self.commit_table = ctx, table, comm, commit_table
         # the C side takes N = world * (table.n + h_slots) and reads that many scalars from z_hat and L~
         world = comm.world if comm is not None else 1
@@ -994,10 +995,11 @@ class P4Rounds:
                                                   len(table.extra_bytes), table.rows, k_slot, k_aff,
                                                   ctypes.c_void_p(z_ptr), ctypes.c_void_p(l_ptr), ctypes.byref(h)),
                    "vmpc_p4_create_sharded")
-        elif jump_k is not None:
+        elif jump_k is not None or lazy_fold:
             _check(ctx.lib.vmpc_p4_create_opts(ctx.handle, ctypes.c_void_p(table.ptr), table.n, len(table.extra_bytes),
                                                table.rows, h_slots, k_slot, k_aff, ctypes.c_void_p(z_ptr),
-                                               ctypes.c_void_p(l_ptr), int(jump_k), ctypes.byref(h)),
+                                               ctypes.c_void_p(l_ptr), -1 if jump_k is None else int(jump_k),
+                                               1 if lazy_fold else 0, ctypes.byref(h)),
                    "vmpc_p4_create_opts")
         else:
             _check(ctx.lib.vmpc_p4_create(ctx.handle, ctypes.c_void_p(table.ptr), table.n, len(table.extra_bytes),
@@ -1026,7 +1028,7 @@ class P4Rounds:
         return a.raw, b.raw
 
     def prefold(self):
-        """a generator fold that is due (jump_k challenges fed): enqueue it now, wait for nothing (vmpc_p4_prefold)"""
+        """a generator fold that is due (lazy_fold context, jump_k challenges fed): enqueue it now, wait for nothing"""
         _check(self.ctx.lib.vmpc_p4_prefold(self.handle), "vmpc_p4_prefold")
 
     def finish(self, last_challenge):

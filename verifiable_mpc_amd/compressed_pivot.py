@@ -64,8 +64,9 @@ EARLY_PAIR_FIRST = os.environ.get("VMPC_EARLY_PAIR_FIRST", "1") != "0"     # the
 REF_TABLE_PAIR_MIN = int(os.environ.get("VMPC_REF_TABLE_PAIR_MIN", "2"))
 # ... and ALL the way down (round 6, second step; the first one stopped at 2^17 elements): the context folds ITS generators
 # once, after REF_TABLE_JUMP_K challenges, in one pass over the table (csrc/fold_jump.hip; 2.9 ms into 2^15 columns,
-# twice that into 2^16) - asked for right after the round that feeds the last of them (vmpc_p4_prefold), so that it runs
-# on the GPU while the host hashes that round's text - and every later pair is a commitment over the folded table (the
+# twice that into 2^16) - a LAZY fold (vmpc_p4_create_opts): the round that feeds the last of them still commits over the
+# unfolded table, the fold is asked for once that pair has been collected (vmpc_p4_prefold) and runs on the GPU while the
+# host hashes the next round's text - and every later pair is a commitment over the folded table (the
 # fused short path, 0.25 ms) instead of an MSM over the exactly folded short vector (0.55 ms behind a 0.78-ms fold).
 # Measured (scripts/ref_stall_probe.py, time outside sha256.update): 44.7 / 41.1 / 40.0 / 41.7 ms at 3 / 4 / 5 / 6
 # challenges against 41.4 with the context closed at 2^17 elements.
@@ -456,7 +457,7 @@ def _ref_table_rounds(g_hat, k, L_tilde, z_hat, transcript):
         side.wait_for(g_hat.ctx)                 # z_hat and L~ were produced on the main stream
     return P4Rounds(side, table, g_hat._table_tail, table.extra_index(k), z_hat.ptr, _coeffs_dev(L_tilde).ptr,
                     n_total=m, commit_table=USE_WIDE_COMMIT_TABLE and getattr(g_hat, "_wide", None) or None,
-                    jump_k=REF_TABLE_JUMP_K)
+                    jump_k=REF_TABLE_JUMP_K, lazy_fold=True)
 
 
 def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, transcript, tail_cs, early):

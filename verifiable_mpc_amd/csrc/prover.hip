@@ -255,6 +255,8 @@ struct vmpc_p4 {
     char *mine, *gathered;            // 2 partial points of this rank; world x 2 gathered ones
     bool poisoned;                    // a call failed after the fold state advanced: only destroy is valid
     bool in_flight;                   // vmpc_p4_round_begin without its vmpc_p4_round_end yet
+    bool lazy_fold;                   // a due fold waits for vmpc_p4_prefold (or the NEXT round), see vmpc_p4_create_opts
+    int products_t;                   // challenges the per-generator products hold (k_fr_tail_scalars_inc), -1: none
     const void *table0;               // the caller's table (the unfolded CRS / block)
     // a second table over the SAME generators and extras for the pair commitments of the rounds before the fold
     // (vmpc_p4_set_commit_table: the 13-row wide-window table - 13 mixed additions per term instead of 16); the fold
@@ -338,6 +340,8 @@ static int p4_create(vmpc_ctx *ctx, vmpc_comm *comm, const void *table, size_t t
     p->arena_pooled = false;
     p->poisoned = false;
     p->in_flight = false;
+    p->lazy_fold = false;
+    p->products_t = -1;
     p->dots_grid = 0;
     p->round = p->committed = p->cur = p->log2_n = 0;
     p->jump_k = 5;                               // VMPC_P4_JUMP=0 keeps every round on the unfolded CRS
@@ -460,14 +464,18 @@ extern "C" int vmpc_p4_create(vmpc_ctx *ctx, const void *table, size_t table_n, 
 }
 
 // The same with the number of rounds before the generator fold chosen by the caller (0: never; < 0: the default), and
-// vmpc_p4_prefold: make a fold that is due NOW - enqueued on the context's stream, nothing waited for - instead of at
-// the start of the next vmpc_p4_round.  For a caller with time between two rounds: the reference-transcript prover
-// hashes tens of megabytes of text on the host while the GPU is idle (compressed_pivot.py:51-59).
+// with a LAZY fold: the round that is given the jump_k-th challenge still commits over the unfolded table (one more
+// challenge product in its scalars) instead of folding first, and the fold is made by vmpc_p4_prefold - enqueued on the
+// context's stream, nothing waited for - or, if the caller never asks, at the start of the round after.  For a caller
+// with time between two rounds: the reference-transcript prover hashes megabytes of text on the host while the GPU is
+// idle (compressed_pivot.py:51-59), and a 3.7-ms fold in front of a round's pair is 3.7 ms in front of that hash.
 extern "C" int vmpc_p4_create_opts(vmpc_ctx *ctx, const void *table, size_t table_n, size_t table_extra, int rows,
                                    int h_slots, int k_slot, const uint8_t k_affine[64], const void *z_hat,
-                                   const void *L_tilde, int jump_k, vmpc_p4 **out) {
-    return p4_create(ctx, nullptr, table, table_n, table_extra, rows, h_slots, k_slot, k_affine, z_hat, L_tilde, out,
-                     jump_k);
+                                   const void *L_tilde, int jump_k, int lazy_fold, vmpc_p4 **out) {
+    const int rc = p4_create(ctx, nullptr, table, table_n, table_extra, rows, h_slots, k_slot, k_affine, z_hat, L_tilde,
+                             out, jump_k);
+    if (rc == VMPC_OK) (*out)->lazy_fold = lazy_fold != 0;
+    return rc;
 }
 
 static bool p4_jump_due(const vmpc_p4 *p);
@@ -590,6 +598,7 @@ static int p4_jump(vmpc_p4 *p) {
     p->block_n = m_out;
     p->jumps_done++;
     p->pending.clear();
+    p->products_t = -1;               // (the products were over the unfolded vector's positions)
     return VMPC_OK;
 }
 
@@ -652,7 +661,7 @@ extern "C" int vmpc_ed25519_lincomb_host(const uint8_t *points, const uint8_t *s
 
 static int p4_round_enqueue(vmpc_p4 *p, const uint32_t *c_mem) {
     vmpc_ctx *ctx = p->ctx;
-    if (p4_jump_due(p)) {
+    if (p4_jump_due(p) && !p->lazy_fold) {
         if (c_mem) return VMPC_E_INVAL;                     // a fold of the generators needs the challenges' values
         VMPC_CHECK(p4_jump(p));
     }
@@ -662,8 +671,16 @@ static int p4_round_enqueue(vmpc_p4 *p, const uint32_t *c_mem) {
     // commitment scalars over the unfolded g_hat (this rank's block of it): challenge products x the (shifted)
     // witness halves
     static const uint8_t zero[32] = {0};
+    if (t >= 1 && p->products_t != t - 1) {
+        // the products are kept incrementally, one challenge per round; a lazy fold leaves the first round on the folded
+        // table with one challenge pending and no products yet: start them (all ones) first
+        if (t != 1) return VMPC_E_INVAL;
+        VMPC_CHECK(vmpc_fr_tail_scalars_block_mem(ctx, zero, nullptr, 0, p->log2_n, z, p->block_lo, p->block_n, p->products,
+                                                  p->va, p->vb));
+    }
     VMPC_CHECK(vmpc_fr_tail_scalars_block_mem(ctx, t ? p->pending.back().data() : zero, c_mem, t, p->log2_n, z, p->block_lo,
                                               p->block_n, p->products, p->va, p->vb));
+    p->products_t = t;
     // extras: the tail of g_hat (h) lives among them, and k with the inner products as exponents (rank 0 only:
     // the k term must enter the sum over the ranks once)
     {
@@ -742,6 +759,15 @@ static int p4_round_body(vmpc_p4 *p, uint8_t out_A[64], uint8_t out_B[64]) {
     return p4_round_collect(p, out_A, out_B);
 }
 
+// lazy fold (vmpc_p4_create_opts): a fold that is still due when the next challenge arrives is made first - the
+// schedule fixed at creation folds exactly jump_k challenges
+static int p4_lazy_fold_now(vmpc_p4 *p) {
+    if (!p->lazy_fold || !p4_jump_due(p)) return VMPC_OK;
+    const int rc = p4_jump(p);
+    if (rc != VMPC_OK) p->poisoned = true;
+    return rc;
+}
+
 // One round: prev_challenge = the challenge derived from the PREVIOUS call's A, B (NULL on the first call).
 // Returns A_i, B_i as 64-byte affine points.  Synchronises the context's stream (the results are needed
 // for the next hash).  A failure after the fold has advanced the state leaves the context unusable (every
@@ -752,6 +778,7 @@ extern "C" int vmpc_p4_round(vmpc_p4 *p, const uint8_t prev_challenge[32], uint8
         (prev_challenge && p->m / 2 < 4))
         return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
+    VMPC_CHECK(p4_lazy_fold_now(p));
     // fold with the previous challenge; exponents of k: L~(0 || z_l) and L~(z_r || 0) (compressed_pivot.py:41-42)
     VMPC_CHECK(p4_fold_dots(p, prev_challenge));      // rejects a non-canonical challenge before touching the state
     const int rc = p4_round_body(p, out_A, out_B);
@@ -767,6 +794,7 @@ extern "C" int vmpc_p4_round_begin(vmpc_p4 *p, const uint8_t prev_challenge[32])
         (prev_challenge && p->m / 2 < 4))
         return VMPC_E_INVAL;
     VMPC_HIP_CHECK(hipSetDevice(p->ctx->device));
+    VMPC_CHECK(p4_lazy_fold_now(p));
     VMPC_CHECK(p4_fold_dots(p, prev_challenge));
     const int rc = p4_round_enqueue(p, nullptr);
     if (rc != VMPC_OK) p->poisoned = true;
@@ -946,8 +974,9 @@ static bool p4_can_queue_ahead(vmpc_p4 *p) {
 // (A_i || B_i) = 128 bytes each; out_z_prime: the two final residues.  The context must be fresh.
 extern "C" int vmpc_p4_run_compact(vmpc_p4 *p, uint8_t state[32], int first_round_index, uint8_t *out_AB,
                                    uint8_t out_z_prime[64]) {
-    if (!p || !state || !out_AB || !out_z_prime || p->committed != 0 || p->in_flight || first_round_index < 0)
-        return VMPC_E_INVAL;
+    if (!p || !state || !out_AB || !out_z_prime || p->committed != 0 || p->in_flight || p->lazy_fold ||
+        first_round_index < 0)
+        return VMPC_E_INVAL;             // (lazy folds are asked for by a caller that drives the rounds itself)
     uint8_t challenge[32];
     const int rounds = p->total_rounds;
     if (!p4_can_queue_ahead(p)) {
