@@ -157,12 +157,15 @@ def test_text_delivered_in_pieces_equals_the_whole(vm, monkeypatch):
     # a second pass over an already delivered text, and the synchronous path, give the same bytes
     assert b"".join(bytes(p) for p in g.text_chunks()) == whole_g[:-2]
     assert bytes(g.text()) == whole_g
-    # folds: slice by slice (512 + 512 + 384 elements here) against one launch
+    # folds: slice by slice, growing (128 + 256 + 512 + 512 elements here), against one launch
     monkeypatch.setattr(vm.PointVector, "TEXT_SLICE", 512)
+    monkeypatch.setattr(vm.PointVector, "TEXT_FIRST_SLICE", 128)
+    monkeypatch.setattr(vm.PointVector, "TEXT_SLICED_FROM", 1024)
     c = rng.randrange(ELL)
     half = 1408
     plain = g[:half].fold(g[half:2 * half], c)
     sliced = g[:half].fold(g[half:2 * half], c, stream_text=True)
+    assert len(sliced._pending_text[1].parts) == 4
     assert bytes(plain.text())[:-2] == b"".join(bytes(p) for p in sliced.text_chunks())
     assert plain.affine_array().tobytes() == sliced.affine_array().tobytes()
     # g + [h] right after g: the parent's text is reused, the extra point formatted on its own

@@ -106,23 +106,27 @@ k_scan_add(OutT *__restrict__ out, const OutT *__restrict__ tile_offsets, size_t
 // up to 32768 items in ONE workgroup of 1024 threads (the histogram of a short MSM - 16640 counters in a late
 // prover round: three launches cost three dispatches)
 #define VMPC_SCAN_SMALL_MAX 32768
-template <typename InT, typename OutT>
+// ITEMS = 8 for up to 8192 items: a 1024-thread workgroup is sixteen waves on ONE CU, and with 32 items in registers
+// they need (nearly) a whole register file - beside a latency-bound kernel that keeps one wave on every SIMD of the
+// chip (the exact fold of a short vector, csrc/exact.hip) the workgroup waited for that kernel to END: 785 us for the
+// text offsets of the fold's previous slice (profiles/r06_fold_slices_timeline.txt).  Eight items fit beside it.
+template <typename InT, typename OutT, int ITEMS>
 __global__ void __launch_bounds__(1024)
 k_scan_small(const InT *__restrict__ in, OutT *__restrict__ out, OutT *__restrict__ total_out, size_t n) {
     __shared__ OutT lds[16];
-    const int per = (int)((n + 1023) / 1024);                  // <= 32 consecutive items per thread
+    const int per = (int)((n + 1023) / 1024);                  // <= ITEMS consecutive items per thread
     const size_t base = (size_t)threadIdx.x * per;
-    OutT v[32];
+    OutT v[ITEMS];
     OutT s = 0;
 #pragma unroll
-    for (int i = 0; i < 32; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         v[i] = (i < per && base + i < n) ? (OutT)in[base + i] : (OutT)0;
         s += v[i];
     }
     OutT tot;
     OutT ex = vmpc_block_excl_scan<OutT>(s, &tot, lds);
 #pragma unroll
-    for (int i = 0; i < 32; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         if (i < per && base + i < n) out[base + i] = ex;
         ex += v[i];
     }
@@ -153,7 +157,8 @@ int vmpc_exclusive_scan(hipStream_t stream, const InT *in, OutT *out, size_t n, 
     OutT *sums = (OutT *)ws;
     char *next_ws = (char *)ws + vmpc_align(tiles * sizeof(OutT));
     if (tiles > 1 && n <= VMPC_SCAN_SMALL_MAX) {
-        k_scan_small<InT, OutT><<<1, 1024, 0, stream>>>(in, out, total_out, n);
+        if (n <= 8192) k_scan_small<InT, OutT, 8><<<1, 1024, 0, stream>>>(in, out, total_out, n);
+        else k_scan_small<InT, OutT, 32><<<1, 1024, 0, stream>>>(in, out, total_out, n);
         VMPC_KERNEL_CHECK();
         return VMPC_OK;
     }

@@ -454,6 +454,8 @@ class PointVector:
         return self
 
     TEXT_SLICE = 1 << 16     # fold(stream_text=True): elements folded, formatted and sent to the host at a time
+    TEXT_FIRST_SLICE = int(os.environ.get("VMPC_FOLD_FIRST_SLICE", str(1 << 13)))      # ... the first time
+    TEXT_SLICED_FROM = int(os.environ.get("VMPC_FOLD_SLICED_FROM", str(1 << 14)))      # shorter folds are not sliced
 
     def fold(self, other, c, keep_proj=None, stream_text=False, after_first=None):
         """[(self[i] ** c) * other[i]] (compressed_pivot.py:64/:178), csrc/exact.hip k_fold.
@@ -474,7 +476,12 @@ class PointVector:
         lp, rp = (self.p.ptr, other.p.ptr) if use_proj else (self.a.ptr, other.a.ptr)
         stride = 96 if use_proj else 64
         out = PointVector(_View(abuf, 0, half, 64), _View(pbuf, 0, half, 96) if pbuf else None, self.ctx)
-        if not (stream_text and pbuf is not None and half >= 2 * self.TEXT_SLICE):
+        # (with a co-runner - after_first: the prover's pair on another stream - the plan of round 6's first half stays:
+        # folds of 2^17 elements or more, a first slice of 2^14, then full slices; the growing plan measured 31 against
+        # 28 ms outside the hash there: the formatter's kernels do not get in beside the pair's bucket kernel AND the
+        # two-wave fold, and the first text is late by the pair)
+        sliced_from = 2 * self.TEXT_SLICE if after_first is not None else self.TEXT_SLICED_FROM
+        if not (stream_text and pbuf is not None and half >= sliced_from):
             self.ctx.fold(lp, rp, not use_proj, reduce_scalar(c), half, pbuf.ptr if pbuf else None, abuf.ptr)
             if stream_text:
                 out.text_begin()
@@ -482,11 +489,16 @@ class PointVector:
                 after_first(False)
             return out
         side, pieces = get_aux_context(2), []
-        # (with a co-runner the first slice is a short one: fewer lanes taken from the work beside it, and its text
-        # is on the host sooner)
-        first = int(os.environ.get("VMPC_FOLD_FIRST_SLICE", str(self.TEXT_SLICE // 4))) if after_first is not None \
-            else self.TEXT_SLICE
-        cuts = [0] + list(range(first, half, self.TEXT_SLICE))
+        # The slices grow: the hash waits for the FIRST one's text and an exact fold is a 253-step ladder whatever the
+        # slice's length - 0.5-0.6 ms on the two-wave kernel (<= 2^13 elements), 0.8 on the quad kernel (<= 2^14), 1.2-1.4
+        # with one lane per element (csrc/exact.hip) - while hashing a slice's text takes 0.1 ms per 2^10 elements: each
+        # slice is back before the host has hashed the one before it.
+        cuts, step = [0], self.TEXT_FIRST_SLICE
+        if after_first is not None:
+            step = self.TEXT_SLICE // 4
+        while cuts[-1] + step < half:
+            cuts.append(cuts[-1] + step)
+            step = min(2 * step, self.TEXT_SLICE) if after_first is None else self.TEXT_SLICE
         for a, b in zip(cuts, cuts[1:] + [half]):
             cnt = b - a
             self.ctx.fold(lp + stride * a, rp + stride * a, not use_proj, reduce_scalar(c), cnt, pbuf.ptr + 96 * a,
