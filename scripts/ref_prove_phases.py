@@ -22,6 +22,8 @@ group = vm.EllipticCurve("Ed25519", "projective")
 gf = vm.GF(group.order)
 g = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(bench.rand_scalars(rng, n)), keep_proj=True)
 gens = {"g": g, "h": group.generator, "k": vm.Ed25519Point.repeat(group.generator, 0x1234567)}
+if os.environ.get("VMPC_CRS_TABLE", "1") != "0":       # as circuit_sat.create_generators hands a CRS over
+    g.precompute([gens["h"], gens["k"]], wide=True)
 x = vm.ScalarVector.from_array(bench.rand_scalars(rng, n))
 L = vm.pivot.LinearForm(vm.ScalarVector.from_array(bench.rand_scalars(rng, n)))
 y = gf(L(x))
@@ -50,6 +52,8 @@ timed(cp, "_fold_commitment")
 timed(cp, "_fold_form")
 timed(cp, "_fold_witness")
 timed(cp, "_round_prover_scalars")
+for _name in ("round", "round_begin", "round_end", "prefold"):
+    timed(vm._native.P4Rounds, _name, "P4Rounds." + _name)
 timed(device.PointVector, "fold")
 timed(device.PointVector, "text", "PointVector.text (wait for format + copy)")
 timed(device.ScalarVector, "text", "ScalarVector.text (wait)")
