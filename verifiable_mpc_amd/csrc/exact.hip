@@ -86,15 +86,17 @@ k_fold(const uint32_t *__restrict__ gl, const uint32_t *__restrict__ gr, int in_
 // the SAME formulas level by level (dbl-2008-bbjlp: 4 squarings | 3 products; add-2008-bbjlp:
 // 4 | 4 | 1 | 3), so the chain is ~1000 multiplications long.  Field arithmetic is exact
 // and commutative/associative, so the (X:Y:Z) produced are bit-identical to k_fold's.
+// (sums stay lazy - uncarried - wherever fe_mul's operand bounds allow, exactly as in ge_proj_dbl / ge_proj_add,
+// ge25519.h: a carry pass is ~25 instructions and the formulas have seven sums per operation)
 __device__ __forceinline__ void quad_proj_dbl(ge_proj &p, int q) {
-    fe in = fe_pick4(p.X, p.Y, p.Z, fe_add(p.X, p.Y), q);
+    fe in = fe_pick4(p.X, p.Y, p.Z, fe_add_lazy(p.X, p.Y), q);
     fe sq = fe_sqr(in);
     fe C = quad_bcast(sq, 0), D = quad_bcast(sq, 1), H = quad_bcast(sq, 2), B = quad_bcast(sq, 3);
-    fe E = fe_neg(C);
-    fe F = fe_add(E, D);
-    fe J = fe_sub(F, fe_dbl(H));
-    fe u = fe_pick4(fe_sub(fe_sub(B, C), D), F, F, F, q);
-    fe v = fe_pick4(J, fe_sub(E, D), J, J, q);
+    fe F = fe_sub_lazy(D, C);                                 // E + D with E = -C;  < 2^27.6
+    fe J = fe_sub(F, fe_add_lazy(H, H));                      // carried
+    fe nCD = fe_neg(fe_add_lazy(C, D));                       // E - D, carried
+    fe u = fe_pick4(fe_sub_lazy(fe_sub_lazy(B, C), D), F, F, F, q);      // B - C - D < 2^28.4 against a reduced J
+    fe v = fe_pick4(J, nCD, J, J, q);
     fe prod = fe_mul(u, v);
     p.X = quad_bcast(prod, 0);
     p.Y = quad_bcast(prod, 1);
@@ -106,15 +108,17 @@ __device__ __forceinline__ void quad_proj_dbl(ge_proj &p, int q) {
 // and the canonical limbs that are stored - do not depend on that order.
 __device__ __forceinline__ ge_proj quad_proj_add(const ge_proj &p, const ge_proj &r, int q) {
     // level 1: A = Z1 Z2, C = X1 X2, D = Y1 Y2, S = (X1+Y1)(X2+Y2)
-    fe l1 = fe_mul(fe_pick4(p.Z, p.X, p.Y, fe_add(p.X, p.Y), q), fe_pick4(r.Z, r.X, r.Y, fe_add(r.X, r.Y), q));
+    fe l1 = fe_mul(fe_pick4(p.Z, p.X, p.Y, fe_add_lazy(p.X, p.Y), q),
+                   fe_pick4(r.Z, r.X, r.Y, fe_add_lazy(r.X, r.Y), q));
     fe A = quad_bcast(l1, 0), C = quad_bcast(l1, 1), D = quad_bcast(l1, 2), S = quad_bcast(l1, 3);
     // level 2: B = A^2, U = C D, A (S - C - D), A (D + C)
-    fe l2 = fe_mul(fe_pick4(A, C, A, A, q), fe_pick4(A, D, fe_sub(fe_sub(S, C), D), fe_add(D, C), q));
+    fe DC = fe_add_lazy(D, C);                                // < 2^27.1
+    fe l2 = fe_mul(fe_pick4(A, C, A, A, q), fe_pick4(A, D, fe_sub(S, DC), DC, q));       // (S - D - C carried)
     fe B = quad_bcast(l2, 0), U = quad_bcast(l2, 1), AS = quad_bcast(l2, 2), AC = quad_bcast(l2, 3);
     // level 3 (every lane): E = d * C * D
     fe E = fe_mul(fe_const_d(), U);
-    fe F = fe_sub(B, E), G = fe_add(B, E);
-    // level 4: X3 = F * A (S - C - D), Y3 = G * A (D + C), Z3 = F G
+    fe F = fe_sub_lazy(B, E), G = fe_add_lazy(B, E);          // < 2^27.6, < 2^27.1
+    // level 4: X3 = F * A (S - C - D), Y3 = G * A (D + C), Z3 = F G   (2^27.6 * 2^27.1 as in ge_proj_add)
     fe l4 = fe_mul(fe_pick4(F, G, F, F, q), fe_pick4(AS, AC, G, G, q));
     ge_proj o;
     o.X = quad_bcast(l4, 0);
