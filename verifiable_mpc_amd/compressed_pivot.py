@@ -463,9 +463,18 @@ def _ref_table_rounds(g_hat, k, L_tilde, z_hat, transcript):
 def _protocol_4_prover_loop(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, transcript, tail_cs, early):
     if _on_device(L_tilde.coeffs, z_hat):
         z_hat = pivot._as_device(z_hat)
-    # reference transcript: the round context that supplies the big rounds' pairs (closed below the threshold, or with
-    # this frame)
+    # reference transcript: the round context that supplies the rounds' pairs; released with this call whatever way it
+    # ends (the context's arena goes back to the vmpc_ctx's pool: the next proof must not find it busy)
     table_rounds = _ref_table_rounds(g_hat, k, L_tilde, z_hat, transcript)
+    try:
+        return _protocol_4_prover_rounds(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, transcript, tail_cs, early,
+                                         table_rounds)
+    finally:
+        if table_rounds is not None:
+            table_rounds.close()
+
+
+def _protocol_4_prover_rounds(g_hat, k, Q, L_tilde, z_hat, gf, proof, round_i, transcript, tail_cs, early, table_rounds):
     fed = 0                  # challenges the context has been given since its last fold
     if table_rounds is not None:
         a0, b0 = table_rounds.round(None)
