@@ -176,10 +176,10 @@ def test_text_delivered_in_pieces_equals_the_whole(vm, monkeypatch):
     assert joined == bytes(fresh.text())[:-2]
 
 
-@pytest.mark.parametrize("n", [2048, 2049, 16385, 32768, 32769])
+@pytest.mark.parametrize("n", [2048, 2049, 8192, 8193, 16385, 32768, 32769])
 def test_text_offsets_across_the_scan_forms(vm, n):
     """the formatter's text offsets are an exclusive scan of the items' lengths (csrc/scan.h): one tile, one workgroup
-    (2049 .. 32768 items) and the three-kernel form must give the same text - checked against Python's own decimals"""
+    (2049 .. 8192 items with 8 per thread, .. 32768 with 32) and the three-kernel form must give the same text - checked against Python's own decimals"""
     rng = random.Random(n)
     vals = [rng.randrange(ELL) >> rng.choice([0, 0, 100, 200, 250]) for _ in range(n)]
     sv = vm.ScalarVector.from_ints(vals)
