@@ -657,7 +657,7 @@ def _protocol_4_verifier_compact(g_hat, k, Q, L_tilde, gf, proof, round_i, trans
     zp = ScalarVector.from_ints([pivot._residue(v) for v in z_prime], ctx)
     v = ScalarVector.empty(N, ctx)
     ctx.fr_challenge_products(rounds, low_bits, zp.ptr, v.ptr)
-    gamma = v.dot(_coeffs_dev(L_tilde))
+    gamma = v.dot_dev(_coeffs_dev(L_tilde))        # stays on the device: it is only ever the exponent of k below
     from .device import get_aux_context
     aux = get_aux_context()
     aux.wait_for(ctx)
