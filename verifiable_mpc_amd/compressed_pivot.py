@@ -354,9 +354,10 @@ def _fold_commitment(A, Q, B, c, order=None):
     return Ed25519Point.from_affine_bytes(raw)
 
 
-def _unfold_commitment(Q0, rounds, order, ctx=None):
+def _unfold_commitment(Q0, rounds, order, ctx=None, wait=True):
     """Q_R from Q' = A * Q**c * B**(c**2) applied R times, as ONE (2R+1)-term MSM:
-    Q_R = (prod_j c_j) Q_0 + sum_i (prod_{j>i} c_j) (A_i + c_i^2 B_i)."""
+    Q_R = (prod_j c_j) Q_0 + sum_i (prod_{j>i} c_j) (A_i + c_i^2 B_i).
+    wait=False: the launched commitment (its .result() is the point)."""
     scalars, points = [], []
     suffix = 1
     for A, B, c in reversed(rounds):
@@ -370,8 +371,8 @@ def _unfold_commitment(Q0, rounds, order, ctx=None):
         scalars.append(suffix * sc % order)
         points.append(pt)
     pv = PointVector.from_points(points, ctx, keep_proj=False)
-    return pivot._commit_launch(ScalarVector.from_ints(scalars, pv.ctx), 0, pv, Ed25519Point.identity,
-                                pv.ctx).result()
+    pending = pivot._commit_launch(ScalarVector.from_ints(scalars, pv.ctx), 0, pv, Ed25519Point.identity, pv.ctx)
+    return pending.result() if wait else pending
 
 
 NATIVE_ROUNDS = os.environ.get("VMPC_NATIVE_ROUNDS", "1") != "0"
@@ -660,10 +661,12 @@ def _protocol_4_verifier_compact(g_hat, k, Q, L_tilde, gf, proof, round_i, trans
     gamma = v.dot_dev(_coeffs_dev(L_tilde))        # stays on the device: it is only ever the exponent of k below
     from .device import get_aux_context
     aux = get_aux_context()
-    aux.wait_for(ctx)
+    # the short one first: a (2R+1)-term MSM is ~25 dependent launches ending in a 0.2-ms recombination chain - pure
+    # latency that now runs on its own stream while the host enqueues the N-term commitment and the GPU computes it
+    # (3.26 -> 2.96 ms per verify at N = 2^20 on one box, alternating runs: before, the N-term one was back first)
+    q_pending = _unfold_commitment(Q, deferred, order, aux, wait=False)
     pending = pivot._commit_launch(v, gamma, g_hat, k, ctx)
-    Q_final = _unfold_commitment(Q, deferred, order, aux)
-    return bool(pending.result() == Q_final)
+    return bool(pending.result() == q_pending.result())
 
 
 def _final_check_host(g_prime, k, L_tilde, z_prime, order):
