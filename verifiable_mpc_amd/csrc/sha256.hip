@@ -7,7 +7,9 @@
 // whole text and cannot be split; it stays on the host's hashlib.)
 #include "common.h"
 
+#ifndef SHA_BLOCK
 #define SHA_BLOCK 256
+#endif
 
 __device__ __constant__ uint32_t SHA_K[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
@@ -55,17 +57,29 @@ k_sha256_chunks(const uint8_t *__restrict__ data, size_t nbytes, size_t chunk, s
     uint32_t w[16];
     size_t full = len / 64;
     const bool aligned = ((uintptr_t)p & 15) == 0;
+    // (aligned: the NEXT block's 64 bytes are requested before this block is compressed - a lane walks its own chunk,
+    // 64 lanes touch 64 different lines per request, and with one wave per SIMD nothing else hides that latency)
+    uint4 nxt[4];
+    if (aligned && full) {
+        const uint4 *q4 = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+        for (int i = 0; i < 4; i++) nxt[i] = q4[i];
+    }
     for (size_t b = 0; b < full; b++) {
         const uint8_t *q = p + 64 * b;
         if (aligned) {
-            const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                uint4 v = q4[i];
+                const uint4 v = nxt[i];
                 w[4 * i] = __builtin_bswap32(v.x);
                 w[4 * i + 1] = __builtin_bswap32(v.y);
                 w[4 * i + 2] = __builtin_bswap32(v.z);
                 w[4 * i + 3] = __builtin_bswap32(v.w);
+            }
+            if (b + 1 < full) {
+                const uint4 *q4 = reinterpret_cast<const uint4 *>(q + 64);
+#pragma unroll
+                for (int i = 0; i < 4; i++) nxt[i] = q4[i];
             }
         } else {
 #pragma unroll
@@ -75,20 +89,39 @@ k_sha256_chunks(const uint8_t *__restrict__ data, size_t nbytes, size_t chunk, s
         }
         sha_compress(st, w);
     }
-    // tail + padding (one or two blocks)
-    size_t rem = len - 64 * full;
-    uint8_t tail[128];
-    for (int i = 0; i < 128; i++) tail[i] = 0;
-    for (size_t i = 0; i < rem; i++) tail[i] = p[64 * full + i];
-    tail[rem] = 0x80;
-    int blocks = rem < 56 ? 1 : 2;
-    uint64_t bits = (uint64_t)len * 8;
-    for (int i = 0; i < 8; i++) tail[64 * blocks - 1 - i] = (uint8_t)(bits >> (8 * i));
-    for (int b = 0; b < blocks; b++) {
-        for (int i = 0; i < 16; i++)
-            w[i] = ((uint32_t)tail[64 * b + 4 * i] << 24) | ((uint32_t)tail[64 * b + 4 * i + 1] << 16) |
-                   ((uint32_t)tail[64 * b + 4 * i + 2] << 8) | tail[64 * b + 4 * i + 3];
+    // tail + padding (one or two blocks).  A chunk that is a whole number of blocks - every 4096-byte leaf but a
+    // buffer's last - ends with ONE constant block; the general case builds its words byte by byte from a function of
+    // the position (a byte array indexed at run time became 56 000 instructions of lane-indexed register moves: as much
+    // time as thirty blocks, for every lane).
+    const size_t rem = len - 64 * full;
+    const uint64_t bits = (uint64_t)len * 8;
+    if (rem == 0) {
+        w[0] = 0x80000000u;
+#pragma unroll
+        for (int i = 1; i < 14; i++) w[i] = 0;
+        w[14] = (uint32_t)(bits >> 32);
+        w[15] = (uint32_t)bits;
         sha_compress(st, w);
+    } else {
+        const int blocks = rem < 56 ? 1 : 2;
+        const uint8_t *t = p + 64 * full;
+        for (int b = 0; b < blocks; b++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const size_t pos = (size_t)64 * b + 4 * i + k;                // position in the padded tail
+                    uint32_t byte = 0;
+                    if (pos < rem) byte = t[pos];
+                    else if (pos == rem) byte = 0x80;
+                    else if (pos >= (size_t)64 * blocks - 8) byte = (uint32_t)(bits >> (8 * ((size_t)64 * blocks - 1 - pos))) & 0xffu;
+                    word = (word << 8) | byte;
+                }
+                w[i] = word;
+            }
+            sha_compress(st, w);
+        }
     }
     for (int i = 0; i < 8; i++) out[8 * ci + i] = __builtin_bswap32(st[i]);   // big-endian digest bytes
 }
