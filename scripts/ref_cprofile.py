@@ -7,9 +7,9 @@ def rs(rng, n):
 k = 20
 ctx = vm.get_context(); rng = np.random.default_rng(3); n = (1 << k) - 1
 group = vm.EllipticCurve("Ed25519", "projective"); gf = vm.GF(group.order)
-g = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(rs(rng, n)))
+g = vm.PointVector.fixed_base(group.generator, vm.ScalarVector.from_array(rs(rng, n)), keep_proj=True)
 gens = {"g": g, "h": group.generator, "k": vm.Ed25519Point.repeat(group.generator, 12345)}
-g.precompute([gens["h"], gens["k"]])
+g.precompute([gens["h"], gens["k"]], wide=True)
 x = vm.ScalarVector.from_array(rs(rng, n)); L = vm.pivot.LinearForm(vm.ScalarVector.from_array(rs(rng, n)))
 y = gf(L(x)); P = vm.pivot.vector_commitment(x, 777, g, gens["h"])
 for rep in range(2):
